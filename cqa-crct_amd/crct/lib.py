@@ -1,0 +1,124 @@
+"""ctypes binding of libcrct_hip.so (C ABI declared in include/crct_hip.h).
+
+The library is built in-tree by ``cqa-crct_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is NO fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrct_hip.so")
+
+c_i32, c_i64, c_u32, c_u64, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+vp = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("preact_out", vp), ("dact_src", vp), ("addend", vp),
+                ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ld_aux", c_i64), ("ld_add", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ta", c_i32), ("tb", c_i32), ("act", c_i32), ("dact", c_i32),
+                ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
+                ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("pooled_t", vp), ("pooled_v", vp), ("fus_h", vp), ("w_cls", vp), ("b_cls", vp), ("w_f6", vp), ("b_f6", vp),
+                ("R", vp), ("labels", vp), ("logits", vp), ("reg", vp), ("stats", vp), ("scratch", vp),
+                ("d_pooled_t", vp), ("d_pooled_v", vp), ("d_fus_h", vp),
+                ("d_w_cls", vp), ("d_b_cls", vp), ("d_w_f6", vp), ("d_b_f6", vp), ("loss_scale_dev", vp),
+                ("B", c_i32), ("Hb", c_i32), ("fusion_sum", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32),
+                ("tol_margin", c_f32), ("nsp_coeff", c_f32), ("reg_coeff", c_f32), ("grad_scale", c_f32),
+                ("drop_thr", c_u32), ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64)]
+
+
+class ModelDims(C.Structure):
+    _fields_ = [("vocab", c_i32), ("n_pos", c_i32), ("n_types", c_i32), ("H", c_i32), ("L", c_i32), ("heads", c_i32), ("I", c_i32),
+                ("Fv", c_i32), ("Hv", c_i32), ("Lv", c_i32), ("v_heads", c_i32), ("Iv", c_i32), ("Hb", c_i32), ("b_heads", c_i32),
+                ("n_color", c_i32), ("n_conn", c_i32), ("v_biatt", c_i32 * 32), ("t_biatt", c_i32 * 32),
+                ("fusion_sum", c_i32), ("with_coattention", c_i32),
+                ("p_hidden", c_f32), ("p_attn", c_f32), ("p_v_hidden", c_f32), ("p_v_attn", c_f32), ("p_cls", c_f32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("tokens", vp), ("segments", vp), ("loc", vp), ("text_keymask", vp), ("image_feat", vp), ("image_loc", vp),
+                ("image_target", vp), ("image_keymask", vp), ("R", vp), ("labels", vp),
+                ("B", c_i32), ("T", c_i32), ("V", c_i32)]
+
+
+class StepCfg(C.Structure):
+    _fields_ = [("training", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32), ("tol_margin", c_f32), ("nsp_coeff", c_f32),
+                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("loss_scale_dev", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/crct_hip.h declares
+_u8 = [c_u32, c_f32, c_u32, c_u64]   # drop_thr, drop_scale, drop_site, seed
+PROTOTYPES = {
+    "crct_last_error": (C.c_char_p, []),
+    "crct_abi_version": (C.c_int, []),
+    "crct_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "crct_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp]),
+    "crct_layernorm_bwd_blocks": (C.c_int, [C.c_int]),
+    "crct_layernorm_bwd": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, c_u32, c_f32, c_u32, c_u32, c_f32, c_u32, c_u64, vp]),
+    "crct_colsum_blocks": (C.c_int, [C.c_int]),
+    "crct_colsum_bf16": (C.c_int, [vp, c_i64, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
+    "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
+    "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
+    "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),
+    "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp]),
+    "crct_embed_image_fwd": (C.c_int, [vp] * 12 + [C.c_int] * 2 + [c_f32] + _u8 + [vp]),
+    "crct_embed_image_bwd": (C.c_int, [vp] * 15 + [C.c_int] * 2 + _u8 + [vp]),
+    "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
+    "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
+    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp]),
+    "crct_engine_create": (vp, [C.POINTER(ModelDims), C.c_char_p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crct_engine_destroy": (None, [vp]),
+    "crct_engine_workspace_bytes": (C.c_size_t, [vp]),
+    "crct_engine_num_segments": (C.c_int, [vp]),
+    "crct_engine_segment_range": (C.c_int, [vp, C.c_int, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "crct_engine_forward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp]),
+    "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
+    "crct_engine_tap": (c_i64, [vp, vp, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcrct_hip.so; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libcrct_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "-- there is no CPU fallback for the CRCT step" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libcrct_hip %s failed (%d): %s" % (what, rc, load().crct_last_error().decode()))
+
+
+def drop_threshold(p):
+    t = float(p) * 4294967296.0
+    if t <= 0.0:
+        return 0
+    return min(int(t), 4294967295)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,147 @@
+"""Thin torch-tensor wrappers over the kernel launchers of libcrct_hip.so.
+
+torch is used only for device memory and the current HIP stream; every computation below is one
+C-ABI call into the hand-written gfx950 kernels (include/crct_hip.h).  bf16 tensors are passed as
+``torch.bfloat16``; all tensors must be contiguous CUDA tensors.  These wrappers exist for the kernel
+parity tests and for building blocks outside the step engine; the training step itself goes
+through ``crct.engine`` (one native call per forward / backward).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+ACT = dict(none=0, gelu=1, relu=2, leaky=3, tanh=4)
+
+
+def _chk(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libcrct_hip kernels need CUDA (HIP) tensors; got a %s tensor -- no CPU fallback" % t.device)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("expected %s, got %s" % (dtype, t.dtype))
+    return t
+
+
+def _drop(p, site):
+    thr = L.drop_threshold(p)
+    return thr, (1.0 / (1.0 - p) if thr else 1.0), int(site)
+
+
+def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
+         preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
+         accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0):
+    lib = L.load()
+    _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    g = L.GemmArgs()
+    g.A, g.B, g.C = L.ptr(A), L.ptr(B), L.ptr(out)
+    g.bias, g.preact_out, g.dact_src, g.addend = L.ptr(bias), L.ptr(preact_out), L.ptr(dact_src), L.ptr(addend)
+    g.lda = lda if lda is not None else (M if ta else K)
+    g.ldb = ldb if ldb is not None else (N if tb else K)
+    g.ldc = ldc if ldc is not None else N
+    g.ld_aux = ld_aux if ld_aux is not None else N
+    g.ld_add = ld_add if ld_add is not None else N
+    g.M, g.N, g.K, g.ta, g.tb = M, N, K, int(ta), int(tb)
+    g.act, g.dact, g.c_is_f32, g.accumulate, g.tile, g.alpha = ACT[act], ACT[dact], int(out.dtype == torch.float32), int(accumulate), tile, alpha
+    g.drop_thr, g.drop_scale, g.drop_site = _drop(p_drop, site)
+    g.seed = seed
+    L.check(lib.crct_gemm_bf16(C.byref(g), L.current_stream()), "gemm")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-12, p_drop=0.0, site=0, seed=0):
+    lib = L.load()
+    M, H = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    thr, sc, st = _drop(p_drop, site)
+    L.check(lib.crct_layernorm_fwd(L.ptr(_chk(x, torch.bfloat16)), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                   M, H, eps, thr, sc, st, seed, L.current_stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, want_lin=False, p_lin=0.0, lin_site=0, p_post=0.0, post_site=0, seed=0,
+                  dgamma=None, dbeta=None, dbias=None, accumulate=False):
+    lib = L.load()
+    M, H = x.shape
+    dx = torch.empty_like(x)
+    dxl = torch.empty_like(x) if want_lin else None
+    nb = lib.crct_layernorm_bwd_blocks(M)
+    part = torch.empty(3 * nb * H, device=x.device, dtype=torch.float32)
+    dgamma = torch.zeros(H, device=x.device) if dgamma is None else dgamma
+    dbeta = torch.zeros(H, device=x.device) if dbeta is None else dbeta
+    dbias = torch.zeros(H, device=x.device) if dbias is None else dbias
+    pt, ps, psite = _drop(p_post, post_site)
+    lt, ls, lsite = _drop(p_lin, lin_site)
+    L.check(lib.crct_layernorm_bwd(L.ptr(_chk(dy, torch.bfloat16)), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dx), L.ptr(dxl),
+                                   L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(part), M, H, int(accumulate),
+                                   pt, ps, psite, lt, ls, lsite, seed, L.current_stream()), "layernorm_bwd")
+    return dx, dxl, dgamma, dbeta, dbias
+
+
+def colsum(x, M, N, ld=None, out=None, accumulate=False):
+    lib = L.load()
+    nb = lib.crct_colsum_blocks(M)
+    part = torch.empty(nb * N, device=x.device, dtype=torch.float32)
+    out = torch.zeros(N, device=x.device) if out is None else out
+    L.check(lib.crct_colsum_bf16(L.ptr(_chk(x, torch.bfloat16)), ld if ld is not None else N, L.ptr(out), L.ptr(part), M, N,
+                                 int(accumulate), L.current_stream()), "colsum")
+    return out
+
+
+def softmax_rows(x):
+    lib = L.load()
+    M, F = x.shape
+    y = torch.empty(M, F, device=x.device, dtype=torch.bfloat16)
+    L.check(lib.crct_softmax_rows_f32_bf16(L.ptr(_chk(x, torch.float32)), L.ptr(y), M, F, L.current_stream()), "softmax_rows")
+    return y
+
+
+def cast_bf16(x, out=None):
+    lib = L.load()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if out is None else out
+    L.check(lib.crct_cast_f32_bf16(L.ptr(_chk(x, torch.float32)), L.ptr(out), x.numel(), L.current_stream()), "cast")
+    return out
+
+
+def attention_fwd(q, k, v, keymask, heads, d, p_drop=0.0, site=0, seed=0):
+    """q [B,Tq,ldq] / k,v [B,Tk,ld*] bf16 (may be column slices of a wider buffer: pass the *slice*)."""
+    lib = L.load()
+    B, Tq = q.shape[0], q.shape[1]
+    Tk = k.shape[1]
+    ctx = torch.empty(B, Tq, heads * d, device=q.device, dtype=torch.bfloat16)
+    thr, sc, st = _drop(p_drop, site)
+    L.check(lib.crct_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(_chk(keymask, torch.uint8)), L.ptr(ctx), B, heads, Tq, Tk, d,
+                                   q.stride(1), k.stride(1), v.stride(1), heads * d, thr, sc, st, seed, L.current_stream()),
+            "attention_fwd")
+    return ctx
+
+
+def attention_bwd(q, k, v, keymask, dctx, heads, d, p_drop=0.0, site=0, seed=0):
+    lib = L.load()
+    B, Tq = q.shape[0], q.shape[1]
+    Tk = k.shape[1]
+    dq = torch.empty(B, Tq, heads * d, device=q.device, dtype=torch.bfloat16)
+    dk = torch.empty(B, Tk, heads * d, device=q.device, dtype=torch.bfloat16)
+    dv = torch.empty_like(dk)
+    thr, sc, st = _drop(p_drop, site)
+    L.check(lib.crct_attention_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(keymask), L.ptr(_chk(dctx, torch.bfloat16)), L.ptr(dq), L.ptr(dk), L.ptr(dv),
+                                   B, heads, Tq, Tk, d, q.stride(1), k.stride(1), v.stride(1), dctx.stride(1),
+                                   heads * d, heads * d, heads * d, thr, sc, st, seed, L.current_stream()), "attention_bwd")
+    return dq, dk, dv
+
+
+def adamw_plan(seg_len):
+    """Host-side block table for crct_adamw_step: returns (blk_seg int32[n], blk_off int64[n])."""
+    lib = L.load()
+    lens = torch.as_tensor(seg_len, dtype=torch.int64)
+    n = lib.crct_adamw_plan(lens.data_ptr(), lens.numel(), None, None, 0)
+    blk_seg = torch.empty(n, dtype=torch.int32)
+    blk_off = torch.empty(n, dtype=torch.int64)
+    lib.crct_adamw_plan(lens.data_ptr(), lens.numel(), blk_seg.data_ptr(), blk_off.data_ptr(), n)
+    return blk_seg, blk_off

@@ -1,0 +1,88 @@
+// Shared device helpers for the CRCT gfx950 kernels (wave64, bf16 storage / fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CRCT_WAVE 64
+
+typedef __attribute__((ext_vector_type(4))) short s4_t;
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+typedef unsigned short bf16_t;   // raw bf16 bits in memory
+
+// ------------------------------------------------------------------ bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even through the hardware convert (keeps NaN a NaN, MI355X_MICROARCH.md)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ------------------------------------------------------------------ wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 (counter based RNG)
+// Dropout masks are never stored: forward and backward regenerate them from
+// (seed, site, element index).  One call yields 4 x u32 for elements idx..idx+3 (idx % 4 == 0).
+struct Philox4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, uint64_t idx4) {
+  uint32_t c0 = (uint32_t)idx4, c1 = (uint32_t)(idx4 >> 32), c2 = site, c3 = 0x9E3779B9u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// keep-threshold for drop probability p: keep iff u32 >= thr
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t <= 0.0) return 0u;
+  if (t >= 4294967295.0) return 4294967295u;
+  return (uint32_t)t;
+}
+
+// ------------------------------------------------------------------ activations
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LEAKY = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float kInvSqrt2Pi = 0.3989422804014327f;
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case ACT_GELU: return gelu_erf(x);
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
+    case ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+// derivative given `s`: the saved PRE-activation for GELU, the saved OUTPUT for relu/leaky/tanh
+__device__ __forceinline__ float act_grad(int act, float s) {
+  switch (act) {
+    case ACT_GELU: return gelu_erf_grad(s);
+    case ACT_RELU: return s > 0.f ? 1.f : 0.f;
+    case ACT_LEAKY: return s > 0.f ? 1.f : 0.01f;
+    case ACT_TANH: return 1.f - s * s;
+    default: return 1.f;
+  }
+}

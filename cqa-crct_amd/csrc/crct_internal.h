@@ -1,0 +1,24 @@
+// Internal declarations shared by the kernel translation units and the step engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/crct_hip.h"
+
+void crct_set_error(const char* fmt, ...);
+#define CRCT_CHECK_HIP(expr)                                                          \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      crct_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+#define CRCT_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      crct_set_error(__VA_ARGS__);              \
+      return 2;                                 \
+    }                                           \
+  } while (0)
+
+hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s);
+int crct_gemm_pick_tile(int M, int N);

@@ -1,0 +1,771 @@
+// Step engine: schedules the hand-written gfx950 kernels for one CRCT training step
+// (forward + joint loss + backward) on one HIP stream, without host synchronisation.
+//
+// Reference path it replaces (levymsn/CQA-CRCT):
+//   encoder_decorator.forward            CRCT/backbone/encoder_decorator.py:73-158
+//   BertForMultiModalPreTraining.forward CRCT/backbone/vilbert.py:1540-1661
+//   BertModel.forward / BertEncoder      vilbert.py:1348-1441 / :822-946 (layer order :852-939)
+//   BertLayer / BertImageLayer           vilbert.py:361-485 / :488-616
+//   BertConnectionLayer                  vilbert.py:619-788
+//   poolers, heads, regressor            vilbert.py:949-976, :1048-1062; regressor.py:5-42
+//   + torch autograd of all of it (train.py:208).
+//
+// Data layout in HBM: parameters live in ONE flat fp32 buffer (and a bf16 shadow with identical
+// element offsets) ordered by first use, so the gradient buffer completes back-to-front during
+// backward and contiguous ranges can be all-reduced while earlier layers are still computing.
+// query/key/value weights of a layer are adjacent -> one [3H, H] fused-QKV GEMM operand.
+// Activations kept for backward are bf16 in a caller-provided workspace.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "crct_internal.h"
+
+typedef unsigned short bf16_t;
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LEAKY = 3, ACT_TANH = 4 };
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void crct_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* crct_last_error(void) { return g_err; }
+extern "C" int crct_abi_version(void) { return 1; }
+
+extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
+  CRCT_REQUIRE(a != nullptr, "gemm: null args");
+  CRCT_REQUIRE(a->A && a->B && a->C, "gemm: null operand");
+  CRCT_REQUIRE(a->N % 4 == 0, "gemm: N=%d must be a multiple of 4", a->N);
+  CRCT_REQUIRE(a->K % 8 == 0, "gemm: K=%d must be a multiple of 8", a->K);
+  CRCT_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", (long)a->lda, (long)a->ldb);
+  CRCT_REQUIRE(a->ldc % 4 == 0, "gemm: ldc=%ld must be a multiple of 4", (long)a->ldc);
+  CRCT_REQUIRE(!(a->ta && !a->tb), "gemm: (ta=1, tb=0) is not built (not used by the step)");
+  CRCT_REQUIRE(!a->ta || a->M % 8 == 0, "gemm: transposed A needs M %% 8 == 0 (M=%d)", a->M);
+  CRCT_REQUIRE(!a->tb || a->N % 8 == 0, "gemm: transposed B needs N %% 8 == 0 (N=%d)", a->N);
+  CRCT_CHECK_HIP(crct_gemm_launch(*a, (hipStream_t)stream));
+  return 0;
+}
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline uint32_t thr_of(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t <= 0.0) return 0u;
+  if (t >= 4294967295.0) return 4294967295u;
+  return (uint32_t)t;
+}
+
+struct Arena {
+  size_t top = 0;
+  size_t take(size_t bytes) { size_t o = top; top = align_up(top + bytes, 256); return o; }
+};
+
+struct Drop { uint32_t thr = 0; float scale = 1.f; uint32_t site = 0; };
+
+// ---- parameter offsets (elements into the flat buffers)
+struct LinearP { int64_t w = -1, b = -1; int in = 0, out = 0; };
+struct LnP { int64_t g = -1, b = -1; };
+struct FfnP { LinearP up, down; LnP ln; };
+struct ProjP { LinearP dense; LnP ln; };      // LN(dropout(dense(ctx)) + residual)
+struct SelfLayerP { LinearP qkv; ProjP proj; FfnP ffn; int H, heads; float p_attn, p_hid; uint32_t site; };
+struct ConnLayerP { LinearP qkv1, qkv2; ProjP proj_v, proj_t; FfnP ffn_v, ffn_t; uint32_t site; };
+
+// ---- activation offsets (bytes into the workspace)
+struct FfnA { size_t u, h, s, y, mean, rstd; };
+struct ProjA { size_t s, a, mean, rstd; };
+struct SelfLayerA { size_t qkv, ctx; ProjA proj; FfnA ffn; };
+struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
+struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv; };
+
+struct Step { char kind; int idx; };
+struct Tap { std::string name; size_t off; char stream; };
+
+}  // namespace
+
+struct crct_engine {
+  CrctModelDims d;
+  std::unordered_map<std::string, int64_t> off, size;
+  int maxB, maxT, maxV;
+  std::vector<Step> sched;
+  std::vector<SelfLayerP> tl, vl;
+  std::vector<ConnLayerP> cl;
+  std::vector<SelfLayerA> tla, vla;
+  std::vector<ConnLayerA> cla;
+  struct { int64_t word, pos, type, wloc, bloc; LnP ln; } et;
+  struct { LinearP img; int64_t color, wloc, bloc; LnP ln; } ev;
+  struct { size_t sum, y, mean, rstd; } eta;
+  struct { size_t soft, lin, sum, y, mean, rstd; } eva;
+  LinearP t_pool, v_pool, cls, tp[4], vp[4], fu[4];
+  struct { size_t pooled_t, pooled_v, t[3], v[3], cat, f[3], scratch, d_pt, d_pv, g[4]; } ha;
+  StreamScratch st, sv;
+  size_t partials, colsum_part;
+  size_t ws_bytes = 0;
+  std::vector<std::pair<int64_t, int64_t>> seg_range;
+  std::vector<Tap> taps;
+  size_t final_t = 0, final_v = 0;   // offsets of the last-layer outputs
+  int cur_t = 0, cur_v = 0;          // ping-pong index of the running activation gradients
+  bool bad = false;
+  int64_t P(const std::string& k) {
+    auto it = off.find(k);
+    if (it == off.end()) { crct_set_error("engine: parameter '%s' missing from the layout", k.c_str()); bad = true; return 0; }
+    return it->second;
+  }
+};
+
+namespace {
+
+LinearP linear_p(crct_engine* e, const std::string& name, int in, int out) {
+  LinearP l;
+  l.w = e->P(name + ".weight"); l.b = e->P(name + ".bias"); l.in = in; l.out = out;
+  return l;
+}
+LnP ln_p(crct_engine* e, const std::string& name) {
+  LnP l; l.g = e->P(name + ".weight"); l.b = e->P(name + ".bias"); return l;
+}
+// three Linear(in, out) stored back to back -> one Linear(in, 3*out)
+LinearP fused3(crct_engine* e, const std::string& a, const std::string& b, const std::string& c, int in, int out) {
+  LinearP l = linear_p(e, a, in, 3 * out);
+  const int64_t wsz = (int64_t)in * out;
+  if (e->P(b + ".weight") != l.w + wsz || e->P(c + ".weight") != l.w + 2 * wsz || e->P(b + ".bias") != l.b + out ||
+      e->P(c + ".bias") != l.b + 2 * out) {
+    crct_set_error("engine: %s / %s / %s must be adjacent in the flat layout (fused QKV)", a.c_str(), b.c_str(), c.c_str());
+    e->bad = true;
+  }
+  return l;
+}
+
+FfnA ffn_a(Arena& ar, size_t M, int H, int I) {
+  FfnA a;
+  a.u = ar.take(M * I * 2); a.h = ar.take(M * I * 2); a.s = ar.take(M * H * 2); a.y = ar.take(M * H * 2);
+  a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
+  return a;
+}
+ProjA proj_a(Arena& ar, size_t M, int H) {
+  ProjA a;
+  a.s = ar.take(M * H * 2); a.a = ar.take(M * H * 2); a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
+  return a;
+}
+StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
+  StreamScratch s;
+  const int Hm = H > Hb ? H : Hb;
+  s.dy[0] = ar.take(M * H * 2); s.dy[1] = ar.take(M * H * 2);
+  s.dres_a = ar.take(M * H * 2); s.dlin_a = ar.take(M * H * 2); s.dres_b = ar.take(M * H * 2); s.dlin_b = ar.take(M * H * 2);
+  s.gc = ar.take(M * H * 2); s.du = ar.take(M * (size_t)I * 2); s.dctx = ar.take(M * (size_t)Hm * 2);
+  s.dqkv = ar.take(M * (size_t)3 * Hm * 2);
+  return s;
+}
+
+// ================================================================================ per-call context
+struct Run {
+  crct_engine* e;
+  const float* p32; const bf16_t* p16; float* g32; char* ws; hipStream_t s;
+  const CrctBatch* b; const CrctStepCfg* c;
+  int rc = 0;
+
+  template <class T> T* W(size_t o) const { return reinterpret_cast<T*>(ws + o); }
+  bf16_t* A(size_t o) const { return W<bf16_t>(o); }
+  float* F(size_t o) const { return W<float>(o); }
+  const float* P(int64_t o) const { return p32 + o; }
+  const bf16_t* PB(int64_t o) const { return p16 + o; }
+  float* G(int64_t o) const { return g32 + o; }
+  Drop drop(float p, uint32_t site) const {
+    Drop d; d.site = site;
+    if (c->training && p > 0.f) { d.thr = thr_of(p); d.scale = 1.0f / (1.0f - p); }
+    return d;
+  }
+  void fail(int r) { if (!rc && r) rc = r; }
+
+  struct Opt {
+    const float* bias = nullptr; void* preact = nullptr; const void* dact_src = nullptr; int dact = 0; int act = 0;
+    const void* addend = nullptr; int64_t ld_aux = 0, ld_add = 0; Drop drop; bool f32 = false; bool acc = false;
+  };
+  void gemm(const void* Ap, int64_t lda, bool ta, const void* Bp, int64_t ldb, bool tb, void* C, int64_t ldc, int M, int N,
+            int K, const Opt& o) {
+    if (rc) return;
+    CrctGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = Ap; g.B = Bp; g.C = C; g.bias = o.bias; g.preact_out = o.preact; g.dact_src = o.dact_src; g.addend = o.addend;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
+    g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
+    g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
+    fail(crct_gemm_bf16(&g, s));
+  }
+  // y[M][out] = x W^T + b (+ epilogue)
+  void lin_fwd(const void* x, int64_t ldx, const LinearP& l, int M, void* y, int64_t ldy, Opt o) {
+    o.bias = P(l.b);
+    gemm(x, ldx, false, PB(l.w), l.in, false, y, ldy, M, l.out, l.in, o);
+  }
+  // dW[out][in] += dy^T x
+  void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M) {
+    Opt o; o.f32 = true; o.acc = true;
+    gemm(dy, lddy, true, x, ldx, true, G(l.w), l.in, l.out, l.in, M, o);
+  }
+  // dx[M][in] = dy W (+ epilogue)
+  void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, const Opt& o) {
+    gemm(dy, lddy, false, PB(l.w), l.in, true, dx, lddx, M, l.in, l.out, o);
+  }
+  void bias_grad(const void* dy, int64_t lddy, const LinearP& l, int M) {
+    if (rc) return;
+    fail(crct_colsum_bf16(dy, lddy, G(l.b), F(e->colsum_part), M, l.out, 1, s));
+  }
+  void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H) {
+    if (rc) return;
+    fail(crct_layernorm_fwd(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, s));
+  }
+  // returns the buffer that holds the gradient of the producing Linear's output
+  size_t ln_bwd(size_t dy, size_t x, size_t mean, size_t rstd, const LnP& ln, const LinearP& lin, size_t dres, size_t dlin,
+                int M, int H, const Drop& dr) {
+    if (rc) return dres;
+    fail(crct_layernorm_bwd(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, G(ln.g), G(ln.b),
+                            G(lin.b), F(e->partials), M, H, 1, 0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
+    return dr.thr ? dlin : dres;
+  }
+  void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
+                int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr) {
+    if (rc) return;
+    fail(crct_attention_fwd(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, c->seed, s));
+  }
+  void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
+                const bf16_t* dctx, int64_t ldo, bf16_t* dq, int64_t lddq, bf16_t* dk, bf16_t* dv, int64_t lddk, int B,
+                int heads, int Tq, int Tk, int d, const Drop& dr) {
+    if (rc) return;
+    fail(crct_attention_bwd(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr,
+                            dr.scale, dr.site, c->seed, s));
+  }
+
+  // ---------------------------------------------------------------- sub-blocks
+  // a = LN(dropout(dense(ctx)) + x)          vilbert.py:424-428 / :555-559 / :749-756
+  void proj_fwd(const ProjP& p, const ProjA& a, size_t ctx, size_t x, int M, const Drop& dr) {
+    Opt o; o.drop = dr; o.addend = A(x); o.ld_add = p.dense.out;
+    lin_fwd(A(ctx), p.dense.in, p.dense, M, A(a.s), p.dense.out, o);
+    ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out);
+  }
+  // in: g = grad of a.  out: dres (residual gradient), dctx.  Parameter gradients accumulated.
+  void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, int M, const Drop& dr) {
+    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.dense, dres, dlin, M, p.dense.out, dr);
+    lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M);
+    lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
+  }
+  // y = LN(dropout(down(gelu(up(x)))) + x)   vilbert.py:454-471 / :585-602 / :782-786
+  void ffn_fwd(const FfnP& p, const FfnA& a, size_t x, int M, const Drop& dr) {
+    Opt o; o.preact = A(a.u); o.ld_aux = p.up.out; o.act = ACT_GELU;
+    lin_fwd(A(x), p.up.in, p.up, M, A(a.h), p.up.out, o);
+    Opt o2; o2.drop = dr; o2.addend = A(x); o2.ld_add = p.down.out;
+    lin_fwd(A(a.h), p.down.in, p.down, M, A(a.s), p.down.out, o2);
+    ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out);
+  }
+  // in: g = grad of a.y.  out: gx = grad of x.
+  void ffn_bwd(const FfnP& p, const FfnA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc, int M, const Drop& dr) {
+    const int H = p.down.out, I = p.up.out;
+    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.down, sc.dres_a, sc.dlin_a, M, H, dr);
+    lin_wgrad(A(dl), H, A(a.h), I, p.down, M);
+    Opt o; o.dact_src = A(a.u); o.dact = ACT_GELU; o.ld_aux = I;
+    lin_dgrad(A(dl), H, p.down, M, A(sc.du), I, o);
+    bias_grad(A(sc.du), I, p.up, M);
+    lin_wgrad(A(sc.du), I, A(x), H, p.up, M);
+    Opt o2; o2.addend = A(sc.dres_a); o2.ld_add = H;
+    lin_dgrad(A(sc.du), I, p.up, M, A(gx), H, o2);
+  }
+
+  // ---------------------------------------------------------------- self-attention layer
+  void self_fwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, const uint8_t* km, int B, int T) {
+    const int M = B * T, H = p.H, d = H / p.heads;
+    lin_fwd(A(x), H, p.qkv, M, A(a.qkv), 3 * H, Opt());
+    attn_fwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(a.ctx), H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
+    proj_fwd(p.proj, a.proj, a.ctx, x, M, drop(p.p_hid, p.site + 1));
+    ffn_fwd(p.ffn, a.ffn, a.proj.a, M, drop(p.p_hid, p.site + 2));
+  }
+  void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc,
+                const uint8_t* km, int B, int T) {
+    const int M = B * T, H = p.H, d = H / p.heads;
+    ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
+    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, M, drop(p.p_hid, p.site + 1));
+    attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
+             A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
+    bias_grad(A(sc.dqkv), 3 * H, p.qkv, M);
+    lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M);
+    Opt o; o.addend = A(sc.dres_b); o.ld_add = H;
+    lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
+  }
+
+  // ---------------------------------------------------------------- connection layer (vilbert.py:774-788)
+  void conn_fwd(const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt) {
+    const CrctModelDims& D = e->d;
+    const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
+    lin_fwd(A(xv), D.Hv, p.qkv1, Mv, A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
+    lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());      // query2/key2/value2  :673-675
+    // text queries over visual keys/values -> ctx1 [B,T,Hb]  :684-701 (dropout1 = v_attention prob)
+    attn_fwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(a.ctx1), Hb, B, D.b_heads,
+             b->T, b->V, d, drop(D.p_v_attn, p.site));
+    // visual queries over text keys/values -> ctx2 [B,V,Hb]  :704-723
+    attn_fwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(a.ctx2), Hb, B, D.b_heads,
+             b->V, b->T, d, drop(D.p_attn, p.site + 1));
+    // cross wiring :780 -- visual stream takes ctx2, text stream takes ctx1
+    proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2));
+    proj_fwd(p.proj_t, a.proj_t, a.ctx1, xt, Mt, drop(D.p_hidden, p.site + 3));
+    ffn_fwd(p.ffn_v, a.ffn_v, a.proj_v.a, Mv, drop(D.p_v_hidden, p.site + 4));
+    ffn_fwd(p.ffn_t, a.ffn_t, a.proj_t.a, Mt, drop(D.p_hidden, p.site + 5));
+  }
+  void conn_bwd(const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
+    const CrctModelDims& D = e->d;
+    const StreamScratch& sv = e->sv; const StreamScratch& st = e->st;
+    const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
+    ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
+    ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
+    proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
+    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, Mt, drop(D.p_hidden, p.site + 3));     // dctx1 [Mt,Hb]
+    // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]
+    attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
+             3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site));
+    // ctx2 = attn(q1, k2, v2): dq1 -> dqkv1[:, 0:Hb], dk2/dv2 -> dqkv2[:, Hb:3Hb]
+    attn_bwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(sv.dctx), Hb, A(sv.dqkv),
+             3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1));
+    bias_grad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv);
+    lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv);
+    Opt ov; ov.addend = A(sv.dres_b); ov.ld_add = D.Hv;
+    lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
+    bias_grad(A(st.dqkv), 3 * Hb, p.qkv2, Mt);
+    lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt);
+    Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
+    lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
+  }
+
+  // ---------------------------------------------------------------- embeddings
+  void embed_fwd() {
+    const CrctModelDims& D = e->d;
+    const int B = b->B, Mv = B * b->V;
+    const Drop dt = drop(D.p_hidden, 1), dv = drop(D.p_hidden, 2);   // both use hidden_dropout_prob (vilbert.py:315,1470)
+    if (!rc) fail(crct_embed_text_fwd(b->tokens, b->segments, b->loc, P(e->et.word), P(e->et.pos), P(e->et.type), P(e->et.wloc),
+                                      P(e->et.bloc), P(e->et.ln.g), P(e->et.ln.b), A(e->eta.sum), A(e->eta.y), F(e->eta.mean),
+                                      F(e->eta.rstd), B, b->T, D.H, D.n_pos, 1e-12f, dt.thr, dt.scale, dt.site, c->seed, s));
+    if (!rc) fail(crct_softmax_rows_f32_bf16(b->image_feat, A(e->eva.soft), Mv, D.Fv, s));
+    lin_fwd(A(e->eva.soft), D.Fv, e->ev.img, Mv, A(e->eva.lin), D.Hv, Opt());
+    if (!rc) fail(crct_embed_image_fwd(A(e->eva.lin), b->image_loc, b->image_target, P(e->ev.wloc), P(e->ev.bloc), P(e->ev.color),
+                                       P(e->ev.ln.g), P(e->ev.ln.b), A(e->eva.sum), A(e->eva.y), F(e->eva.mean), F(e->eva.rstd),
+                                       Mv, D.Hv, 1e-12f, dv.thr, dv.scale, dv.site, c->seed, s));
+  }
+  void embed_bwd(size_t gt, size_t gv) {
+    const CrctModelDims& D = e->d;
+    const int B = b->B, Mv = B * b->V;
+    const Drop dt = drop(D.p_hidden, 1), dv = drop(D.p_hidden, 2);
+    if (!rc) fail(crct_embed_text_bwd(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
+                                      P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
+                                      G(e->et.ln.g), G(e->et.ln.b), F(e->partials), B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
+                                      dt.site, c->seed, s));
+    if (!rc) fail(crct_embed_image_bwd(A(gv), A(e->eva.sum), F(e->eva.mean), F(e->eva.rstd), b->image_loc, b->image_target,
+                                       P(e->ev.ln.g), A(e->sv.gc), G(e->ev.color), G(e->ev.wloc), G(e->ev.bloc), G(e->ev.img.b),
+                                       G(e->ev.ln.g), G(e->ev.ln.b), F(e->partials), Mv, D.Hv, dv.thr, dv.scale, dv.site,
+                                       c->seed, s));
+    lin_wgrad(A(e->sv.gc), D.Hv, A(e->eva.soft), D.Fv, e->ev.img, Mv);   // no dgrad: features are inputs
+  }
+
+  // ---------------------------------------------------------------- heads
+  void pipe_fwd(const LinearP* l, const bf16_t* x0, int64_t ldx0, const size_t* acts, bf16_t* out_last, int64_t ld_last, int B) {
+    // Linear+LeakyReLU x3, then a plain Linear into `out_last` (regressor.py:8-28)
+    Opt o; o.act = ACT_LEAKY;
+    lin_fwd(x0, ldx0, l[0], B, A(acts[0]), l[0].out, o);
+    lin_fwd(A(acts[0]), l[0].out, l[1], B, A(acts[1]), l[1].out, o);
+    lin_fwd(A(acts[1]), l[1].out, l[2], B, A(acts[2]), l[2].out, o);
+    lin_fwd(A(acts[2]), l[2].out, l[3], B, out_last, ld_last, Opt());
+  }
+  // backward of a pipe: du3 = grad of the last Linear's output (ld = ld3); writes dx0 (+= if acc)
+  void pipe_bwd(const LinearP* l, const bf16_t* x0, int64_t ldx0, const size_t* acts, const bf16_t* du3, int64_t ld3,
+                bf16_t* dx0, int64_t lddx0, bool acc0, int B) {
+    const size_t ga = e->ha.g[0], gb = e->ha.g[1];
+    bias_grad(du3, ld3, l[3], B);
+    lin_wgrad(du3, ld3, A(acts[2]), l[2].out, l[3], B);
+    Opt o; o.dact = ACT_LEAKY; o.dact_src = A(acts[2]); o.ld_aux = l[2].out;
+    lin_dgrad(du3, ld3, l[3], B, A(ga), l[2].out, o);                         // du2
+    bias_grad(A(ga), l[2].out, l[2], B);
+    lin_wgrad(A(ga), l[2].out, A(acts[1]), l[1].out, l[2], B);
+    o.dact_src = A(acts[1]); o.ld_aux = l[1].out;
+    lin_dgrad(A(ga), l[2].out, l[2], B, A(gb), l[1].out, o);                  // du1
+    bias_grad(A(gb), l[1].out, l[1], B);
+    lin_wgrad(A(gb), l[1].out, A(acts[0]), l[0].out, l[1], B);
+    o.dact_src = A(acts[0]); o.ld_aux = l[0].out;
+    lin_dgrad(A(gb), l[1].out, l[1], B, A(ga), l[0].out, o);                  // du0
+    bias_grad(A(ga), l[0].out, l[0], B);
+    lin_wgrad(A(ga), l[0].out, x0, ldx0, l[0], B);
+    if (dx0) { Opt od; od.acc = acc0; lin_dgrad(A(ga), l[0].out, l[0], B, dx0, lddx0, od); }
+  }
+
+  void heads_fwd(size_t seq_t, size_t seq_v, float* logits, float* reg, float* stats, bool with_grad) {
+    const CrctModelDims& D = e->d;
+    const int B = b->B;
+    const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;     // CLS / IMG rows: hidden_states[:, 0]
+    Opt orelu; orelu.act = ACT_RELU;
+    lin_fwd(A(seq_t), ldt, e->t_pool, B, A(e->ha.pooled_t), D.Hb, orelu);      // vilbert.py:955-961
+    lin_fwd(A(seq_v), ldv, e->v_pool, B, A(e->ha.pooled_v), D.Hb, orelu);      // :970-976
+    // regressor on the raw CLS / IMG states (vilbert.py:1599-1600); cat = (hv, hw)  regressor.py:39-41
+    pipe_fwd(e->vp, A(seq_v), ldv, e->ha.v, A(e->ha.cat), 512, B);
+    pipe_fwd(e->tp, A(seq_t), ldt, e->ha.t, A(e->ha.cat) + 256, 512, B);
+    Opt o; o.act = ACT_LEAKY;
+    lin_fwd(A(e->ha.cat), 512, e->fu[0], B, A(e->ha.f[0]), 512, o);
+    lin_fwd(A(e->ha.f[0]), 512, e->fu[1], B, A(e->ha.f[1]), 256, o);
+    lin_fwd(A(e->ha.f[1]), 256, e->fu[2], B, A(e->ha.f[2]), 256, o);
+    if (rc) return;
+    CrctHeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.pooled_t = A(e->ha.pooled_t); h.pooled_v = A(e->ha.pooled_v); h.fus_h = A(e->ha.f[2]);
+    h.w_cls = P(e->cls.w); h.b_cls = P(e->cls.b); h.w_f6 = P(e->fu[3].w); h.b_f6 = P(e->fu[3].b);
+    h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
+    if (with_grad && g32) {
+      h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
+      h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
+    }
+    h.loss_scale_dev = c->loss_scale_dev;
+    h.B = B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
+    h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
+    const Drop dc = drop(D.p_cls, 3);
+    h.drop_thr = dc.thr; h.drop_scale = dc.scale; h.drop_site = dc.site; h.seed = c->seed;
+    fail(crct_head_loss(&h, s));
+  }
+  // heads backward: fills the CLS / IMG rows of the running activation gradients (other rows zero)
+  void heads_bwd(size_t seq_t, size_t seq_v, size_t gt, size_t gv, float* logits, float* reg, float* stats) {
+    const CrctModelDims& D = e->d;
+    const int B = b->B;
+    const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;
+    // the loss kernel is re-run with gradient outputs enabled (cheap: B rows) so that forward can
+    // be called alone for evaluation
+    heads_fwd_grad_only(logits, reg, stats);
+    if (rc) return;
+    if (hipMemsetAsync(A(gt), 0, (size_t)B * b->T * D.H * 2, s) != hipSuccess ||
+        hipMemsetAsync(A(gv), 0, (size_t)B * b->V * D.Hv * 2, s) != hipSuccess) { crct_set_error("engine: memset failed"); rc = 1; return; }
+    // poolers (gradients already w.r.t. the pre-activations)
+    bias_grad(A(e->ha.d_pt), D.Hb, e->t_pool, B);
+    lin_wgrad(A(e->ha.d_pt), D.Hb, A(seq_t), ldt, e->t_pool, B);
+    lin_dgrad(A(e->ha.d_pt), D.Hb, e->t_pool, B, A(gt), ldt, Opt());
+    bias_grad(A(e->ha.d_pv), D.Hb, e->v_pool, B);
+    lin_wgrad(A(e->ha.d_pv), D.Hb, A(seq_v), ldv, e->v_pool, B);
+    lin_dgrad(A(e->ha.d_pv), D.Hb, e->v_pool, B, A(gv), ldv, Opt());
+    // fusion MLP: g[2] = grad of fusion.4's pre-activation
+    const size_t g2 = e->ha.g[2], g3 = e->ha.g[3];
+    bias_grad(A(g2), 256, e->fu[2], B);
+    lin_wgrad(A(g2), 256, A(e->ha.f[1]), 256, e->fu[2], B);
+    Opt o; o.dact = ACT_LEAKY; o.dact_src = A(e->ha.f[1]); o.ld_aux = 256;
+    lin_dgrad(A(g2), 256, e->fu[2], B, A(g3), 256, o);                         // d fusion.2 pre-act
+    bias_grad(A(g3), 256, e->fu[1], B);
+    lin_wgrad(A(g3), 256, A(e->ha.f[0]), 512, e->fu[1], B);
+    o.dact_src = A(e->ha.f[0]); o.ld_aux = 512;
+    lin_dgrad(A(g3), 256, e->fu[1], B, A(g2), 512, o);                         // d fusion.0 pre-act [B,512]
+    bias_grad(A(g2), 512, e->fu[0], B);
+    lin_wgrad(A(g2), 512, A(e->ha.cat), 512, e->fu[0], B);
+    lin_dgrad(A(g2), 512, e->fu[0], B, A(g3), 512, Opt());                     // d cat [B,512] = (d hv, d hw)
+    // pipes; their input gradients accumulate onto the pooler's rows
+    pipe_bwd(e->vp, A(seq_v), ldv, e->ha.v, A(g3), 512, A(gv), ldv, true, B);
+    pipe_bwd(e->tp, A(seq_t), ldt, e->ha.t, A(g3) + 256, 512, A(gt), ldt, true, B);
+  }
+  void heads_fwd_grad_only(float* logits, float* reg, float* stats) {
+    const CrctModelDims& D = e->d;
+    CrctHeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.pooled_t = A(e->ha.pooled_t); h.pooled_v = A(e->ha.pooled_v); h.fus_h = A(e->ha.f[2]);
+    h.w_cls = P(e->cls.w); h.b_cls = P(e->cls.b); h.w_f6 = P(e->fu[3].w); h.b_f6 = P(e->fu[3].b);
+    h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
+    h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
+    h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
+    h.loss_scale_dev = c->loss_scale_dev;
+    h.B = b->B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
+    h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
+    const Drop dc = drop(D.p_cls, 3);
+    h.drop_thr = dc.thr; h.drop_scale = dc.scale; h.drop_site = dc.site; h.seed = c->seed;
+    fail(crct_head_loss(&h, s));
+  }
+};
+
+int check_batch(const crct_engine* e, const CrctBatch* b) {
+  CRCT_REQUIRE(b && b->B >= 1 && b->T >= 1 && b->V >= 1, "engine: bad batch sizes");
+  CRCT_REQUIRE(b->B <= e->maxB && b->T <= e->maxT && b->V <= e->maxV, "engine: batch (B=%d,T=%d,V=%d) exceeds the engine maximum (%d,%d,%d)",
+               b->B, b->T, b->V, e->maxB, e->maxT, e->maxV);
+  CRCT_REQUIRE(b->tokens && b->segments && b->loc && b->text_keymask && b->image_feat && b->image_loc && b->image_target &&
+                   b->image_keymask && b->R, "engine: null batch pointer");
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const char* names, const int64_t* offsets,
+                                             const int64_t* sizes, int n_params, int max_B, int max_T, int max_V) {
+  if (!dims || !names || !offsets || !sizes) { crct_set_error("engine_create: null argument"); return nullptr; }
+  crct_engine* e = new crct_engine();
+  e->d = *dims; e->maxB = max_B; e->maxT = max_T; e->maxV = max_V;
+  const CrctModelDims& D = e->d;
+  {
+    const char* p = names;
+    for (int i = 0; i < n_params; ++i) {
+      const char* q = strchr(p, '\n');
+      std::string k = q ? std::string(p, q - p) : std::string(p);
+      e->off[k] = offsets[i]; e->size[k] = sizes[i];
+      if (!q) break;
+      p = q + 1;
+    }
+  }
+  auto fail = [&](const char* msg) -> crct_engine_t* { if (msg) crct_set_error("%s", msg); delete e; return nullptr; };
+  if (D.H % D.heads || D.Hv % D.v_heads || D.Hb % D.b_heads) return fail("engine_create: hidden size not a multiple of heads");
+  if (D.H % 8 || D.Hv % 8 || D.Hb % 8 || D.I % 8 || D.Iv % 8 || D.Fv % 8) return fail("engine_create: sizes must be multiples of 8");
+  if (D.n_conn > 32) return fail("engine_create: more than 32 connection layers");
+  // ---- schedule (vilbert.py:852-939)
+  {
+    int vs = 0, ts = 0;
+    for (int c = 0; c < D.n_conn; ++c) {
+      for (int i = vs; i < D.v_biatt[c]; ++i) e->sched.push_back({'v', i});
+      for (int i = ts; i < D.t_biatt[c]; ++i) e->sched.push_back({'t', i});
+      if (D.with_coattention) e->sched.push_back({'c', c});
+      vs = D.v_biatt[c]; ts = D.t_biatt[c];
+    }
+    for (int i = vs; i < D.Lv; ++i) e->sched.push_back({'v', i});
+    for (int i = ts; i < D.L; ++i) e->sched.push_back({'t', i});
+  }
+  // ---- parameters
+  char buf[256];
+  uint32_t site = 16;
+  for (int i = 0; i < D.L; ++i) {
+    snprintf(buf, sizeof(buf), "bert.encoder.layer.%d.", i);
+    std::string p(buf);
+    SelfLayerP l;
+    l.H = D.H; l.heads = D.heads; l.p_attn = D.p_attn; l.p_hid = D.p_hidden; l.site = site; site += 4;
+    l.qkv = fused3(e, p + "attention.self.query", p + "attention.self.key", p + "attention.self.value", D.H, D.H);
+    l.proj.dense = linear_p(e, p + "attention.output.dense", D.H, D.H);
+    l.proj.ln = ln_p(e, p + "attention.output.LayerNorm");
+    l.ffn.up = linear_p(e, p + "intermediate.dense", D.H, D.I);
+    l.ffn.down = linear_p(e, p + "output.dense", D.I, D.H);
+    l.ffn.ln = ln_p(e, p + "output.LayerNorm");
+    e->tl.push_back(l);
+  }
+  for (int i = 0; i < D.Lv; ++i) {
+    snprintf(buf, sizeof(buf), "bert.encoder.v_layer.%d.", i);
+    std::string p(buf);
+    SelfLayerP l;
+    l.H = D.Hv; l.heads = D.v_heads; l.p_attn = D.p_v_attn; l.p_hid = D.p_v_hidden; l.site = site; site += 4;
+    l.qkv = fused3(e, p + "attention.self.query", p + "attention.self.key", p + "attention.self.value", D.Hv, D.Hv);
+    l.proj.dense = linear_p(e, p + "attention.output.dense", D.Hv, D.Hv);
+    l.proj.ln = ln_p(e, p + "attention.output.LayerNorm");
+    l.ffn.up = linear_p(e, p + "intermediate.dense", D.Hv, D.Iv);
+    l.ffn.down = linear_p(e, p + "output.dense", D.Iv, D.Hv);
+    l.ffn.ln = ln_p(e, p + "output.LayerNorm");
+    e->vl.push_back(l);
+  }
+  for (int i = 0; i < D.n_conn; ++i) {
+    snprintf(buf, sizeof(buf), "bert.encoder.c_layer.%d.", i);
+    std::string p(buf);
+    ConnLayerP l;
+    l.site = site; site += 8;
+    l.qkv1 = fused3(e, p + "biattention.query1", p + "biattention.key1", p + "biattention.value1", D.Hv, D.Hb);
+    l.qkv2 = fused3(e, p + "biattention.query2", p + "biattention.key2", p + "biattention.value2", D.H, D.Hb);
+    l.proj_v.dense = linear_p(e, p + "biOutput.dense1", D.Hb, D.Hv); l.proj_v.ln = ln_p(e, p + "biOutput.LayerNorm1");
+    l.proj_t.dense = linear_p(e, p + "biOutput.dense2", D.Hb, D.H); l.proj_t.ln = ln_p(e, p + "biOutput.LayerNorm2");
+    l.ffn_v.up = linear_p(e, p + "v_intermediate.dense", D.Hv, D.Iv);
+    l.ffn_v.down = linear_p(e, p + "v_output.dense", D.Iv, D.Hv); l.ffn_v.ln = ln_p(e, p + "v_output.LayerNorm");
+    l.ffn_t.up = linear_p(e, p + "t_intermediate.dense", D.H, D.I);
+    l.ffn_t.down = linear_p(e, p + "t_output.dense", D.I, D.H); l.ffn_t.ln = ln_p(e, p + "t_output.LayerNorm");
+    e->cl.push_back(l);
+  }
+  e->et.word = e->P("bert.embeddings.word_embeddings.weight");
+  e->et.pos = e->P("bert.embeddings.position_embeddings.weight");
+  e->et.type = e->P("bert.embeddings.plotqa_type_embeddings.weight");
+  e->et.wloc = e->P("bert.embeddings.txt_location_embeddings.weight");
+  e->et.bloc = e->P("bert.embeddings.txt_location_embeddings.bias");
+  e->et.ln = ln_p(e, "bert.embeddings.LayerNorm");
+  e->ev.img = linear_p(e, "bert.v_embeddings.new_image_embeddings", D.Fv, D.Hv);
+  e->ev.color = e->P("bert.v_embeddings.color_emb.weight");
+  e->ev.wloc = e->P("bert.v_embeddings.new_loc_emb.weight");
+  e->ev.bloc = e->P("bert.v_embeddings.new_loc_emb.bias");
+  e->ev.ln = ln_p(e, "bert.v_embeddings.LayerNorm");
+  e->t_pool = linear_p(e, "bert.t_pooler.dense", D.H, D.Hb);
+  e->v_pool = linear_p(e, "bert.v_pooler.dense", D.Hv, D.Hb);
+  e->cls = linear_p(e, "cls.bi_seq_relationship", D.Hb, 2);
+  {
+    const int tw[5] = {D.H, D.H, 512, 256, 256}, vw[5] = {D.Hv, D.Hv, 512, 256, 256}, fw[5] = {512, 512, 256, 256, 1};
+    for (int j = 0; j < 4; ++j) {
+      snprintf(buf, sizeof(buf), "regressor.txt_pipe.%d", 2 * j); e->tp[j] = linear_p(e, buf, tw[j], tw[j + 1]);
+      snprintf(buf, sizeof(buf), "regressor.vis_pipe.%d", 2 * j); e->vp[j] = linear_p(e, buf, vw[j], vw[j + 1]);
+      snprintf(buf, sizeof(buf), "regressor.fusion.%d", 2 * j); e->fu[j] = linear_p(e, buf, fw[j], fw[j + 1]);
+    }
+  }
+  if (e->bad) return fail(nullptr);
+
+  // ---- workspace
+  Arena ar;
+  const size_t Mt = (size_t)max_B * max_T, Mv = (size_t)max_B * max_V, B = max_B;
+  e->eta.sum = ar.take(Mt * D.H * 2); e->eta.y = ar.take(Mt * D.H * 2); e->eta.mean = ar.take(Mt * 4); e->eta.rstd = ar.take(Mt * 4);
+  e->eva.soft = ar.take(Mv * D.Fv * 2); e->eva.lin = ar.take(Mv * D.Hv * 2); e->eva.sum = ar.take(Mv * D.Hv * 2);
+  e->eva.y = ar.take(Mv * D.Hv * 2); e->eva.mean = ar.take(Mv * 4); e->eva.rstd = ar.take(Mv * 4);
+  e->taps.push_back({"emb.t", e->eta.y, 't'});
+  e->taps.push_back({"emb.v", e->eva.y, 'v'});
+  e->tla.resize(D.L); e->vla.resize(D.Lv); e->cla.resize(D.n_conn);
+  for (int i = 0; i < D.L; ++i) {
+    SelfLayerA& a = e->tla[i];
+    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.proj = proj_a(ar, Mt, D.H); a.ffn = ffn_a(ar, Mt, D.H, D.I);
+  }
+  for (int i = 0; i < D.Lv; ++i) {
+    SelfLayerA& a = e->vla[i];
+    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.proj = proj_a(ar, Mv, D.Hv); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv);
+  }
+  for (int i = 0; i < D.n_conn; ++i) {
+    ConnLayerA& a = e->cla[i];
+    a.qkv1 = ar.take(Mv * 3 * D.Hb * 2); a.qkv2 = ar.take(Mt * 3 * D.Hb * 2);
+    a.ctx1 = ar.take(Mt * D.Hb * 2); a.ctx2 = ar.take(Mv * D.Hb * 2);
+    a.proj_v = proj_a(ar, Mv, D.Hv); a.proj_t = proj_a(ar, Mt, D.H);
+    a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv); a.ffn_t = ffn_a(ar, Mt, D.H, D.I);
+  }
+  e->ha.pooled_t = ar.take(B * D.Hb * 2); e->ha.pooled_v = ar.take(B * D.Hb * 2);
+  e->ha.t[0] = ar.take(B * D.H * 2); e->ha.t[1] = ar.take(B * 512 * 2); e->ha.t[2] = ar.take(B * 256 * 2);
+  e->ha.v[0] = ar.take(B * D.Hv * 2); e->ha.v[1] = ar.take(B * 512 * 2); e->ha.v[2] = ar.take(B * 256 * 2);
+  e->ha.cat = ar.take(B * 512 * 2);
+  e->ha.f[0] = ar.take(B * 512 * 2); e->ha.f[1] = ar.take(B * 256 * 2); e->ha.f[2] = ar.take(B * 256 * 2);
+  e->ha.scratch = ar.take(B * 8 * 4);
+  e->ha.d_pt = ar.take(B * D.Hb * 2); e->ha.d_pv = ar.take(B * D.Hb * 2);
+  {
+    size_t w = 512;
+    if ((size_t)D.H > w) w = D.H;
+    if ((size_t)D.Hv > w) w = D.Hv;
+    for (int k = 0; k < 4; ++k) e->ha.g[k] = ar.take(B * w * 2);
+  }
+  e->st = scratch_a(ar, Mt, D.H, D.I, D.Hb);
+  e->sv = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
+  {
+    size_t wmax = D.H > D.Hv ? D.H : D.Hv;
+    e->partials = ar.take((size_t)8 * 256 * wmax * 4);
+    size_t nmax = 3 * (size_t)D.Hb;
+    if ((size_t)D.I > nmax) nmax = D.I;
+    if ((size_t)D.Iv > nmax) nmax = D.Iv;
+    if (3 * (size_t)D.H > nmax) nmax = 3 * (size_t)D.H;
+    if (3 * (size_t)D.Hv > nmax) nmax = 3 * (size_t)D.Hv;
+    if (nmax < 1024) nmax = 1024;
+    e->colsum_part = ar.take((size_t)64 * nmax * 4);
+  }
+  e->ws_bytes = ar.top;
+
+  // ---- taps + final outputs, following the schedule
+  {
+    size_t xt = e->eta.y, xv = e->eva.y;
+    for (const Step& st : e->sched) {
+      if (st.kind == 't') xt = e->tla[st.idx].ffn.y;
+      else if (st.kind == 'v') xv = e->vla[st.idx].ffn.y;
+      else { xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
+      snprintf(buf, sizeof(buf), "%c%d.t", st.kind, st.idx); e->taps.push_back({buf, xt, 't'});
+      snprintf(buf, sizeof(buf), "%c%d.v", st.kind, st.idx); e->taps.push_back({buf, xv, 'v'});
+    }
+    e->final_t = xt; e->final_v = xv;
+    e->taps.push_back({"seq_t", xt, 't'});
+    e->taps.push_back({"seq_v", xv, 'v'});
+  }
+
+  // ---- gradient segments in backward order: heads, schedule reversed, embeddings
+  auto range_of = [&](std::vector<std::string> prefixes) {
+    int64_t lo = INT64_MAX, hi = -1;
+    for (auto& kv : e->off)
+      for (auto& pf : prefixes)
+        if (kv.first.compare(0, pf.size(), pf) == 0) {
+          if (kv.second < lo) lo = kv.second;
+          const int64_t end = kv.second + e->size[kv.first];
+          if (end > hi) hi = end;
+        }
+    if (hi < 0) { lo = 0; hi = 0; }
+    return std::make_pair(lo, hi);
+  };
+  e->seg_range.push_back(range_of({"bert.t_pooler.", "bert.v_pooler.", "cls.bi_seq_relationship.", "regressor."}));
+  for (int i = (int)e->sched.size() - 1; i >= 0; --i) {
+    const Step& st = e->sched[i];
+    snprintf(buf, sizeof(buf), "bert.encoder.%s.%d.", st.kind == 't' ? "layer" : (st.kind == 'v' ? "v_layer" : "c_layer"), st.idx);
+    e->seg_range.push_back(range_of({std::string(buf)}));
+  }
+  e->seg_range.push_back(range_of({"bert.embeddings.", "bert.v_embeddings."}));
+  return e;
+}
+
+extern "C" void crct_engine_destroy(crct_engine_t* e) { delete e; }
+extern "C" size_t crct_engine_workspace_bytes(const crct_engine_t* e) { return e ? e->ws_bytes : 0; }
+extern "C" int crct_engine_num_segments(const crct_engine_t* e) { return e ? (int)e->seg_range.size() : 0; }
+extern "C" int crct_engine_segment_range(const crct_engine_t* e, int seg, int64_t* lo, int64_t* hi) {
+  CRCT_REQUIRE(e && seg >= 0 && seg < (int)e->seg_range.size(), "segment_range: bad segment %d", seg);
+  *lo = e->seg_range[seg].first; *hi = e->seg_range[seg].second;
+  return 0;
+}
+
+extern "C" int crct_engine_forward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
+                                   const CrctStepCfg* cfg, void* workspace, float* logits, float* reg, float* stats,
+                                   crct_stream_t stream) {
+  CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && logits && reg && stats, "engine_forward: null argument");
+  if (int r = check_batch(e, batch)) return r;
+  Run R{e, params_f32, (const bf16_t*)params_bf16, nullptr, (char*)workspace, (hipStream_t)stream, batch, cfg};
+  R.embed_fwd();
+  size_t xt = e->eta.y, xv = e->eva.y;
+  for (const Step& st : e->sched) {
+    if (st.kind == 't') { R.self_fwd(e->tl[st.idx], e->tla[st.idx], xt, batch->text_keymask, batch->B, batch->T); xt = e->tla[st.idx].ffn.y; }
+    else if (st.kind == 'v') { R.self_fwd(e->vl[st.idx], e->vla[st.idx], xv, batch->image_keymask, batch->B, batch->V); xv = e->vla[st.idx].ffn.y; }
+    else { R.conn_fwd(e->cl[st.idx], e->cla[st.idx], xv, xt); xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
+  }
+  R.heads_fwd(xt, xv, logits, reg, stats, false);
+  return R.rc;
+}
+
+extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
+                                    const CrctStepCfg* cfg, void* workspace, float* grads_f32, float* logits, float* reg,
+                                    float* stats, int seg, crct_stream_t stream) {
+  CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && grads_f32 && logits && reg && stats, "engine_backward: null argument");
+  CRCT_REQUIRE(batch && batch->labels, "engine_backward: labels are required (training step)");
+  if (int r = check_batch(e, batch)) return r;
+  Run R{e, params_f32, (const bf16_t*)params_bf16, grads_f32, (char*)workspace, (hipStream_t)stream, batch, cfg};
+  const int nseg = (int)e->seg_range.size();
+  const int s0 = seg < 0 ? 0 : seg, s1 = seg < 0 ? nseg : seg + 1;
+  CRCT_REQUIRE(s1 <= nseg, "engine_backward: bad segment %d", seg);
+  // inputs of every schedule step (outputs of the previous step of that stream)
+  std::vector<size_t> in_t(e->sched.size()), in_v(e->sched.size());
+  {
+    size_t xt = e->eta.y, xv = e->eva.y;
+    for (size_t i = 0; i < e->sched.size(); ++i) {
+      in_t[i] = xt; in_v[i] = xv;
+      const Step& st = e->sched[i];
+      if (st.kind == 't') xt = e->tla[st.idx].ffn.y;
+      else if (st.kind == 'v') xv = e->vla[st.idx].ffn.y;
+      else { xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
+    }
+  }
+  for (int sgi = s0; sgi < s1 && !R.rc; ++sgi) {
+    if (sgi == 0) {
+      e->cur_t = 0; e->cur_v = 0;
+      R.heads_bwd(e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
+    } else if (sgi == nseg - 1) {
+      R.embed_bwd(e->st.dy[e->cur_t], e->sv.dy[e->cur_v]);
+    } else {
+      const size_t i = e->sched.size() - (size_t)sgi;
+      const Step& st = e->sched[i];
+      if (st.kind == 't') {
+        R.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], e->st, batch->text_keymask, batch->B, batch->T);
+        e->cur_t ^= 1;
+      } else if (st.kind == 'v') {
+        R.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], e->sv, batch->image_keymask, batch->B, batch->V);
+        e->cur_v ^= 1;
+      } else {
+        R.conn_bwd(e->cl[st.idx], e->cla[st.idx], in_v[i], in_t[i], e->sv.dy[e->cur_v], e->st.dy[e->cur_t], e->sv.dy[e->cur_v ^ 1], e->st.dy[e->cur_t ^ 1]);
+        e->cur_t ^= 1; e->cur_v ^= 1;
+      }
+    }
+  }
+  return R.rc;
+}
+
+extern "C" int64_t crct_engine_tap(crct_engine_t* e, const void* workspace, const char* name, int B, int T, int V, void* out,
+                                   int64_t cap, crct_stream_t stream) {
+  if (!e || !name) return -1;
+  for (const Tap& t : e->taps)
+    if (t.name == name) {
+      const int64_t n = t.stream == 't' ? (int64_t)B * T * e->d.H : (int64_t)B * V * e->d.Hv;
+      if (n > cap) { crct_set_error("tap: buffer too small"); return -1; }
+      if (hipMemcpyAsync(out, (const char*)workspace + t.off, (size_t)n * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return -1;
+      return n;
+    }
+  crct_set_error("tap: unknown activation '%s'", name);
+  return -1;
+}

@@ -1,0 +1,182 @@
+// Classification head + regression tail + joint loss, and their gradient seeds, without host syncs.
+// Reference: BertPreTrainingHeads.forward vilbert.py:1048-1062 (fusion 'mul'/'sum', dropout 0.1,
+// Linear(1024, 2)); PlotQA_Regressor_v20 tail regressor.py:31-34,41 (Linear(256,1) + Tanh);
+// regression bookkeeping + CrossEntropyLoss(ignore_index=-1) vilbert.py:1583-1657; loss
+// combination encoder_decorator.py:144-153.  All B rows are regressed and masked by R[:,1]
+// (the reference gathers those rows: same values, same gradients, static shapes).
+#include "common.cuh"
+#include "crct_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ bool head_keep(const CrctHeadArgs& a, int b, int c) {
+  if (!a.drop_thr) return true;
+  const uint64_t idx = (uint64_t)b * (uint64_t)a.Hb + (uint64_t)c;
+  const Philox4 p = philox4x32_10(a.seed, a.drop_site, idx >> 2);
+  const uint32_t k = (uint32_t)idx & 3u;
+  const uint32_t u = k == 0 ? p.x : (k == 1 ? p.y : (k == 2 ? p.z : p.w));
+  return u >= a.drop_thr;
+}
+
+// scratch row layout (fp32 x 8): dlogit0, dlogit1, dz, nsp_loss_b, valid, ok5, okt, needs
+__global__ __launch_bounds__(256) void head_rows_kernel(const CrctHeadArgs a, float* scratch) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* pt = reinterpret_cast<const bf16_t*>(a.pooled_t) + (long)b * a.Hb;
+  const bf16_t* pv = reinterpret_cast<const bf16_t*>(a.pooled_v) + (long)b * a.Hb;
+  const bf16_t* fh = reinterpret_cast<const bf16_t*>(a.fus_h) + (long)b * 256;
+  const float dsc = a.drop_thr ? a.drop_scale : 1.0f;
+  // ---- logits
+  float l0 = 0.f, l1 = 0.f;
+  for (int c = tid; c < a.Hb; c += 256) {
+    const float t = bf2f(pt[c]), v = bf2f(pv[c]);
+    float f = a.fusion_sum ? t + v : t * v;
+    f = head_keep(a, b, c) ? f * dsc : 0.f;
+    l0 += f * a.w_cls[c]; l1 += f * a.w_cls[a.Hb + c];
+  }
+  l0 = block_sum(l0, red) + a.b_cls[0];
+  l1 = block_sum(l1, red) + a.b_cls[1];
+  // ---- regression tail
+  float z = 0.f;
+  for (int c = tid; c < 256; c += 256) z += bf2f(fh[c]) * a.w_f6[c];
+  z = block_sum(z, red) + a.b_f6[0];
+  const float r = tanhf(z);
+  // ---- labels: count of rows that enter the CE mean (ignore_index = -1)
+  int n_valid = 0;
+  long label = -1;
+  if (a.labels) {
+    for (int i = tid; i < a.B; i += 256) n_valid += (a.labels[i] != -1);
+    n_valid = (int)(block_sum((float)n_valid, red) + 0.5f);
+    label = a.labels[b];
+  }
+  const float gs = a.grad_scale * (a.loss_scale_dev ? a.loss_scale_dev[0] : 1.0f);
+  // per-row scalars (every thread computes them identically)
+  const float mx = fmaxf(l0, l1);
+  const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+  float nsp_b = 0.f, dl0 = 0.f, dl1 = 0.f;
+  const bool valid = a.labels && label != -1;
+  if (valid) {
+    nsp_b = lse - (label == 0 ? l0 : l1);
+    const float w = a.nsp_coeff * gs / (float)max(n_valid, 1);
+    dl0 = (expf(l0 - lse) - (label == 0 ? 1.f : 0.f)) * w;
+    dl1 = (expf(l1 - lse) - (label == 1 ? 1.f : 0.f)) * w;
+  }
+  const float* Rb = a.R + (long)b * 4;
+  const bool needs = Rb[1] == 1.0f;
+  const float target = Rb[0] / Rb[3];
+  const float diff = r - target, l1v = fabsf(diff);
+  float rl, drl;   // reg loss and d(reg loss)/dr
+  if (a.use_l1) { rl = l1v; drl = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f); }
+  else {           // SmoothL1, beta = 0.5
+    if (l1v < 0.5f) { rl = diff * diff; drl = 2.0f * diff; }    // 0.5 d^2 / beta
+    else { rl = l1v - 0.25f; drl = diff > 0.f ? 1.f : -1.f; }
+  }
+  const bool both0 = (r == 0.f) && (target == 0.f);
+  float d5 = l1v / fabsf(target);
+  if (target == 0.f) d5 = 1.f;
+  if (both0) d5 = 0.f;
+  const bool ok5 = ((d5 <= 0.05f) || both0) && needs;
+  const bool okt = (l1v <= a.tol_margin) && needs;
+  if (!a.kind_l1 && fabsf(target) > 1.f) { rl = 0.f; drl = 0.f; }
+  if (!needs) { rl = 0.f; drl = 0.f; }
+  const float dz = drl * (a.reg_coeff * gs / (float)a.B) * (1.f - r * r);
+  if (tid == 0) {
+    a.logits[b * 2] = l0; a.logits[b * 2 + 1] = l1;
+    a.reg[0 * a.B + b] = needs ? r * Rb[3] : 0.f;
+    a.reg[1 * a.B + b] = rl;
+    a.reg[2 * a.B + b] = needs ? l1v : 0.f;
+    a.reg[3 * a.B + b] = r;                       // raw tanh output (diagnostic)
+    a.reg[4 * a.B + b] = needs ? d5 : 0.f;
+    float* s = scratch + (long)b * 8;
+    s[0] = dl0; s[1] = dl1; s[2] = dz; s[3] = nsp_b; s[4] = valid ? 1.f : 0.f;
+    s[5] = ok5 ? 1.f : 0.f; s[6] = okt ? 1.f : 0.f; s[7] = needs ? 1.f : 0.f;
+  }
+  // ---- gradient seeds (w.r.t. the PRE-activations of the poolers / fusion.4)
+  if (a.d_pooled_t) {
+    bf16_t* dpt = reinterpret_cast<bf16_t*>(a.d_pooled_t) + (long)b * a.Hb;
+    bf16_t* dpv = reinterpret_cast<bf16_t*>(a.d_pooled_v) + (long)b * a.Hb;
+    for (int c = tid; c < a.Hb; c += 256) {
+      const float t = bf2f(pt[c]), v = bf2f(pv[c]);
+      float df = dl0 * a.w_cls[c] + dl1 * a.w_cls[a.Hb + c];
+      df = head_keep(a, b, c) ? df * dsc : 0.f;
+      const float gt = a.fusion_sum ? df : df * v, gv = a.fusion_sum ? df : df * t;
+      dpt[c] = f2bf(t > 0.f ? gt : 0.f);        // relu'(pre) == (post > 0)
+      dpv[c] = f2bf(v > 0.f ? gv : 0.f);
+    }
+    bf16_t* dfh = reinterpret_cast<bf16_t*>(a.d_fus_h) + (long)b * 256;
+    for (int c = tid; c < 256; c += 256) {
+      const float hval = bf2f(fh[c]);
+      dfh[c] = f2bf(dz * a.w_f6[c] * (hval > 0.f ? 1.f : 0.01f));
+    }
+  }
+}
+
+// stats + parameter gradients of bi_seq_relationship and fusion.6 (sums over the batch rows)
+__global__ __launch_bounds__(256) void head_reduce_kernel(const CrctHeadArgs a, const float* scratch) {
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 256 + tid;
+  const float dsc = a.drop_thr ? a.drop_scale : 1.0f;
+  if (a.d_w_cls && c < a.Hb) {
+    const bf16_t* pt = reinterpret_cast<const bf16_t*>(a.pooled_t);
+    const bf16_t* pv = reinterpret_cast<const bf16_t*>(a.pooled_v);
+    float g0 = 0.f, g1 = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+      const float t = bf2f(pt[(long)b * a.Hb + c]), v = bf2f(pv[(long)b * a.Hb + c]);
+      float f = a.fusion_sum ? t + v : t * v;
+      f = head_keep(a, b, c) ? f * dsc : 0.f;
+      g0 += scratch[b * 8] * f; g1 += scratch[b * 8 + 1] * f;
+    }
+    a.d_w_cls[c] += g0; a.d_w_cls[a.Hb + c] += g1;
+  }
+  if (a.d_w_f6 && c < 256) {
+    const bf16_t* fh = reinterpret_cast<const bf16_t*>(a.fus_h);
+    float g = 0.f;
+    for (int b = 0; b < a.B; ++b) g += scratch[b * 8 + 2] * bf2f(fh[(long)b * 256 + c]);
+    a.d_w_f6[c] += g;
+  }
+  if (blockIdx.x == 0 && tid < 64) {
+    // one wave reduces the per-row records
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float rl = 0.f;
+    for (int b = tid; b < a.B; b += 64) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += scratch[b * 8 + k];
+      rl += a.reg[1 * a.B + b];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = wave_sum(s[k]);
+    rl = wave_sum(rl);
+    if (tid == 0) {
+      const float nsp = s[4] > 0.f ? s[3] / s[4] : 0.f;
+      const float reg_mean = rl / (float)a.B;
+      a.stats[0] = a.labels ? a.nsp_coeff * nsp + a.reg_coeff * reg_mean : 0.f;
+      a.stats[1] = nsp; a.stats[2] = reg_mean; a.stats[3] = s[7]; a.stats[4] = s[5]; a.stats[5] = s[6];
+      a.stats[6] = s[4]; a.stats[7] = 0.f;
+      if (a.d_b_cls) { a.d_b_cls[0] += s[0]; a.d_b_cls[1] += s[1]; }
+      if (a.d_b_f6) a.d_b_f6[0] += s[2];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int crct_head_loss(const CrctHeadArgs* args, crct_stream_t stream) {
+  CRCT_REQUIRE(args && args->B > 0 && args->Hb > 0, "head_loss: bad sizes");
+  CRCT_REQUIRE(args->scratch, "head_loss: scratch (fp32 [B][8]) is required");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_rows_kernel, dim3(args->B), dim3(256), 0, s, *args, args->scratch);
+  CRCT_CHECK_HIP(hipGetLastError());
+  const int nb = ((args->Hb > 256 ? args->Hb : 256) + 255) / 256;
+  hipLaunchKernelGGL(head_reduce_kernel, dim3(nb), dim3(256), 0, s, *args, (const float*)args->scratch);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,694 @@
+// Row-wise HBM-bound kernels of the CRCT step: LayerNorm fwd/bwd, text / image embedding
+// fwd/bwd (sum of gathers + Linear(4) + LayerNorm + dropout), column sums, row softmax, casts.
+// One wave (64 lanes) owns one row; every lane keeps NCH 16-byte chunks (8 bf16) of the row in
+// registers, so a row is read once and written once.  Statistics are fp32.
+// Reference arithmetic: BertLayerNorm vilbert.py:281-294; BertEmbeddingLocation :320-358;
+// BertImageEmbeddings :1474-1496.
+#include "common.cuh"
+#include "crct_internal.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;   // waves per 256-thread workgroup
+
+template <int NCH>
+struct Row {
+  float v[NCH][8];
+};
+
+template <int NCH>
+__device__ __forceinline__ void row_load_bf16(Row<NCH>& r, const bf16_t* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const uint4 u = *reinterpret_cast<const uint4*>(p + c);
+      r.v[i][0] = bf2f((bf16_t)(u.x & 0xffff)); r.v[i][1] = bf2f((bf16_t)(u.x >> 16));
+      r.v[i][2] = bf2f((bf16_t)(u.y & 0xffff)); r.v[i][3] = bf2f((bf16_t)(u.y >> 16));
+      r.v[i][4] = bf2f((bf16_t)(u.z & 0xffff)); r.v[i][5] = bf2f((bf16_t)(u.z >> 16));
+      r.v[i][6] = bf2f((bf16_t)(u.w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(u.w >> 16));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void row_store_bf16(const Row<NCH>& r, bf16_t* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      uint4 u;
+      u.x = pack2bf(r.v[i][0], r.v[i][1]); u.y = pack2bf(r.v[i][2], r.v[i][3]);
+      u.z = pack2bf(r.v[i][4], r.v[i][5]); u.w = pack2bf(r.v[i][6], r.v[i][7]);
+      *reinterpret_cast<uint4*>(p + c) = u;
+    }
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void row_load_f32(Row<NCH>& r, const float* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const float4 a = *reinterpret_cast<const float4*>(p + c);
+      const float4 b = *reinterpret_cast<const float4*>(p + c + 4);
+      r.v[i][0] = a.x; r.v[i][1] = a.y; r.v[i][2] = a.z; r.v[i][3] = a.w;
+      r.v[i][4] = b.x; r.v[i][5] = b.y; r.v[i][6] = b.z; r.v[i][7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void row_add_f32(Row<NCH>& r, const float* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const float4 a = *reinterpret_cast<const float4*>(p + c);
+      const float4 b = *reinterpret_cast<const float4*>(p + c + 4);
+      r.v[i][0] += a.x; r.v[i][1] += a.y; r.v[i][2] += a.z; r.v[i][3] += a.w;
+      r.v[i][4] += b.x; r.v[i][5] += b.y; r.v[i][6] += b.z; r.v[i][7] += b.w;
+    }
+  }
+}
+// r += W[c][0..3] . loc + b[c]   (a Linear(4, H): txt_location_embeddings / new_loc_emb)
+template <int NCH>
+__device__ __forceinline__ void row_add_loc_linear(Row<NCH>& r, const float* w, const float* b, const float l[4], int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + (long)(c + j) * 4);
+        r.v[i][j] += b[c + j] + wv.x * l[0] + wv.y * l[1] + wv.z * l[2] + wv.w * l[3];
+      }
+    }
+  }
+}
+
+template <int NCH>
+__device__ __forceinline__ void row_stats(const Row<NCH>& r, int H, int lane, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += r.v[i][j];     // out-of-range chunks hold zeros
+  mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = r.v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  rstd = 1.0f / sqrtf(var + eps);
+}
+
+// y = gamma * (x - mean) * rstd + beta, optional post-norm dropout keyed by (row*H + col)
+template <int NCH>
+__device__ __forceinline__ void row_normalize(Row<NCH>& r, const float* gamma, const float* beta, int H, int lane,
+                                              float mean, float rstd, long row, uint32_t thr, float scale,
+                                              uint32_t site, uint64_t seed) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = gg[j] * ((r.v[i][j] - mean) * rstd) + bb[j];
+      if (thr) {
+        const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)c;
+        const Philox4 p0 = philox4x32_10(seed, site, idx >> 2), p1 = philox4x32_10(seed, site, (idx >> 2) + 1);
+        const uint32_t u[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[i][j] = u[j] >= thr ? r.v[i][j] * scale : 0.f;
+      }
+    }
+  }
+}
+
+// multiply the row by the dropout keep-mask * scale of (site, seed) keyed by (row*H + col)
+template <int NCH>
+__device__ __forceinline__ void row_apply_dropmask(Row<NCH>& r, int H, int lane, long row, uint32_t thr, float scale,
+                                                   uint32_t site, uint64_t seed) {
+  if (!thr) return;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)c;
+      const Philox4 p0 = philox4x32_10(seed, site, idx >> 2), p1 = philox4x32_10(seed, site, (idx >> 2) + 1);
+      const uint32_t u[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = u[j] >= thr ? r.v[i][j] * scale : 0.f;
+    }
+  }
+}
+
+// LayerNorm backward of one row.  in: dy (gradient w.r.t. y), x (pre-norm row).  out: dy <- dx,
+// xhat in x.  dgamma/dbeta accumulators updated.
+template <int NCH>
+__device__ __forceinline__ void row_ln_bwd(Row<NCH>& dy, Row<NCH>& x, const float* gamma, int H, int lane,
+                                           float mean, float rstd, Row<NCH>& acc_dg, Row<NCH>& acc_db) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x.v[i][j] - mean) * rstd;
+        x.v[i][j] = xh;
+        acc_dg.v[i][j] += dy.v[i][j] * xh;
+        acc_db.v[i][j] += dy.v[i][j];
+        const float g = dy.v[i][j] * gg[j];
+        dy.v[i][j] = g;
+        s1 += g; s2 += g * xh;
+      }
+    }
+  }
+  const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dy.v[i][j] = rstd * (dy.v[i][j] - c1 - x.v[i][j] * c2);
+    }
+  }
+}
+
+template <int NCH>
+__device__ __forceinline__ void row_zero(Row<NCH>& r) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+}
+template <int NCH>
+__device__ __forceinline__ void row_acc(Row<NCH>& a, const Row<NCH>& r, float s = 1.f) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a.v[i][j] += r.v[i][j] * s;
+}
+template <int NCH>
+__device__ __forceinline__ void row_atomic_add(const Row<NCH>& r, float* dst, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(dst + c + j, r.v[i][j]);
+    }
+  }
+}
+
+// Sum one per-lane column accumulator over the 4 waves of the block and store to partial[blk][H].
+// `red` is LDS [4][H] floats.
+template <int NCH>
+__device__ __forceinline__ void block_reduce_store(const Row<NCH>& acc, float* red, float* partial_row, int H, int lane, int wave) {
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave * H + c + j] = acc.v[i][j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256)
+    partial_row[c] = red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c];
+}
+
+// ------------------------------------------------------------------------------ LayerNorm fwd
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H, float eps,
+                                                     uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    Row<NCH> r;
+    row_load_bf16(r, x + row * H, H, lane);
+    float mean, rstd;
+    row_stats(r, H, lane, eps, mean, rstd);
+    row_normalize(r, gamma, beta, H, lane, mean, rstd, row, thr, scale, site, seed);
+    row_store_bf16(r, y + row * H, H, lane);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
+// ------------------------------------------------------------------------------ LayerNorm bwd
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy_p, const bf16_t* __restrict__ x_p,
+                                                     const float* __restrict__ mean_p, const float* __restrict__ rstd_p,
+                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dx_p,
+                                                     bf16_t* __restrict__ dxl_p, float* __restrict__ partials, int M, int H,
+                                                     uint32_t post_thr, float post_scale, uint32_t post_site,
+                                                     uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Row<NCH> adg, adb, adl;
+  row_zero(adg); row_zero(adb); row_zero(adl);
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    Row<NCH> dy, x;
+    row_load_bf16(dy, dy_p + row * H, H, lane);
+    row_load_bf16(x, x_p + row * H, H, lane);
+    row_apply_dropmask(dy, H, lane, row, post_thr, post_scale, post_site, seed);
+    row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
+    row_store_bf16(dy, dx_p + row * H, H, lane);
+    if (dxl_p) {
+      row_apply_dropmask(dy, H, lane, row, lin_thr, lin_scale, lin_site, seed);
+      row_store_bf16(dy, dxl_p + row * H, H, lane);
+    }
+    row_acc(adl, dy);
+  }
+  const long nb = gridDim.x;
+  block_reduce_store(adg, red, partials + (0 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(adb, red, partials + (1 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(adl, red, partials + (2 * nb + blockIdx.x) * H, H, lane, wave);
+}
+
+// out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
+// dimension (ldo) > 1 column group: out index = c*stride_q
+struct FinalizeArgs {
+  float* out[8];
+  int stride[8];
+  int Q, nblk, H, accumulate;
+  const float* partials;
+};
+__global__ void finalize_partials_kernel(const FinalizeArgs a) {
+  const int q = blockIdx.y;
+  float* o = a.out[q];
+  if (!o) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.H) return;
+  const float* p = a.partials + ((long)q * a.nblk) * a.H + c;
+  float s = 0.f;
+  for (int b = 0; b < a.nblk; ++b) s += p[(long)b * a.H];
+  const long oi = (long)c * a.stride[q];
+  o[oi] = a.accumulate ? o[oi] + s : s;
+}
+
+// ------------------------------------------------------------------------------ column sum
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ partials, int M, int N) {
+  // block handles a strip of rows; thread handles column pairs
+  const int nb = gridDim.y;
+  const int rows_per = (M + nb - 1) / nb;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= N) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (long)r * ld + c);
+    s0 += bf2f((bf16_t)(u & 0xffff)); s1 += bf2f((bf16_t)(u >> 16));
+  }
+  partials[(long)blockIdx.y * N + c] = s0;
+  partials[(long)blockIdx.y * N + c + 1] = s1;
+}
+
+// ------------------------------------------------------------------------------ row softmax f32 -> bf16
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int M, int F) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const float* xr = x + row * F;
+    float mx = -INFINITY;
+    for (int c = lane * 4; c < F; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane * 4; c < F; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      s += expf(v.x - mx) + expf(v.y - mx) + expf(v.z - mx) + expf(v.w - mx);
+    }
+    const float inv = 1.0f / wave_sum(s);
+    for (int c = lane * 4; c < F; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      uint2 o = make_uint2(pack2bf(expf(v.x - mx) * inv, expf(v.y - mx) * inv), pack2bf(expf(v.z - mx) * inv, expf(v.w - mx) * inv));
+      *reinterpret_cast<uint2*>(y + row * F + c) = o;
+    }
+  }
+}
+
+__global__ void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (; i + 8 <= n; i += stride) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + i + 4);
+    uint4 u = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+    *reinterpret_cast<uint4*>(y + i) = u;
+  }
+  if (i < n && i + 8 > n)
+    for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+}
+
+// ------------------------------------------------------------------------------ text embedding
+// first question/answer token of a batch row (segments -1 or 1), T if none: vilbert.py:327-332
+__device__ __forceinline__ int first_qa_index(const int64_t* segs_row, int T, int lane) {
+  int best = T;
+  for (int t = lane; t < T; t += 64) {
+    const long s = segs_row[t];
+    if (s == -1 || s == 1) { best = t; break; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+  return best;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_text_fwd_kernel(
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ segs, const float* __restrict__ loc,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+    const float* __restrict__ w_loc, const float* __restrict__ b_loc, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ sum_out, bf16_t* __restrict__ y,
+    float* __restrict__ mean_o, float* __restrict__ rstd_o, int B, int T, int H, int n_pos, float eps,
+    uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long M = (long)B * T;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const int b = (int)(row / T), t = (int)(row % T);
+    const long seg = segs[row];
+    const bool qa = (seg == -1 || seg == 1);
+    Row<NCH> r;
+    row_load_f32(r, word + ids[row] * (long)H, H, lane);
+    if (qa) {
+      const int fq = first_qa_index(segs + (long)b * T, T, lane);
+      int pid = t - fq;
+      pid = pid < 0 ? 0 : (pid >= n_pos ? n_pos - 1 : pid);
+      row_add_f32(r, pos + (long)pid * H, H, lane);
+    }
+    if (seg != 0) row_add_f32(r, type + (seg == -1 ? 0 : seg) * (long)H, H, lane);
+    const float4 lv = *reinterpret_cast<const float4*>(loc + row * 4);
+    const float l[4] = {lv.x, lv.y, lv.z, lv.w};
+    if (fabsf(l[0]) + fabsf(l[1]) + fabsf(l[2]) + fabsf(l[3]) != 0.f) row_add_loc_linear(r, w_loc, b_loc, l, H, lane);
+    // the saved pre-norm row is the bf16-rounded one, and the norm is taken over exactly that
+    row_store_bf16(r, sum_out + row * H, H, lane);
+    row_load_bf16(r, sum_out + row * H, H, lane);
+    float mean, rstd;
+    row_stats(r, H, lane, eps, mean, rstd);
+    row_normalize(r, gamma, beta, H, lane, mean, rstd, row, thr, scale, site, seed);
+    row_store_bf16(r, y + row * H, H, lane);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_text_bwd_kernel(
+    const bf16_t* __restrict__ dy_p, const bf16_t* __restrict__ sum_p, const float* __restrict__ mean_p,
+    const float* __restrict__ rstd_p, const int64_t* __restrict__ ids, const int64_t* __restrict__ segs,
+    const float* __restrict__ loc, const float* __restrict__ gamma, float* __restrict__ d_word,
+    float* __restrict__ d_pos, float* __restrict__ d_type, float* __restrict__ partials, int B, int T, int H, int n_pos,
+    uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long M = (long)B * T;
+  Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3;
+  row_zero(adg); row_zero(adb); row_zero(abl); row_zero(aw0); row_zero(aw1); row_zero(aw2); row_zero(aw3);
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const int b = (int)(row / T), t = (int)(row % T);
+    const long seg = segs[row];
+    const bool qa = (seg == -1 || seg == 1);
+    Row<NCH> dy, x;
+    row_load_bf16(dy, dy_p + row * H, H, lane);
+    row_load_bf16(x, sum_p + row * H, H, lane);
+    row_apply_dropmask(dy, H, lane, row, thr, scale, site, seed);
+    row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
+    row_atomic_add(dy, d_word + ids[row] * (long)H, H, lane);
+    if (qa) {
+      const int fq = first_qa_index(segs + (long)b * T, T, lane);
+      int pid = t - fq;
+      pid = pid < 0 ? 0 : (pid >= n_pos ? n_pos - 1 : pid);
+      row_atomic_add(dy, d_pos + (long)pid * H, H, lane);
+    }
+    if (seg != 0) row_atomic_add(dy, d_type + (seg == -1 ? 0 : seg) * (long)H, H, lane);
+    const float4 lv = *reinterpret_cast<const float4*>(loc + row * 4);
+    if (fabsf(lv.x) + fabsf(lv.y) + fabsf(lv.z) + fabsf(lv.w) != 0.f) {
+      row_acc(abl, dy);
+      row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
+    }
+  }
+  const long nb = gridDim.x;
+  block_reduce_store(adg, red, partials + (0 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(adb, red, partials + (1 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(abl, red, partials + (2 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw0, red, partials + (3 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw1, red, partials + (4 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw2, red, partials + (5 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw3, red, partials + (6 * nb + blockIdx.x) * H, H, lane, wave);
+}
+
+// ------------------------------------------------------------------------------ image embedding
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_image_fwd_kernel(
+    const bf16_t* __restrict__ img, const float* __restrict__ loc, const int64_t* __restrict__ target,
+    const float* __restrict__ w_loc, const float* __restrict__ b_loc, const float* __restrict__ color,
+    const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ sum_out,
+    bf16_t* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H, float eps,
+    uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    Row<NCH> r;
+    row_load_bf16(r, img + row * H, H, lane);
+    const float4 lv = *reinterpret_cast<const float4*>(loc + row * 4);
+    const float l[4] = {lv.x, lv.y, lv.z, lv.w};
+    row_add_loc_linear(r, w_loc, b_loc, l, H, lane);
+    row_add_f32(r, color + target[row] * (long)H, H, lane);
+    row_store_bf16(r, sum_out + row * H, H, lane);
+    row_load_bf16(r, sum_out + row * H, H, lane);
+    float mean, rstd;
+    row_stats(r, H, lane, eps, mean, rstd);
+    row_normalize(r, gamma, beta, H, lane, mean, rstd, row, thr, scale, site, seed);
+    row_store_bf16(r, y + row * H, H, lane);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_image_bwd_kernel(
+    const bf16_t* __restrict__ dy_p, const bf16_t* __restrict__ sum_p, const float* __restrict__ mean_p,
+    const float* __restrict__ rstd_p, const float* __restrict__ loc, const int64_t* __restrict__ target,
+    const float* __restrict__ gamma, bf16_t* __restrict__ dsum_p, float* __restrict__ d_color,
+    float* __restrict__ partials, int M, int H, uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3;
+  row_zero(adg); row_zero(adb); row_zero(abl); row_zero(aw0); row_zero(aw1); row_zero(aw2); row_zero(aw3);
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    Row<NCH> dy, x;
+    row_load_bf16(dy, dy_p + row * H, H, lane);
+    row_load_bf16(x, sum_p + row * H, H, lane);
+    row_apply_dropmask(dy, H, lane, row, thr, scale, site, seed);
+    row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
+    row_store_bf16(dy, dsum_p + row * H, H, lane);
+    row_atomic_add(dy, d_color + target[row] * (long)H, H, lane);
+    const float4 lv = *reinterpret_cast<const float4*>(loc + row * 4);
+    row_acc(abl, dy);       // = d b_loc = d b_img (both are plain column sums of d_sum)
+    row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
+  }
+  const long nb = gridDim.x;
+  block_reduce_store(adg, red, partials + (0 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(adb, red, partials + (1 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(abl, red, partials + (2 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw0, red, partials + (3 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw1, red, partials + (4 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw2, red, partials + (5 * nb + blockIdx.x) * H, H, lane, wave);
+  block_reduce_store(aw3, red, partials + (6 * nb + blockIdx.x) * H, H, lane, wave);
+}
+
+inline int nch_for(int H) { return (H / 8 + 63) / 64; }
+inline int row_grid(long M, int cap) {
+  long g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+#define DISPATCH_NCH(H, ...)                                           \
+  switch (nch_for(H)) {                                                \
+    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;             \
+    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
+    case 3: { constexpr int NCH = 3; __VA_ARGS__; } break;             \
+    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
+    default: crct_set_error("row width %d > 2048 unsupported", H); return 2; \
+  }
+
+int launch_finalize(const FinalizeArgs& fa, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3((fa.H + 127) / 128, fa.Q), dim3(128), 0, s, fa);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       int M, int H, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site,
+                       uint64_t seed, crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm: H=%d must be a positive multiple of 8", H);
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
+                                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr,
+                                     drop_scale, drop_site, seed));
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_layernorm_bwd_blocks(int M) { return row_grid(M, 256); }
+
+int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       void* dx, void* dx_lin, float* dgamma, float* dbeta, float* dbias_lin, float* partials,
+                       int M, int H, int accumulate, uint32_t post_thr, float post_scale, uint32_t post_site,
+                       uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed, crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm_bwd: H=%d must be a positive multiple of 8", H);
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = crct_layernorm_bwd_blocks(M);
+  const size_t lds = (size_t)4 * H * sizeof(float);
+  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
+                                     (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin, partials, M, H,
+                                     post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
+  CRCT_CHECK_HIP(hipGetLastError());
+  FinalizeArgs fa = {};
+  fa.out[0] = dgamma; fa.out[1] = dbeta; fa.out[2] = dbias_lin;
+  fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
+  fa.Q = 3; fa.nblk = nb; fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
+  return launch_finalize(fa, s);
+}
+
+int crct_colsum_blocks(int M) { int b = (M + 31) / 32; return b < 1 ? 1 : (b > 64 ? 64 : b); }
+
+int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int M, int N, int accumulate,
+                     crct_stream_t stream) {
+  CRCT_REQUIRE(N % 2 == 0 && ld % 2 == 0, "colsum: N=%d and ld must be even", N);
+  if (N <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = crct_colsum_blocks(M);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N / 2 + 255) / 256, nb), dim3(256), 0, s, (const bf16_t*)x, (long)ld, partials, M, N);
+  CRCT_CHECK_HIP(hipGetLastError());
+  FinalizeArgs fa = {};
+  fa.out[0] = out; fa.stride[0] = 1; fa.Q = 1; fa.nblk = nb; fa.H = N; fa.accumulate = accumulate; fa.partials = partials;
+  return launch_finalize(fa, s);
+}
+
+int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_stream_t stream) {
+  CRCT_REQUIRE(F % 4 == 0, "softmax_rows: F=%d must be a multiple of 4", F);
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, M, F);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream) {
+  if (n <= 0) return 0;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* loc, const float* word, const float* pos,
+                        const float* type, const float* w_loc, const float* b_loc, const float* gamma,
+                        const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int T, int H,
+                        int n_pos, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                        crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_text: H=%d must be a positive multiple of 8", H);
+  if ((long)B * T <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_fwd_kernel<NCH>), dim3(row_grid((long)B * T, 2048)), dim3(256), 0, s, ids,
+                                     segs, loc, word, pos, type, w_loc, b_loc, gamma, beta, (bf16_t*)sum_out, (bf16_t*)y,
+                                     mean, rstd, B, T, H, n_pos, eps, drop_thr, drop_scale, drop_site, seed));
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
+                                        const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
+                                        float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
+                                        float* d_gamma, float* d_beta, float* partials, int B, int T, int H, int n_pos,
+                                        uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                                        crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_text_bwd: H=%d must be a positive multiple of 8", H);
+  const long M = (long)B * T;
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = crct_layernorm_bwd_blocks((int)M);
+  const size_t lds = (size_t)4 * H * sizeof(float);
+  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
+                                     (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
+                                     partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed));
+  CRCT_CHECK_HIP(hipGetLastError());
+  FinalizeArgs fa = {};
+  fa.out[0] = d_gamma; fa.out[1] = d_beta; fa.out[2] = d_bloc;
+  fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
+  for (int k = 0; k < 4; ++k) { fa.out[3 + k] = d_wloc ? d_wloc + k : nullptr; fa.stride[3 + k] = 4; }
+  fa.Q = 7; fa.nblk = nb; fa.H = H; fa.accumulate = 1; fa.partials = partials;
+  return launch_finalize(fa, s);
+}
+
+extern "C" int crct_embed_image_fwd(const void* img_lin, const float* loc, const int64_t* target, const float* w_loc,
+                                    const float* b_loc, const float* color, const float* gamma, const float* beta,
+                                    void* sum_out, void* y, float* mean, float* rstd, int M, int H, float eps,
+                                    uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                                    crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_image: H=%d must be a positive multiple of 8", H);
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
+                                     (const bf16_t*)img_lin, loc, target, w_loc, b_loc, color, gamma, beta,
+                                     (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed));
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int crct_embed_image_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
+                                    const float* loc, const int64_t* target, const float* gamma, void* d_sum,
+                                    float* d_color, float* d_wloc, float* d_bloc, float* d_bimg, float* d_gamma,
+                                    float* d_beta, float* partials, int M, int H, uint32_t drop_thr, float drop_scale,
+                                    uint32_t drop_site, uint64_t seed, crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_image_bwd: H=%d must be a positive multiple of 8", H);
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = crct_layernorm_bwd_blocks(M);
+  const size_t lds = (size_t)4 * H * sizeof(float);
+  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
+                                     (const bf16_t*)sum_saved, mean, rstd, loc, target, gamma, (bf16_t*)d_sum, d_color,
+                                     partials, M, H, drop_thr, drop_scale, drop_site, seed));
+  CRCT_CHECK_HIP(hipGetLastError());
+  // two finalize passes share the column-sum partial (index 2): b_loc and b_img
+  FinalizeArgs fa = {};
+  fa.out[0] = d_gamma; fa.out[1] = d_beta; fa.out[2] = d_bloc;
+  fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
+  for (int k = 0; k < 4; ++k) { fa.out[3 + k] = d_wloc ? d_wloc + k : nullptr; fa.stride[3 + k] = 4; }
+  fa.Q = 7; fa.nblk = nb; fa.H = H; fa.accumulate = 1; fa.partials = partials;
+  if (launch_finalize(fa, s)) return 1;
+  if (d_bimg) {
+    FinalizeArgs fb = {};
+    fb.out[0] = d_bimg; fb.stride[0] = 1; fb.Q = 1; fb.nblk = nb; fb.H = H; fb.accumulate = 1;
+    fb.partials = partials + (size_t)2 * nb * H;
+    return launch_finalize(fb, s);
+  }
+  return 0;
+}

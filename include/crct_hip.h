@@ -1,0 +1,273 @@
+/* crct_hip.h -- C ABI of libcrct_hip.so: the MI355X (gfx950) CRCT co-attention training step.
+ *
+ * The reference (levymsn/CQA-CRCT) has no FFI: its boundary for this path is the Python surface
+ * train.py uses.  This header is the native boundary underneath our mirror of that
+ * surface (cqa-crct_amd/crct): plain pointers, sizes and a HIP stream -- no torch types.  Every
+ * entry point cites the reference code whose arithmetic it replaces.  All device pointers are HBM
+ * addresses owned by the caller; all kernels are enqueued on `stream` and never synchronise.
+ *
+ * Return value: 0 on success, non-zero on error (message via crct_last_error()).
+ * Activations / activation gradients are bf16 (raw uint16 bits), statistics, parameters,
+ * parameter gradients and optimizer state are fp32.
+ */
+#ifndef CRCT_HIP_H
+#define CRCT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* crct_stream_t; /* hipStream_t */
+
+enum { CRCT_ACT_NONE = 0, CRCT_ACT_GELU = 1, CRCT_ACT_RELU = 2, CRCT_ACT_LEAKY = 3, CRCT_ACT_TANH = 4 };
+
+const char* crct_last_error(void);
+int crct_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue.  C[M][N] = epi( alpha * sum_k A'(m,k) B'(n,k) )
+ *   ta = 0: A'(m,k) = A[m*lda + k]   ta = 1: A'(m,k) = A[k*lda + m]      (bf16)
+ *   tb = 0: B'(n,k) = B[n*ldb + k]   tb = 1: B'(n,k) = B[k*ldb + n]      (bf16)
+ * epilogue order: *alpha, +bias[n], store pre-activation, act, *act'(dact_src), dropout, +addend,
+ * (+C if accumulate), store as bf16 or fp32.
+ * Replaces nn.Linear forward / dgrad / wgrad everywhere in CRCT/backbone/vilbert.py
+ * (:388-390 :425 :455 :468 :518-520 :662-675 :749-752 :959 :974 :1060) and regressor.py:8-34.
+ * Requirements: lda, ldb, ldc, ld_aux, ld_add multiples of 8 elements, N % 4 == 0, K % 8 == 0,
+ * and for a transposed operand its row extent (M for ta, N for tb) % 8 == 0; pointers 16-byte aligned.
+ */
+typedef struct CrctGemmArgs {
+  const void* A; const void* B; void* C;
+  const float* bias;        /* [N] or NULL */
+  void* preact_out;         /* bf16 [M][ld_aux] or NULL: value before `act` */
+  const void* dact_src;     /* bf16 [M][ld_aux] or NULL: multiply by act'(.) of kind `dact` */
+  const void* addend;       /* bf16 [M][ld_add] or NULL */
+  int64_t lda, ldb, ldc, ld_aux, ld_add;
+  int32_t M, N, K;
+  int32_t ta, tb;
+  int32_t act, dact;
+  int32_t c_is_f32, accumulate;
+  int32_t tile;             /* -1 = auto; 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64 */
+  float alpha;
+  uint32_t drop_thr;        /* 0 = no dropout, else keep iff philox_u32 >= thr */
+  float drop_scale;         /* 1/(1-p) */
+  uint32_t drop_site;
+  uint64_t seed;
+} CrctGemmArgs;
+
+int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row LayerNorm (TF style, eps inside sqrt) -- BertLayerNorm, vilbert.py:281-294 -- over rows that
+ * already hold dense(x)+dropout+residual (the GEMM epilogue adds them).
+ *   y = gamma * (x - mean) * rstd + beta ; optional inverted dropout AFTER the norm (embeddings,
+ *   vilbert.py:356-357, :1494-1495).  x, y bf16 [M][H]; mean, rstd fp32 [M].
+ */
+int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int M, int H, float eps,
+                       uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                       crct_stream_t stream);
+
+/* LayerNorm backward.  dy bf16 [M][H] (gradient w.r.t. y, or w.r.t. post-norm-dropout output when
+ * post_* is set), x = saved pre-norm rows.  Writes
+ *   dx      bf16 [M][H]   gradient w.r.t. the pre-norm sum (also the residual branch's gradient)
+ *   dx_lin  bf16 [M][H]   (optional) dx with the PRE-norm dropout mask of the producing Linear
+ *                         re-applied (site/seed of that Linear's epilogue) = gradient of dense(x)
+ *   dgamma, dbeta, dbias_lin  fp32 [H]: column sums (dbias_lin = colsum(dx_lin or dx)), written or
+ *                         accumulated (`accumulate`).  `partials` is fp32 scratch [3][nblk][H],
+ *                         nblk = crct_layernorm_bwd_blocks(M).
+ */
+int crct_layernorm_bwd_blocks(int M);
+int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
+                       const float* gamma, void* dx, void* dx_lin,
+                       float* dgamma, float* dbeta, float* dbias_lin, float* partials,
+                       int M, int H, int accumulate,
+                       uint32_t post_thr, float post_scale, uint32_t post_site,
+                       uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
+                       crct_stream_t stream);
+
+/* Column sum of a bf16 [M][ld] matrix into fp32 out[N] (bias gradients).  partials: [nblk][N]. */
+int crct_colsum_blocks(int M);
+int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int M, int N,
+                     int accumulate, crct_stream_t stream);
+
+/* Row softmax fp32 [M][F] -> bf16 [M][F]  (F.softmax(image_feat), vilbert.py:1476). */
+int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_stream_t stream);
+
+/* fp32 -> bf16 copy (weight shadow refresh). */
+int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention over short sequences, one workgroup per (batch, head), everything
+ * in LDS: P = softmax(q k^T / sqrt(d) + (1-keymask)*-10000), dropout(P), ctx = P v.
+ * Replaces vilbert.py:392-412 (text self), :522-543 (visual self), :684-701 / :704-723 (co-attn).
+ * q [B][Tq][ldq], k/v [B][Tk][ldk] bf16 with head h at column h*d; keymask fp32/int-free: uint8 [B][Tk]
+ * (1 = attend); ctx bf16 [B][Tq][ldo].  Tq, Tk <= 128, d <= 64, d % 8 == 0.
+ */
+int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx,
+                       int B, int heads, int Tq, int Tk, int d,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                       uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                       crct_stream_t stream);
+/* Backward: recomputes P from q,k (no probabilities are stored).  dq/dk/dv have the layout of q/k/v.
+ * accumulate_kv != 0 adds into dk/dv instead of overwriting (unused by the step; kept for tests). */
+int crct_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* keymask,
+                       const void* dctx, void* dq, void* dk, void* dv,
+                       int B, int heads, int Tq, int Tk, int d,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                       int64_t lddq, int64_t lddk, int64_t lddv,
+                       uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                       crct_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Text embeddings: BertEmbeddingLocation.forward, vilbert.py:320-358.
+ *  sum = word[ids] + pos[posid]*(qa) + type[seg']*(seg != 0) + (W_loc loc + b_loc)*(|loc|_1 != 0)
+ *  y = dropout(LN(sum)).  Writes the pre-norm sum (bf16), y (bf16), mean/rstd.
+ */
+int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* loc,
+                        const float* word, const float* pos, const float* type,
+                        const float* w_loc, const float* b_loc, const float* gamma, const float* beta,
+                        void* sum_out, void* y, float* mean, float* rstd,
+                        int B, int T, int H, int n_pos, float eps,
+                        uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                        crct_stream_t stream);
+/* Backward: scatter-adds (fp32 atomics) into the word / position / type tables, reduces the
+ * loc-Linear and LayerNorm parameter gradients.  partials: fp32 [7][nblk][H], nblk = crct_layernorm_bwd_blocks(B*T).
+ * All parameter-gradient outputs are ACCUMULATED into (caller zeroes the gradient buffer per step). */
+int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
+                        const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
+                        float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
+                        float* d_gamma, float* d_beta, float* partials,
+                        int B, int T, int H, int n_pos,
+                        uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                        crct_stream_t stream);
+
+/* Image embeddings: BertImageEmbeddings.forward (dataset 'plotqa'), vilbert.py:1474-1496.
+ *  sum = img_lin (bf16 [M][H], = new_image_embeddings(softmax(feat)) from the GEMM) + W_loc loc + b_loc
+ *        + color_emb[target];  y = dropout(LN(sum)). */
+int crct_embed_image_fwd(const void* img_lin, const float* loc, const int64_t* target,
+                         const float* w_loc, const float* b_loc, const float* color,
+                         const float* gamma, const float* beta,
+                         void* sum_out, void* y, float* mean, float* rstd,
+                         int M, int H, float eps,
+                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                         crct_stream_t stream);
+/* Backward: d_sum (bf16 [M][H], feeds the wgrad GEMM of new_image_embeddings), color scatter-add,
+ * loc-Linear / LayerNorm / image-Linear-bias gradients (accumulated).  partials: fp32 [8][nblk][H]. */
+int crct_embed_image_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
+                         const float* loc, const int64_t* target, const float* gamma,
+                         void* d_sum, float* d_color, float* d_wloc, float* d_bloc, float* d_bimg,
+                         float* d_gamma, float* d_beta, float* partials,
+                         int M, int H,
+                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                         crct_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Heads + losses: BertPreTrainingHeads.forward (vilbert.py:1048-1062), the tail of
+ * PlotQA_Regressor_v20 (regressor.py:31-41: Linear(256,1)+Tanh), the regression bookkeeping and
+ * CrossEntropyLoss(ignore_index=-1) of vilbert.py:1583-1657, and the loss combination of
+ * encoder_decorator.py:144-153 -- one launch, no host sync.
+ *  pooled_t, pooled_v  bf16 [B][Hb] (relu'd pooler outputs), fus_h bf16 [B][256] (LeakyReLU(fusion.4(..)))
+ *  outputs: logits fp32 [B][2]; reg fp32 [5][B] = pred*scale, reg_loss, reg_l1, raw tanh output, dist5;
+ *           stats fp32 [8] = loss, nsp_loss, mean_B reg_loss, n_needs, n_right5, n_rightT, n_valid_labels, 0
+ *  gradient seeds, already multiplied by grad_scale (* *loss_scale_dev): d_pooled_t / d_pooled_v
+ *  bf16 [B][Hb] = gradient w.r.t. the poolers' PRE-activations (dropout and ReLU undone),
+ *  d_fus_h bf16 [B][256] = gradient w.r.t. fusion.4's pre-activation; parameter gradients of
+ *  bi_seq_relationship / fusion.6 are ACCUMULATED into d_w_cls[2][Hb], d_b_cls[2], d_w_f6[256], d_b_f6[1].
+ */
+typedef struct CrctHeadArgs {
+  const void* pooled_t; const void* pooled_v; const void* fus_h;
+  const float* w_cls; const float* b_cls; const float* w_f6; const float* b_f6;
+  const float* R;                 /* [B][4] gt, needs, tol, scale */
+  const int64_t* labels;          /* [B] or NULL (evaluation) */
+  float* logits; float* reg; float* stats;
+  float* scratch;                 /* fp32 [B][8] per-row records (dlogits, dz, loss terms) */
+  void* d_pooled_t; void* d_pooled_v; void* d_fus_h;   /* NULL in evaluation */
+  float* d_w_cls; float* d_b_cls; float* d_w_f6; float* d_b_f6;
+  const float* loss_scale_dev;    /* optional device scalar multiplied into every gradient */
+  int32_t B, Hb;
+  int32_t fusion_sum;             /* 0 = 'mul' (default, vilbert.py:163), 1 = 'sum' */
+  int32_t use_l1;                 /* params['L1'] : L1Loss vs SmoothL1Loss(beta=0.5), vilbert.py:1525-1528 */
+  int32_t kind_l1;                /* reg_loss_kind == 'L1' (evaluation) -> no zeroing of |target|>1 */
+  float tol_margin, nsp_coeff, reg_coeff, grad_scale;
+  uint32_t drop_thr; float drop_scale; uint32_t drop_site; uint64_t seed;   /* cls.dropout (0.1) */
+} CrctHeadArgs;
+int crct_head_loss(const CrctHeadArgs* args, crct_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW (torch.optim.AdamW semantics as constructed by utils.py:228-249) over
+ * the flat fp32 parameter / gradient / moment buffers, refreshing the bf16 weight shadow.
+ * seg_* describe the tensors that receive gradients: element offset, length, lr, weight decay.
+ * blk_seg / blk_off: per-workgroup (segment id, element offset inside it), built by the caller
+ * with crct_adamw_plan().  inv_scale_dev: optional device scalar dividing the gradients (GradScaler).
+ */
+int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap);
+int crct_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
+                    const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
+                    const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk,
+                    float beta1, float beta2, float eps, int step, const float* inv_scale_dev,
+                    crct_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Step engine: the whole forward + loss + backward of one batch as one native call
+ * (encoder_decorator.forward + BertForMultiModalPreTraining.forward + autograd of both;
+ * encoder_decorator.py:73-158, vilbert.py:1540-1661, layer order vilbert.py:852-939).
+ */
+typedef struct CrctModelDims {
+  int32_t vocab, n_pos, n_types, H, L, heads, I;
+  int32_t Fv, Hv, Lv, v_heads, Iv, Hb, b_heads, n_color;
+  int32_t n_conn;
+  int32_t v_biatt[32], t_biatt[32];
+  int32_t fusion_sum, with_coattention;
+  float p_hidden, p_attn, p_v_hidden, p_v_attn, p_cls;
+} CrctModelDims;
+
+typedef struct crct_engine crct_engine_t;
+
+/* names: '\n'-joined parameter keys (reference state_dict names without 'bert_pretrained.'),
+ * offsets / sizes: element offset and element count of each in the flat buffers. */
+crct_engine_t* crct_engine_create(const CrctModelDims* dims, const char* names, const int64_t* offsets,
+                                  const int64_t* sizes, int n_params, int max_B, int max_T, int max_V);
+void crct_engine_destroy(crct_engine_t*);
+size_t crct_engine_workspace_bytes(const crct_engine_t*);
+int crct_engine_num_segments(const crct_engine_t*);
+/* Backward segment s (0 = heads ... last = embeddings) has finished writing gradient elements
+ * [lo, hi) of the flat gradient buffer once crct_engine_backward(.., s, ..) returns. */
+int crct_engine_segment_range(const crct_engine_t*, int seg, int64_t* lo, int64_t* hi);
+
+typedef struct CrctBatch {
+  const int64_t* tokens; const int64_t* segments; const float* loc; const uint8_t* text_keymask;
+  const float* image_feat; const float* image_loc; const int64_t* image_target; const uint8_t* image_keymask;
+  const float* R; const int64_t* labels;   /* labels NULL => evaluation */
+  int32_t B, T, V;
+} CrctBatch;
+
+typedef struct CrctStepCfg {
+  int32_t training;          /* dropout on/off */
+  int32_t use_l1, kind_l1;
+  float tol_margin, nsp_coeff, reg_coeff, grad_scale;
+  uint64_t seed;
+  const float* loss_scale_dev;
+} CrctStepCfg;
+
+int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,
+                        const CrctBatch* batch, const CrctStepCfg* cfg, void* workspace,
+                        float* logits, float* reg, float* stats, crct_stream_t stream);
+/* Backward of the batch whose forward was the last crct_engine_forward on this workspace.
+ * seg < 0 runs every segment, else segments must be issued in order 0 .. num_segments-1.
+ * Gradients are ACCUMULATED into grads_f32 (zero it per optimizer step).  Segment 0 re-evaluates the
+ * loss kernel with gradient outputs on, so logits / reg / stats are (re)written identically. */
+int crct_engine_backward(crct_engine_t*, const float* params_f32, const void* params_bf16,
+                         const CrctBatch* batch, const CrctStepCfg* cfg, void* workspace,
+                         float* grads_f32, float* logits, float* reg, float* stats, int seg,
+                         crct_stream_t stream);
+/* Debug taps: copy a named bf16 activation ("emb.t", "t3.t", "c0.v", "seq_t" ...) of the last
+ * forward (batch B, T, V) into `out` (device, bf16); returns the element count or -1. */
+int64_t crct_engine_tap(crct_engine_t*, const void* workspace, const char* name, int B, int T, int V,
+                        void* out, int64_t cap, crct_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,224 @@
+"""Generate the golden fixtures by RUNNING THE REFERENCE (build container only).
+
+Imports levymsn/CQA-CRCT from /root/reference on CPU (three sys.modules shims),
+builds ``BertForMultiModalPreTraining`` the way ``VisualDialogEncoder.__init__`` /
+``from_pretrained`` do before weight loading (encoder_decorator.py:11-17, vilbert.py:1205), fills
+it with name-keyed seeded weights, feeds seeded synthetic batches through the reference's own
+``encoder_decorator.forward`` + ``loss.backward()``, and writes inputs / outputs / gradients as
+.npz files next to this script.  Reference source never enters the repo; only these vectors do.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "cqa-crct_amd"))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/CRCT"
+
+from crct import config as C          # noqa: E402
+from crct import synthetic as S       # noqa: E402
+from oracle import crct_oracle as O   # noqa: E402
+
+
+def import_reference():
+    m = types.ModuleType("pytorch_pretrained_bert")
+    fu = types.ModuleType("pytorch_pretrained_bert.file_utils")
+    fu.cached_path = lambda *a, **k: (_ for _ in ()).throw(EnvironmentError("no network"))
+    m.file_utils = fu
+    sys.modules["pytorch_pretrained_bert"] = m
+    sys.modules["pytorch_pretrained_bert.file_utils"] = fu
+    sys.path.insert(0, REF)
+    from backbone import vilbert, encoder_decorator   # type: ignore
+    return vilbert, encoder_decorator
+
+
+def build_reference_model(vilbert, encoder_decorator, cfg, params):
+    rcfg = vilbert.BertConfig.from_dict(cfg.to_dict())
+    model = encoder_decorator.VisualDialogEncoder.__new__(encoder_decorator.VisualDialogEncoder)
+    torch.nn.Module.__init__(model)
+    model.bert_pretrained = vilbert.BertForMultiModalPreTraining(rcfg, params=params)
+    model.bert_pretrained.cls.dropout.p = 0.0      # hard-coded 0.1 at vilbert.py:1045
+    model.train()
+    return model
+
+
+def run_case(name, cfg, params, batch, vilbert, ed, save_weights, evaluation=False, grad_sample=None):
+    params = dict(params)
+    params["device"] = torch.device("cpu")
+    model = build_reference_model(vilbert, ed, cfg, params)
+    S.seeded_fill_(model.state_dict(), base_seed=7)
+    sd = {k[len("bert_pretrained."):]: v for k, v in model.named_parameters()}
+    # -------- reference
+    out = ed.forward(model, {k: v.clone() for k, v in batch.items()}, params, evaluation=evaluation)
+    if evaluation:
+        loss, lm, nsp, img, scores, reg = out
+    else:
+        loss, lm, nsp, img, scores, reg, leg = out
+        loss.backward()
+    # -------- oracle on the same weights (sanity; the test suite re-checks from the files)
+    osd = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    taps = {}
+    oout = O.oracle_step(osd, cfg, params, batch, evaluation=evaluation, training=True, taps=taps,
+                         cls_dropout=0.0)
+    if not evaluation:
+        oout[0].backward()
+        d = abs(float(oout[0]) - float(loss))
+        print("  [%s] loss ref %.8f oracle %.8f |d|=%.2e" % (name, float(loss), float(oout[0]), d))
+        assert d < 1e-5
+        worst = 0.0
+        for k, p in sd.items():
+            if p.grad is None:
+                assert osd[k].grad is None or float(osd[k].grad.abs().max()) == 0.0, k
+                continue
+            # key biases have a mathematically zero gradient (softmax shift invariance): 1e-10 noise
+            den = float(p.grad.abs().max()) + 1e-6
+            worst = max(worst, float((p.grad - osd[k].grad).abs().max()) / den)
+        print("  [%s] worst relative grad diff %.2e" % (name, worst))
+        assert worst < 1e-3
+    assert float((oout[4] - scores).abs().max()) < 1e-5
+    assert float((oout[5][0] - reg[0]).abs().max()) < 1e-3
+
+    rec = {"in." + k: v.numpy() for k, v in batch.items()}
+    rec["out.nsp_scores"] = scores.detach().numpy()
+    rec["out.reg_pred"] = reg[0].detach().numpy()
+    rec["out.reg_loss"] = reg[1].detach().numpy()
+    rec["out.reg_l1"] = reg[2].detach().numpy()
+    rec["out.reg_right"] = np.array(reg[3], dtype=np.int64)
+    rec["out.reg_dist5"] = reg[4].detach().numpy()
+    # hidden states of the reference at the heads' inputs (recomputed through the reference modules)
+    with torch.no_grad():
+        bp = model.bert_pretrained
+        T = batch["tokens"].shape[1]
+        key_t = O.text_key_mask(batch["sep_indices"], batch["hist_len"], T)
+        seq_t, seq_v, _, _, _ = bp.bert(batch["tokens"], batch["loc"], batch["image_feat"], batch["image_loc"],
+                                        token_type_ids=batch["segments"], attention_mask=key_t,
+                                        image_attention_mask=batch["image_mask"],
+                                        image_target=batch["image_target"])
+        rec["out.seq_t_cls"] = seq_t[:, 0].numpy()
+        rec["out.seq_v_img"] = seq_v[:, 0].numpy()
+        rec["out.emb_t"] = bp.bert.embeddings(batch["tokens"], token_type_ids=batch["segments"],
+                                              loc=batch["loc"]).numpy()
+        rec["out.emb_v"] = bp.bert.v_embeddings(batch["image_feat"], batch["image_loc"],
+                                                batch["image_target"], None).numpy()
+    if not evaluation:
+        rec["out.loss"] = np.array(float(loss), dtype=np.float64)
+        rec["out.nsp_loss"] = nsp.detach().numpy()
+        for k, p in sd.items():
+            if p.grad is None:
+                rec["gradnorm." + k] = np.array(-1.0)          # never receives a gradient
+                continue
+            g = p.grad
+            rec["gradnorm." + k] = np.array(float(g.double().norm()))
+            if save_weights:
+                rec["grad." + k] = g.numpy()
+            else:
+                flat = g.reshape(-1)
+                n = min(flat.numel(), 64)
+                idx = (torch.arange(n, dtype=torch.int64) * (flat.numel() - 1)) // max(n - 1, 1)
+                rec["gradidx." + k] = idx.numpy()
+                rec["gradsample." + k] = flat[idx].numpy()
+    if save_weights:
+        for k, p in sd.items():
+            rec["w." + k] = p.detach().numpy()
+    meta = dict(cfg=cfg.to_dict(), params={k: v for k, v in params.items() if k != "device"},
+                evaluation=evaluation, weight_seed=7, cls_dropout=0.0)
+    rec["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("  wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+    return model
+
+
+def optimizer_case(vilbert, ed):
+    """One AdamW + WarmupLinearScheduleNonZero step of the reference's own utils.py on the tiny model."""
+    sys.modules.setdefault("pandas", __import__("pandas"))
+    import importlib
+    utils = importlib.import_module("utils")
+    cfg = C.tiny_config()
+    params = C.default_params(categories=9, L1=True, device=torch.device("cpu"))
+    model = build_reference_model(vilbert, ed, cfg, params)
+    S.seeded_fill_(model.state_dict(), base_seed=7)
+    batch = S.make_batch(3, 7, 5, cfg.v_feature_size, categories=9, vocab_size=cfg.vocab_size, seed=11)
+    cwd = os.getcwd()
+    os.chdir(REF)                      # get_optimizer opens config/language_weights.json relative to CWD
+    try:
+        opt = utils.get_optimizer(params, model)
+    finally:
+        os.chdir(cwd)
+    sched = utils.WarmupLinearScheduleNonZero(opt, warmup_steps=4, t_total=10, min_lr=1.3e-5)
+    rec = {}
+    lrs = []
+    for it in range(3):
+        out = ed.forward(model, {k: v.clone() for k, v in batch.items()}, params)
+        out[0].backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    for k, p in model.named_parameters():
+        rec["w3." + k[len("bert_pretrained."):]] = p.detach().numpy()
+    rec["lrs"] = np.array(lrs)
+    rec["groups_lr_wd"] = np.array([[g["lr"], g["weight_decay"]] for g in opt.param_groups])
+    # schedule table (utils.py:22-29)
+    steps = [0, 1, 2999, 3000, 3001, 50000, 59999, 60000, 70000]
+    s2 = utils.WarmupLinearScheduleNonZero(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=2e-5),
+                                           warmup_steps=3000, t_total=60000, min_lr=1.3e-5)
+    vals = []
+    for st in steps:
+        s2.last_epoch = st
+        vals.append(s2.get_lr()[0])
+    rec["sched_steps"] = np.array(steps)
+    rec["sched_lr"] = np.array(vals)
+    path = os.path.join(HERE, "tiny_adamw3.npz")
+    np.savez_compressed(path, **rec)
+    print("  wrote", path)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    vilbert, ed = import_reference()
+    # ---- tiny config, full weights + all gradients committed
+    tiny = C.tiny_config()
+    p_tiny = C.default_params(categories=9)
+    b = S.make_batch(3, 7, 5, tiny.v_feature_size, categories=9, vocab_size=tiny.vocab_size, seed=11)
+    # edge cases for the embeddings: all-zero loc rows, segments incl. -1,0,1,2..11
+    b["segments"][0, 1] = 2
+    b["segments"][1, 1] = 3
+    b["loc"][0, 1] = 0
+    b["R"][0, 1] = 1.0
+    b["R"][1, 1] = 0.0
+    b["R"][2, 1] = 1.0
+    b["R"][2, 0] = 0.0                      # target == 0 rule (vilbert.py:1633)
+    b["next_sentence_labels"][1, 0] = -1    # ignore_index row
+    b["needs_reg"] = (b["R"][:, 1:2] == 1)
+    run_case("tiny_L1", tiny, p_tiny, b, vilbert, ed, save_weights=True)
+    p_s = dict(p_tiny, L1=False)
+    b2 = {k: v.clone() for k, v in b.items()}
+    b2["R"][0, 0] = 250.0                   # |target| > 1 -> zeroed in 'L1_smooth' kind (vilbert.py:1641)
+    run_case("tiny_smoothL1", tiny, p_s, b2, vilbert, ed, save_weights=False)
+    run_case("tiny_eval", tiny, p_tiny, b2, vilbert, ed, save_weights=False, evaluation=True)
+    optimizer_case(vilbert, ed)
+    # ---- full vilbert.json shapes, seeded weights: only inputs / outputs / gradient samples committed
+    for nm, B, V, T, Fv in (("full_B4_V36_T20_F1024", 4, 36, 20, 1024),
+                            ("full_B4_V36_T20_F2048", 4, 36, 20, 2048),
+                            ("full_B2_V100_T40_F2048", 2, 100, 40, 2048)):
+        cfg = C.vilbert_config(v_feature_size=Fv, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                               v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
+        params = C.default_params()
+        batch = S.make_batch(B, T, V, Fv, seed=1234)
+        # keep the committed inputs small: features rounded to fp16-representable values
+        batch["image_feat"] = batch["image_feat"].half().float()
+        run_case(nm, cfg, params, batch, vilbert, ed, save_weights=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,261 @@
+"""Kernel-level parity (-m gpu): every launcher of libcrct_hip.so, called through the C ABI, against
+plain fp32 PyTorch / the CPU oracle on identical seeded inputs.
+
+Tolerances (stated per SURVEY.md 8c): kernels take bf16 operands and accumulate in fp32, so against an
+fp32 reference evaluated on the SAME bf16-rounded operands the only differences are accumulation
+order and the final bf16 rounding of the output: |err| <= 1e-2 * max|ref| for bf16 outputs,
+<= 2e-3 * max|ref| for fp32 outputs.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from crct import ops, lib as L   # noqa: E402
+from oracle import crct_oracle as O   # noqa: E402
+
+DEV = "cuda"
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1600, 3072, 768), (2880, 1024, 2048), (1600, 768, 3072), (80, 1024, 768),
+                                   (21, 64, 96), (15, 128, 32), (300, 2304, 768)])
+@pytest.mark.parametrize("tile", [-1, 0, 3])
+def test_gemm_forward(M, N, K, tile):
+    x, w, b = bf(rand(M, K, seed=1)), bf(rand(N, K, scale=0.05, seed=2)), rand(N, seed=3)
+    y = ops.gemm(x, w, M, N, K, bias=b, tile=tile)
+    ref = x.float() @ w.float().t() + b
+    assert rel_err(y, ref) < 1e-2
+    y32 = ops.gemm(x, w, M, N, K, bias=b, out_f32=True, tile=tile)
+    assert rel_err(y32, ref) < 2e-3
+
+
+def test_gemm_identity_asymmetric():
+    # A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)
+    n = 128
+    eye = bf(torch.eye(n, device=DEV))
+    w = bf(torch.arange(n * n, device=DEV, dtype=torch.float32).reshape(n, n) % 251 - 125)
+    y = ops.gemm(eye, w, n, n, n, out_f32=True)
+    assert torch.equal(y, w.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(1600, 768, 2304), (2880, 1024, 3072), (21, 64, 192), (80, 768, 1024)])
+def test_gemm_dgrad(M, N, K):
+    # dx[M][N=in] = dy[M][K=out] @ W[K=out][N=in]
+    dy, w = bf(rand(M, K, seed=4)), bf(rand(K, N, scale=0.05, seed=5))
+    add = bf(rand(M, N, seed=6))
+    dx = ops.gemm(dy, w, M, N, K, tb=True, addend=add)
+    ref = dy.float() @ w.float() + add.float()
+    assert rel_err(dx, ref) < 1e-2
+
+
+@pytest.mark.parametrize("R,N,K", [(1600, 768, 3072), (2880, 1024, 1024), (21, 64, 128), (80, 1024, 768), (1600, 2304, 768)])
+def test_gemm_wgrad(R, N, K):
+    # dW[N=out][K=in] = dy[R][N]^T @ x[R][K]; fp32 output, accumulate
+    dy, x = bf(rand(R, N, seed=7)), bf(rand(R, K, seed=8))
+    out = torch.ones(N, K, device=DEV)
+    ops.gemm(dy, x, N, K, R, ta=True, tb=True, lda=N, ldb=K, out=out, accumulate=True)
+    ref = dy.float().t() @ x.float() + 1.0
+    assert rel_err(out, ref) < 2e-3
+
+
+def test_gemm_strided_rows():
+    # CLS-row gather: A rows are hidden_states[:, 0] with row stride T*H
+    B, T, H, N = 80, 20, 768, 1024
+    seq = bf(rand(B * T, H, seed=9))
+    w = bf(rand(N, H, scale=0.05, seed=10))
+    y = ops.gemm(seq, w, B, N, H, lda=T * H, act="relu")
+    ref = torch.relu(seq.view(B, T, H)[:, 0].float() @ w.float().t())
+    assert rel_err(y, ref) < 1e-2
+    # and the scatter back: dgrad written with ldc = T*H, accumulate
+    dy = bf(rand(B, N, seed=11))
+    g = torch.zeros(B * T, H, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(dy, w, B, H, N, tb=True, out=g, ldc=T * H)
+    ops.gemm(dy, w, B, H, N, tb=True, out=g, ldc=T * H, accumulate=True)
+    refg = 2 * (dy.float() @ w.float())
+    assert rel_err(g.view(B, T, H)[:, 0], refg) < 1.5e-2
+    assert float(g.view(B, T, H)[:, 1:].abs().max()) == 0.0
+
+
+def test_gemm_epilogues():
+    M, N, K = 333, 256, 128
+    x, w, b = bf(rand(M, K, seed=1)), bf(rand(N, K, scale=0.1, seed=2)), rand(N, seed=3)
+    pre = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    h = ops.gemm(x, w, M, N, K, bias=b, act="gelu", preact_out=pre)
+    u = x.float() @ w.float().t() + b
+    assert rel_err(pre, u) < 1e-2
+    assert rel_err(h, O.gelu_erf(u)) < 1e-2
+    for act, fn in (("relu", torch.relu), ("leaky", lambda t: torch.nn.functional.leaky_relu(t, 0.01)), ("tanh", torch.tanh)):
+        assert rel_err(ops.gemm(x, w, M, N, K, bias=b, act=act), fn(u)) < 1e-2
+    # backward-through-activation epilogue: out = (x w^T) * gelu'(pre)
+    g = ops.gemm(x, w, M, N, K, dact_src=pre, dact="gelu")
+    pf = pre.float().requires_grad_(True)
+    O.gelu_erf(pf).sum().backward()
+    assert rel_err(g, (x.float() @ w.float().t()) * pf.grad) < 1.5e-2
+    gl = ops.gemm(x, w, M, N, K, dact_src=h, dact="leaky")
+    assert rel_err(gl, (x.float() @ w.float().t()) * torch.where(h.float() > 0, 1.0, 0.01)) < 1e-2
+
+
+def test_dropout_mask_consistency_and_rate():
+    # the GEMM epilogue's mask must be regenerated bit-identically by the LayerNorm backward
+    M, N, K, p, site, seed = 512, 768, 64, 0.1, 77, 123456789
+    x, w = bf(rand(M, K, seed=1)), bf(rand(N, K, seed=2))
+    y0 = ops.gemm(x, w, M, N, K, out_f32=True)
+    y1 = ops.gemm(x, w, M, N, K, out_f32=True, p_drop=p, site=site, seed=seed)
+    keep = y1 != 0
+    rate = 1.0 - float(keep.float().mean())
+    assert abs(rate - p) < 0.01
+    assert torch.allclose(y1[keep], y0[keep] / (1 - p), rtol=1e-5)
+    # different site / seed -> different mask
+    y2 = ops.gemm(x, w, M, N, K, out_f32=True, p_drop=p, site=site + 1, seed=seed)
+    assert float(((y2 != 0) != keep).float().mean()) > 0.05
+    # LN backward re-applies exactly this mask to produce the producing Linear's gradient
+    s = bf(rand(M, N, seed=3))
+    gamma, beta = 1 + 0.1 * rand(N, seed=4), rand(N, seed=5)
+    _, mean, rstd = ops.layernorm_fwd(s, gamma, beta)
+    dy = bf(rand(M, N, seed=6))
+    dx, dxl, _, _, dbias = ops.layernorm_bwd(dy, s, mean, rstd, gamma, want_lin=True, p_lin=p, lin_site=site, seed=seed)
+    exp = torch.where(keep, dx.float() / (1 - p), torch.zeros_like(dx.float()))
+    assert rel_err(dxl, exp) < 1e-2
+    assert float(((dxl != 0) & ~keep).sum()) == 0
+    assert rel_err(dbias, dxl.float().sum(0)) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("M,H", [(1600, 768), (2880, 1024), (21, 64), (15, 96), (7, 2048)])
+def test_layernorm_fwd_bwd(M, H):
+    x = bf(rand(M, H, scale=2.0, seed=1) + 0.3)
+    gamma, beta = 1 + 0.1 * rand(H, seed=2), 0.1 * rand(H, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = O.layer_norm(xr, gr, br)
+    assert rel_err(y, yr) < 1e-2
+    assert rel_err(mean, xr.mean(-1)) < 1e-4
+    dy = bf(rand(M, H, seed=4))
+    yr.backward(dy.float())
+    dx, _, dg, db, dbias = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+    assert rel_err(dx, xr.grad) < 1e-2
+    assert rel_err(dg, gr.grad) < 2e-3
+    assert rel_err(db, br.grad) < 2e-3
+    assert rel_err(dbias, dx.float().sum(0)) < 2e-3
+    # accumulate flag
+    dg2 = dg.clone()
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=dg2, dbeta=db.clone(), dbias=dbias.clone(), accumulate=True)
+    assert rel_err(dg2, 2 * gr.grad) < 2e-3
+
+
+def test_colsum_softmax_cast():
+    x = bf(rand(1600, 3072, seed=1))
+    assert rel_err(ops.colsum(x, 1600, 3072), x.float().sum(0)) < 1e-4
+    xs = bf(rand(37, 520, seed=2))
+    assert rel_err(ops.colsum(xs, 37, 256, ld=520), xs.float()[:, :256].sum(0)) < 1e-4
+    f = rand(2880, 2048, seed=3)
+    assert rel_err(ops.softmax_rows(f), torch.softmax(f, -1)) < 1e-2
+    f2 = rand(15, 32, seed=4) * 5
+    assert rel_err(ops.softmax_rows(f2), torch.softmax(f2, -1)) < 1e-2
+    w = rand(100003, seed=5)
+    assert torch.equal(ops.cast_bf16(w), w.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, km, heads, d):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    qh = q.float().view(B, Tq, heads, d).permute(0, 2, 1, 3)
+    kh = k.float().view(B, Tk, heads, d).permute(0, 2, 1, 3)
+    vh = v.float().view(B, Tk, heads, d).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(d) + (1.0 - km.float())[:, None, None, :] * -10000.0
+    return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, heads * d)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", [(80, 16, 20, 20, 48), (80, 16, 36, 36, 64), (80, 32, 20, 36, 32), (80, 32, 36, 20, 32),
+                                             (4, 16, 100, 100, 64), (4, 32, 40, 100, 32), (4, 32, 100, 40, 32), (3, 4, 7, 5, 16),
+                                             (3, 4, 5, 7, 24)])
+def test_attention_fwd_bwd(B, heads, Tq, Tk, d):
+    Hh = heads * d
+    # q / k / v as column slices of fused [*, 3*Hh] buffers, as the step engine passes them
+    bufq = bf(rand(B, Tq, 3 * Hh, seed=1))
+    bufk = bf(rand(B, Tk, 3 * Hh, seed=2))
+    q, k, v = bufq[:, :, :Hh], bufk[:, :, Hh:2 * Hh], bufk[:, :, 2 * Hh:]
+    km = torch.ones(B, Tk, dtype=torch.uint8, device=DEV)
+    for b in range(B):
+        km[b, Tk - (b % 4):] = 0
+    ctx = ops.attention_fwd(q, k, v, km, heads, d)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, km, heads, d)
+    assert rel_err(ctx, ref) < 1e-2
+    dctx = bf(rand(B, Tq, Hh, seed=3))
+    ref.backward(dctx.float())
+    dq, dk, dv = ops.attention_bwd(q, k, v, km, dctx, heads, d)
+    assert rel_err(dq, qr.grad) < 1.5e-2
+    assert rel_err(dk, kr.grad) < 1.5e-2
+    assert rel_err(dv, vr.grad) < 1.5e-2
+
+
+def test_attention_dropout_statistics_and_grad_consistency():
+    B, heads, T, d, p = 16, 16, 36, 64, 0.1
+    Hh = heads * d
+    q, k = bf(rand(B, T, Hh, seed=1)), bf(rand(B, T, Hh, seed=2))
+    v = bf(torch.ones(B, T, Hh, device=DEV))        # ctx = sum_j dropout(P)_ij  -> E = 1
+    km = torch.ones(B, T, dtype=torch.uint8, device=DEV)
+    ctx = ops.attention_fwd(q, k, v, km, heads, d, p_drop=p, site=5, seed=99)
+    assert abs(float(ctx.float().mean()) - 1.0) < 0.01
+    assert float(ctx.float().std()) > 0.01
+    # same seed -> identical; backward uses the same mask: dv = Pd^T dctx, with dctx = 1: colsum(Pd) summed = Tq
+    ctx2 = ops.attention_fwd(q, k, v, km, heads, d, p_drop=p, site=5, seed=99)
+    assert torch.equal(ctx, ctx2)
+    ones = bf(torch.ones(B, T, Hh, device=DEV))
+    _, _, dv = ops.attention_bwd(q, k, v, km, ones, heads, d, p_drop=p, site=5, seed=99)
+    # sum_j dv[j, c] = sum_i sum_j Pd[i, j] = sum_i ctx[i, c]
+    assert rel_err(dv.float().sum(1), ctx.float().sum(1)) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------- AdamW
+def test_adamw_matches_torch():
+    lib = L.load()
+    sizes = [4096 * 3 + 17, 64, 5000, 768]
+    offs, top = [], 0
+    for s in sizes:
+        offs.append(top)
+        top += (s + 63) // 64 * 64
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(top, generator=g).to(DEV)
+    grad = torch.randn(top, generator=g).to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.zeros(top, device=DEV, dtype=torch.bfloat16)
+    lrs, wds = [2e-5, 1e-3, 2e-5, 5e-4], [0.01, 0.0, 0.01, 0.0]
+    ref_params = [p[o:o + s].clone().cpu().requires_grad_(True) for o, s in zip(offs, sizes)]
+    opt = torch.optim.AdamW([{"params": [rp], "lr": lr, "weight_decay": wd} for rp, lr, wd in zip(ref_params, lrs, wds)], lr=1e-3)
+    blk_seg, blk_off = ops.adamw_plan(sizes)
+    d = lambda t, dt: torch.as_tensor(t, dtype=dt).to(DEV)   # noqa: E731
+    seg_off, seg_len, seg_lr, seg_wd = d(offs, torch.int64), d(sizes, torch.int64), d(lrs, torch.float32), d(wds, torch.float32)
+    bs, bo = blk_seg.to(DEV), blk_off.to(DEV)
+    for step in (1, 2, 3):
+        for rp, o, s in zip(ref_params, offs, sizes):
+            rp.grad = grad[o:o + s].cpu().clone() * step
+        opt.step()
+        L.check(lib.crct_adamw_step(p.data_ptr(), (grad * step).data_ptr(), m.data_ptr(), v.data_ptr(), pb.data_ptr(), seg_off.data_ptr(),
+                                    seg_len.data_ptr(), seg_lr.data_ptr(), seg_wd.data_ptr(), bs.data_ptr(), bo.data_ptr(), bs.numel(),
+                                    0.9, 0.999, 1e-8, step, None, L.current_stream()))
+    for rp, o, s in zip(ref_params, offs, sizes):
+        assert torch.allclose(p[o:o + s].cpu(), rp.detach(), rtol=1e-5, atol=1e-7)
+        assert torch.equal(pb[o:o + s].cpu(), p[o:o + s].cpu().to(torch.bfloat16))
+    # padding between tensors is never touched
+    assert float(m[sizes[0]:offs[1]].abs().max()) == 0.0
