@@ -25,7 +25,7 @@ class HeadArgs(C.Structure):
     _fields_ = [("pooled_t", vp), ("pooled_v", vp), ("fus_h", vp), ("w_cls", vp), ("b_cls", vp), ("w_f6", vp), ("b_f6", vp),
                 ("R", vp), ("labels", vp), ("logits", vp), ("reg", vp), ("stats", vp), ("scratch", vp),
                 ("d_pooled_t", vp), ("d_pooled_v", vp), ("d_fus_h", vp),
-                ("d_w_cls", vp), ("d_b_cls", vp), ("d_w_f6", vp), ("d_b_f6", vp), ("loss_scale_dev", vp),
+                ("d_w_cls", vp), ("d_b_cls", vp), ("d_w_f6", vp), ("d_b_f6", vp), ("g_nsp_dev", vp), ("g_reg_dev", vp),
                 ("B", c_i32), ("Hb", c_i32), ("fusion_sum", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32),
                 ("tol_margin", c_f32), ("nsp_coeff", c_f32), ("reg_coeff", c_f32), ("grad_scale", c_f32),
                 ("drop_thr", c_u32), ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64)]
@@ -47,7 +47,7 @@ class Batch(C.Structure):
 
 class StepCfg(C.Structure):
     _fields_ = [("training", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32), ("tol_margin", c_f32), ("nsp_coeff", c_f32),
-                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("loss_scale_dev", vp)]
+                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/crct_hip.h declares

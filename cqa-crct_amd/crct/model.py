@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference model surface for the CRCT hot path.
+
+  ``VisualDialogEncoder(params)``           <- CRCT/backbone/encoder_decorator.py:9-54
+  ``CrctModel`` (``.bert_pretrained``)      <- BertForMultiModalPreTraining, CRCT/backbone/vilbert.py:1499-1661
+
+Same constructor arguments, same ``forward`` keyword arguments / return tuples, same
+``state_dict`` keys, shapes and order (561 entries, incl. the tied ``cls.predictions.decoder.weight``),
+same ``named_parameters()`` order (560), so the reference's optimizer construction, checkpoints
+(``train.py:284-291``) and step adapter keep working.  Underneath there is no torch compute: all
+parameters are views into ONE flat fp32 HBM buffer (+ a bf16 shadow, + a flat fp32 gradient buffer)
+and ``forward`` / ``backward`` are single calls into the native step engine (hand-written gfx950
+kernels, ``include/crct_hip.h``).  The module refuses to run without the HIP library or off-GPU.
+"""
+import math
+import os
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import BertConfig
+from .engine import StepEngine
+from .layout import parameter_table, used_span
+
+
+class _Node(nn.Module):
+    """Name-only container used to reproduce the reference's dotted parameter names."""
+
+    def forward(self, *a, **k):   # pragma: no cover
+        raise RuntimeError("structural node of the CRCT parameter tree; call the model instead")
+
+
+class _StepFn(torch.autograd.Function):
+    """Autograd bridge: differentiable outputs are nsp_loss [1] and the per-row regression loss [B];
+    backward hands their upstream gradients (device tensors, no sync) to the engine, which
+    accumulates every parameter gradient into the flat buffer (``param.grad`` are views of it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, tensors, step):
+        logits, reg, stats = model._engine.forward(model._flat_p, model._flat_b16, tensors, step)
+        ctx.model, ctx.tensors, ctx.step = model, tensors, step
+        logits, reg_all, stats = logits.clone(), reg.clone(), stats.clone()
+        ctx.mark_non_differentiable(logits, reg_all, stats)
+        return stats[1:2].clone(), reg[1].clone(), logits, reg_all, stats
+
+    @staticmethod
+    def backward(ctx, g_nsp, g_reg, _gl, _gr, _gs):
+        model = ctx.model
+        step = dict(ctx.step)
+        B = ctx.tensors["tokens"].shape[0]
+        dev = model._flat_p.device
+        step["g_nsp"] = (g_nsp if g_nsp is not None else torch.zeros(1, device=dev)).contiguous().float()
+        step["g_reg"] = (g_reg if g_reg is not None else torch.zeros(B, device=dev)).contiguous().float()
+        model._run_backward(ctx.tensors, step)
+        return None, None, None, None
+
+
+class CrctModel(nn.Module):
+    def __init__(self, config, params=None):
+        super().__init__()
+        if not isinstance(config, BertConfig):
+            raise ValueError("Parameter config in `CrctModel(config)` should be an instance of class `BertConfig`.")
+        if params.get("CE_REG") or params.get("binary_answers") or params.get("dataset", "plotqa") not in ("plotqa", "plotqa_colorless"):
+            raise NotImplementedError("only the PlotQA regression path (PlotQA_Regressor_v20) is built (SURVEY.md section 2)")
+        self.config, self.params = config, params
+        device = torch.device(params.get("device", "cuda"))
+        if device.type != "cuda":
+            raise RuntimeError("CrctModel needs an MI355X (params['device']=%s): the CRCT step has no CPU path" % device)
+        self.table, self.total = parameter_table(config, params)
+        self._flat_p = torch.zeros(self.total, device=device)
+        self._flat_g = torch.zeros(self.total, device=device)
+        self._flat_b16 = torch.zeros(self.total, device=device, dtype=torch.bfloat16)
+        self._shadow_ver = -1
+        self._entries = {e.name: e for e in self.table}
+        self._build_tree()
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._engine = None
+        self._seed, self._calls = int(params.get("seed", 0)) * 1000003 + 12345, 0
+        self.cls_dropout = 0.1                       # vilbert.py:1045
+        self.sync_stats = True                       # reg[3] as python ints (host sync) like the reference
+        self._ddp = None
+        self.init_weights(int(params.get("seed", 0)))
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate_shadow())
+
+    # ------------------------------------------------------------------ parameter tree
+    def _build_tree(self):
+        word = None
+        for e in self.table:
+            view = self._flat_p[e.offset:e.offset + e.numel].view(e.shape)
+            p = nn.Parameter(view, requires_grad=True)
+            node = self
+            parts = e.name.split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            node.register_parameter(parts[-1], p)
+            if e.used:
+                p.grad = self._flat_g[e.offset:e.offset + e.numel].view(e.shape)
+            if e.name == "bert.embeddings.word_embeddings.weight":
+                word = p
+        # tied LM decoder weight (vilbert.py:1029): second state_dict key, same Parameter
+        node = self._modules["cls"]._modules["predictions"]
+        node.add_module("decoder", _Node())
+        node._modules["decoder"].register_parameter("weight", word)
+
+    def _params_by_name(self):
+        return dict(self.named_parameters())
+
+    @torch.no_grad()
+    def init_weights(self, seed=0):
+        """init_bert_weights (vilbert.py:1099-1110): N(0, initializer_range) for Linear / Embedding weights,
+        zero biases, LayerNorm = (1, 0); the regressor keeps nn.Linear's default init (it is created
+        after ``self.apply(self.init_bert_weights)``, vilbert.py:1510-1523)."""
+        g = torch.Generator(device=self._flat_p.device).manual_seed(seed)
+        for e in self.table:
+            v = self._flat_p[e.offset:e.offset + e.numel]
+            if e.name.startswith("regressor."):
+                fan_in = e.shape[1] if len(e.shape) == 2 else self._entries[e.name[:-4] + "weight"].shape[1]
+                bound = 1.0 / math.sqrt(fan_in)
+                v.uniform_(-bound, bound, generator=g)
+            elif "LayerNorm" in e.name:
+                v.fill_(1.0 if e.name.endswith("weight") else 0.0)
+            elif e.name.endswith("bias"):
+                v.zero_()
+            else:
+                v.normal_(0.0, self.config.initializer_range, generator=g)
+        self._invalidate_shadow()
+
+    def _invalidate_shadow(self):
+        self._shadow_ver = -1
+
+    def _refresh_shadow(self):
+        if self._shadow_ver != self._flat_p._version:
+            ops.cast_bf16(self._flat_p, out=self._flat_b16)
+            self._shadow_ver = self._flat_p._version
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, device=self._flat_p.device))
+        if probe.dtype != torch.float32:
+            raise RuntimeError("CrctModel keeps fp32 master weights (bf16 compute is internal); .half()/.bfloat16() is not supported")
+        if probe.device != self._flat_p.device:
+            if probe.device.type != "cuda":
+                raise RuntimeError("CrctModel cannot leave the GPU: the CRCT step has no CPU path")
+            self._flat_p, self._flat_g, self._flat_b16 = fn(self._flat_p), fn(self._flat_g), self._flat_b16.to(probe.device)
+            self._anchor = torch.zeros(1, device=probe.device, requires_grad=True)
+            self._engine = None
+            self._rebind()
+        return self
+
+    def _rebind(self):
+        byname = self._params_by_name()
+        for e in self.table:
+            p = byname[e.name]
+            p.data = self._flat_p[e.offset:e.offset + e.numel].view(e.shape)
+            if e.used:
+                p.grad = self._flat_g[e.offset:e.offset + e.numel].view(e.shape)
+        self._invalidate_shadow()
+
+    # ------------------------------------------------------------------ flat views for the optimizer / DDP
+    @property
+    def flat_params(self):
+        return self._flat_p
+
+    @property
+    def flat_grads(self):
+        return self._flat_g
+
+    @property
+    def flat_shadow(self):
+        return self._flat_b16
+
+    def note_params_updated_natively(self):
+        """Called by the fused optimizer, which rewrites the flat buffers and the shadow itself."""
+        self._shadow_ver = self._flat_p._version
+
+    def zero_flat_grads(self):
+        self._flat_g.zero_()
+
+    def _ensure_grad_views(self):
+        """``optimizer.zero_grad()`` of stock torch sets ``.grad = None``: re-attach the views and clear."""
+        missing = False
+        byname = None
+        for e in self.table:
+            if not e.used:
+                continue
+            if byname is None:
+                byname = self._params_by_name()
+            if byname[e.name].grad is None:
+                missing = True
+                break
+        if missing:
+            self._flat_g.zero_()
+            for e in self.table:
+                if e.used:
+                    byname[e.name].grad = self._flat_g[e.offset:e.offset + e.numel].view(e.shape)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _get_engine(self, B, T, V):
+        eng = self._engine
+        if eng is None or B > eng.max[0] or T > eng.max[1] or V > eng.max[2]:
+            mb = max(B, eng.max[0] if eng else 0)
+            mt = max(T, eng.max[1] if eng else 0)
+            mv = max(V, eng.max[2] if eng else 0)
+            self._engine = StepEngine(self.config, self.params, mb, mt, mv, self._flat_p.device, self.cls_dropout)
+        return self._engine
+
+    def _run_backward(self, tensors, step):
+        self._ensure_grad_views()
+        eng = self._engine
+        if self._ddp is None:
+            eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, -1)
+        else:
+            self._ddp.backward(self, eng, tensors, step)
+
+    def _device_inputs(self, input_ids, txt_loc, image_feat, image_loc, token_type_ids, attention_mask,
+                       image_attention_mask, image_target, R, labels):
+        dev = self._flat_p.device
+
+        def to(t, dtype):
+            return t.to(device=dev, dtype=dtype, non_blocking=True).contiguous()
+        B, T = input_ids.shape
+        V = image_feat.shape[1]
+        if attention_mask is None:
+            attention_mask = torch.ones(B, T, dtype=torch.uint8)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        if image_attention_mask is None:
+            image_attention_mask = torch.ones(B, V, dtype=torch.uint8)
+        t = dict(tokens=to(input_ids, torch.int64), segments=to(token_type_ids, torch.int64), loc=to(txt_loc, torch.float32),
+                 text_keymask=to(attention_mask != 0, torch.uint8), image_feat=to(image_feat, torch.float32),
+                 image_loc=to(image_loc, torch.float32), image_target=to(image_target, torch.int64),
+                 image_keymask=to(image_attention_mask != 0, torch.uint8), R=to(R, torch.float32))
+        if labels is not None:
+            t["labels"] = to(labels.reshape(-1), torch.int64)
+        return t
+
+    # ------------------------------------------------------------------ forward (vilbert.py:1540-1661)
+    def forward(self, input_ids, txt_loc, image_feat, image_loc, sep_indices=None, sep_len=None, token_type_ids=None,
+                attention_mask=None, image_attention_mask=None, masked_lm_labels=None, image_label=None, image_target=None,
+                next_sentence_label=None, output_all_attention_masks=False, gt_reg=None, areas=None, legend_pred=None):
+        if areas is not None:
+            raise NotImplementedError("'areas' belongs to the figure_qa / dvqa datasets (vilbert.py:1464-1489), out of scope")
+        if gt_reg is None:
+            raise ValueError("gt_reg=[R, kind] is required (vilbert.py:1586)")
+        if image_target is None:
+            raise ValueError("image_target is required by the image embeddings (vilbert.py:1479)")
+        R, kind = gt_reg[0], gt_reg[1]
+        train_branch = masked_lm_labels is not None and next_sentence_label is not None and image_target is not None
+        tensors = self._device_inputs(input_ids, txt_loc, image_feat, image_loc, token_type_ids, attention_mask,
+                                      image_attention_mask, image_target, R, next_sentence_label if train_branch else None)
+        B, T = tensors["tokens"].shape
+        V = tensors["image_feat"].shape[1]
+        self._get_engine(B, T, V)
+        self._refresh_shadow()
+        self._calls += 1
+        p = self.params
+        step = dict(training=self.training, use_l1=bool(p["L1"]), kind_l1=(kind == "L1"), tol_margin=float(p["tol_margin"]),
+                    nsp_coeff=float(p.get("nsp_loss_coeff", 1.0)), reg_coeff=float(p.get("reg_loss_coeff", 1.0)),
+                    seed=(self._seed + self._calls * 7919 + int(p.get("rank", 0)) * 104729) & 0x7FFFFFFFFFFFFFFF)
+        dev = self._flat_p.device
+        if train_branch and torch.is_grad_enabled():
+            nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)
+        else:
+            logits, reg, stats = self._engine.forward(self._flat_p, self._flat_b16, tensors, step)
+            logits, reg, stats = logits.clone(), reg.clone(), stats.clone()
+            nsp, reg_loss = stats[1:2], reg[1]
+        self.last_stats = stats
+        if self.sync_stats:
+            right = (int(stats[4].item()), int(stats[5].item()))          # vilbert.py:1647 (.item() host syncs)
+        else:
+            right = (stats[4], stats[5])
+        reg_out = [reg[0], reg_loss, reg[2], right, reg[4]]
+        legend_loss = torch.zeros(1, device=dev)
+        if train_branch:
+            zero = torch.zeros(1, 1, device=dev)
+            return zero, zero.clone(), nsp, None, None, logits, reg_out, legend_loss       # vilbert.py:1659
+        return None, None, logits, None, None, reg_out, legend_loss                         # vilbert.py:1661
+
+
+class VisualDialogEncoder(nn.Module):
+    """encoder_decorator.py:9-54.  ``params['model_config']`` must exist (same assertion as :14).
+    The reference then downloads BERT-base; offline we keep the init_bert_weights initialisation
+    (exactly the state of the reference model right before its weight loading, vilbert.py:1205)."""
+
+    def __init__(self, params, config=None):
+        super().__init__()
+        if config is None:
+            config_path = params["model_config"]
+            assert os.path.exists(config_path), "model_config file not found"
+            config = BertConfig.from_json_file(config_path)
+        self.bert_pretrained = CrctModel(config, params=params)
+        self.bert_pretrained.train()
+
+    def forward(self, input_ids, txt_loc, image_feat, image_loc, sep_indices=None, sep_len=None, token_type_ids=None,
+                attention_mask=None, masked_lm_labels=None, next_sentence_label=None, head_mask=None,
+                random_round_indices=None, output_nsp_scores=False, output_lm_scores=False, image_attention_mask=None,
+                image_label=None, image_target=None, gt_reg=None, areas=None, legend_pred=None):
+        masked_lm_loss = masked_img_loss = nsp_loss = prediction_scores_t = None
+        kw = dict(sep_indices=sep_indices, sep_len=sep_len, token_type_ids=token_type_ids, attention_mask=attention_mask,
+                  masked_lm_labels=masked_lm_labels, next_sentence_label=next_sentence_label,
+                  image_attention_mask=image_attention_mask, image_label=image_label, image_target=image_target,
+                  gt_reg=gt_reg, areas=areas, legend_pred=legend_pred)
+        if next_sentence_label is not None and masked_lm_labels is not None and image_target is not None:
+            masked_lm_loss, masked_img_loss, nsp_loss, _, prediction_scores_t, seq_relationship_score, reg_loss, legend_loss = \
+                self.bert_pretrained(input_ids, txt_loc, image_feat, image_loc, **kw)
+        else:
+            prediction_scores_t, _, seq_relationship_score, _, _, reg_loss, legend_loss = \
+                self.bert_pretrained(input_ids, txt_loc, image_feat, image_loc, **kw)
+        out = (masked_lm_loss, masked_img_loss, nsp_loss, seq_relationship_score)
+        if output_lm_scores:
+            out = out + (prediction_scores_t,)
+        return out + (reg_loss, legend_loss)

@@ -1,0 +1,166 @@
+"""Optimizer / LR-schedule surface of the reference (CRCT/utils.py:11-29, 228-249) on flat buffers.
+
+``get_optimizer(params, model)`` returns a ``torch.optim.Optimizer`` with the reference's layout --
+ONE param group per tensor in ``named_parameters()`` order, lr = ``params['lr']`` for BERT-base
+language tensors else ``params['image_lr']``, weight decay 0 for names containing ``bias`` /
+``LayerNorm.bias`` / ``LayerNorm.weight`` -- so ``optimizer.state_dict()`` / ``load_state_dict()``
+round-trip with reference checkpoints (train.py:105-130, 284-291).  The update itself is ONE HIP
+kernel over the flat parameter / gradient / moment buffers (crct_adamw_step), which also refreshes
+the bf16 weight shadow; tensors that never receive a gradient are skipped, as torch.optim.AdamW
+skips ``grad is None`` parameters.
+"""
+import json
+import os
+
+import torch
+from torch.optim.lr_scheduler import _LRScheduler
+
+from . import lib as L
+from . import ops
+from .layout import NO_DECAY, is_language_weight
+
+
+class WarmupLinearScheduleNonZero(_LRScheduler):
+    """Linear warm-up to the base lr over ``warmup_steps``, then linear decay towards 0 at ``t_total``,
+    floored at ``min_lr`` (utils.py:11-29)."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, min_lr=1.3e-5, last_epoch=-1):
+        self.warmup_steps, self.t_total, self.min_lr = warmup_steps, t_total, min_lr
+        super().__init__(optimizer, last_epoch=last_epoch)
+
+    def get_lr(self):
+        step = self.last_epoch
+        if step < self.warmup_steps:
+            f = float(step) / float(max(1, self.warmup_steps))
+        else:
+            f = max(0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
+        return [b * f if (b * f) > self.min_lr else self.min_lr for b in self.base_lrs]
+
+
+def _crct_core(model):
+    core = getattr(model, "bert_pretrained", model)
+    core = getattr(core, "module", core)
+    if not hasattr(core, "flat_params"):
+        core = getattr(core, "bert_pretrained", core)
+    return core
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics, one launch.  ``param_groups`` keep the caller's layout."""
+
+    def __init__(self, param_groups, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(param_groups, defaults)
+        self.core = _crct_core(model)
+        core = self.core
+        dev = core.flat_params.device
+        self._m = torch.zeros_like(core.flat_params)
+        self._v = torch.zeros_like(core.flat_params)
+        self._step = 0
+        byname = dict(core.named_parameters())
+        self._used = [e for e in core.table if e.used]
+        ids = {id(byname[e.name]): e for e in self._used}
+        self._group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if id(p) in ids:
+                    self._group_of[ids[id(p)].name] = gi
+        self._segs = [e for e in self._used if e.name in self._group_of]
+        to_dev = lambda v, dt: torch.as_tensor(v, dtype=dt).to(dev)   # noqa: E731
+        self._seg_off = to_dev([e.offset for e in self._segs], torch.int64)
+        self._seg_len = to_dev([e.numel for e in self._segs], torch.int64)
+        blk_seg, blk_off = ops.adamw_plan([e.numel for e in self._segs])
+        self._blk_seg, self._blk_off = blk_seg.to(dev), blk_off.to(dev)
+        self._lr_host = torch.empty(len(self._segs), dtype=torch.float32).pin_memory()
+        self._wd_host = torch.empty(len(self._segs), dtype=torch.float32).pin_memory()
+        self._lr_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
+        self._wd_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
+        self._last = None
+        # expose the moments the way torch.optim.AdamW does (views of the flat buffers)
+        for e in self._segs:
+            p = byname[e.name]
+            self.state[p] = dict(step=torch.tensor(0.0), exp_avg=self._m[e.offset:e.offset + e.numel].view(e.shape),
+                                 exp_avg_sq=self._v[e.offset:e.offset + e.numel].view(e.shape))
+        self._byname = byname
+
+    def _upload_hyper(self):
+        lrs = [self.param_groups[self._group_of[e.name]]["lr"] for e in self._segs]
+        wds = [self.param_groups[self._group_of[e.name]]["weight_decay"] for e in self._segs]
+        key = (tuple(lrs), tuple(wds))
+        if key != self._last:
+            self._lr_host.copy_(torch.tensor(lrs, dtype=torch.float32))
+            self._wd_host.copy_(torch.tensor(wds, dtype=torch.float32))
+            self._lr_dev.copy_(self._lr_host, non_blocking=True)
+            self._wd_dev.copy_(self._wd_host, non_blocking=True)
+            self._last = key
+
+    @torch.no_grad()
+    def step(self, closure=None, inv_scale=None):
+        loss = closure() if closure is not None else None
+        core = self.core
+        self._upload_hyper()
+        self._step += 1
+        g0 = self.param_groups[0]
+        lib = L.load()
+        L.check(lib.crct_adamw_step(core.flat_params.data_ptr(), core.flat_grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                    core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
+                                    self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr(),
+                                    self._blk_off.data_ptr(), self._blk_seg.numel(), g0["betas"][0], g0["betas"][1], g0["eps"],
+                                    self._step, L.ptr(inv_scale), L.current_stream()), "adamw_step")
+        core.note_params_updated_natively()
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        # one memset; .grad views stay attached (set_to_none would only force a re-attach next step)
+        self.core.zero_flat_grads()
+
+    def state_dict(self):
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        idx = 0
+        pos_to_param = {}
+        for g, sg in zip(self.param_groups, groups):
+            for p, sid in zip(g["params"], sg["params"]):
+                pos_to_param[sid] = p
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+        step = 0
+        for sid, st in state_dict["state"].items():
+            p = pos_to_param[sid]
+            mine = self.state.get(p)
+            if mine is None:
+                continue
+            mine["exp_avg"].copy_(st["exp_avg"])
+            mine["exp_avg_sq"].copy_(st["exp_avg_sq"])
+            step = max(step, int(float(st["step"])))
+        self._step = step
+        self._last = None
+
+
+def get_optimizer(params, dialog_encoder, language_weights_json=None):
+    """utils.py:228-249 with the fused kernel underneath.  ``language_weights_json`` may point at the
+    reference's ``config/language_weights.json``; by default its membership rule is applied
+    (crct.layout.is_language_weight)."""
+    listed = None
+    path = language_weights_json or os.path.join("config", "language_weights.json")
+    if language_weights_json or os.path.exists(path):
+        with open(path) as f:
+            listed = set(json.load(f))
+    groups = []
+    for key, value in dict(dialog_encoder.named_parameters()).items():
+        if not value.requires_grad:
+            continue
+        bare = key[len("bert_pretrained."):] if key.startswith("bert_pretrained.") else key
+        lang = (key in listed) if listed is not None else is_language_weight(bare)
+        lr = params["lr"] if lang else params["image_lr"]
+        wd = 0 if any(nd in key for nd in NO_DECAY) else params["wd"]
+        groups.append({"params": [value], "lr": lr, "weight_decay": wd})
+    return FusedAdamW(groups, dialog_encoder, lr=params["lr"])

@@ -1,0 +1,62 @@
+"""Step adapter: the batch-dict -> model -> loss function the reference's train / eval loops call.
+
+Mirror of ``forward()`` and ``sequence_mask()`` of CRCT/backbone/encoder_decorator.py:57-158 -- same
+arguments, same return tuples (train: 7-tuple, evaluation: 6-tuple with ``loss=None``), same loss
+combination ``nsp_loss_coeff * nsp + reg_loss_coeff * mean_B(reg_loss)``.  Host tensors of the batch
+are moved to ``params['device']`` with non-blocking copies; the key-length mask is built on the
+host side of the boundary exactly as the reference does (it depends only on integer indices).
+"""
+import numpy as np
+import torch
+
+
+def sequence_mask(sequence_length, max_len=None):
+    """True for positions < length (encoder_decorator.py:57-70)."""
+    if max_len is None:
+        max_len = int(sequence_length.max())
+    rng = torch.arange(0, max_len, device=sequence_length.device).long()
+    return rng.unsqueeze(0) < sequence_length.unsqueeze(1)
+
+
+def forward(dialog_encoder, batch, params, output_nsp_scores=False, output_lm_scores=False, evaluation=False,
+            sample_ids=None):
+    idx = np.arange(batch["tokens"].shape[0]) if sample_ids is None else sample_ids
+    dev = params["device"]
+
+    def pick(key):
+        return batch[key][idx]
+
+    tokens, txt_loc, segments = pick("tokens"), pick("loc"), pick("segments")
+    sep_indices, mask, hist_len = pick("sep_indices"), pick("mask"), pick("hist_len")
+    features, image_loc, image_mask = pick("image_feat"), pick("image_loc"), pick("image_mask")
+    R = pick("R")
+    if "areas" in batch:
+        raise NotImplementedError("'areas' is a figure_qa / dvqa input (encoder_decorator.py:93-96); PlotQA path only")
+    next_sentence_labels = image_label = None
+    if not evaluation:
+        next_sentence_labels = pick("next_sentence_labels")
+        image_label = pick("image_label")
+        regression_target = [R, "L1_smooth"]          # :104
+    else:
+        regression_target = [R, "L1"]                 # :106
+    image_target = pick("image_target")
+
+    # text key mask = arange(T) < sep_indices[hist_len] + 1   (:118-120); integer work, stays on the host side
+    lengths = torch.gather(sep_indices, 1, hist_len.view(-1, 1)).squeeze(1) + 1
+    attention_mask = sequence_mask(lengths, max_len=tokens.shape[1])
+    sep_len = hist_len + 1
+
+    lm_loss, img_loss, nsp_loss, nsp_scores, regression, legend_loss = dialog_encoder(
+        tokens, txt_loc, features, image_loc, sep_indices=sep_indices, sep_len=sep_len, token_type_ids=segments,
+        masked_lm_labels=mask, attention_mask=attention_mask, next_sentence_label=next_sentence_labels,
+        output_nsp_scores=output_nsp_scores, output_lm_scores=output_lm_scores, image_attention_mask=image_mask,
+        image_label=image_label, image_target=image_target, gt_reg=regression_target, areas=None)
+
+    reg_loss = regression[1].mean()
+    loss = None
+    if not evaluation:
+        loss = (params["nsp_loss_coeff"] * nsp_loss) + (params["reg_loss_coeff"] * reg_loss)     # :145
+        loss = loss.sum()
+    if evaluation:
+        return loss, lm_loss, nsp_loss, img_loss, nsp_scores, regression
+    return loss, lm_loss, nsp_loss, img_loss, nsp_scores, regression, legend_loss

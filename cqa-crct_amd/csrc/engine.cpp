@@ -44,7 +44,7 @@ extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a != nullptr, "gemm: null args");
   CRCT_REQUIRE(a->A && a->B && a->C, "gemm: null operand");
   CRCT_REQUIRE(a->N % 4 == 0, "gemm: N=%d must be a multiple of 4", a->N);
-  CRCT_REQUIRE(a->K % 8 == 0, "gemm: K=%d must be a multiple of 8", a->K);
+  CRCT_REQUIRE((a->ta && a->tb) || a->K % 8 == 0, "gemm: K=%d must be a multiple of 8 for a K-contiguous operand", a->K);
   CRCT_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", (long)a->lda, (long)a->ldb);
   CRCT_REQUIRE(a->ldc % 4 == 0, "gemm: ldc=%ld must be a multiple of 4", (long)a->ldc);
   CRCT_REQUIRE(!(a->ta && !a->tb), "gemm: (ta=1, tb=0) is not built (not used by the step)");
@@ -422,7 +422,7 @@ struct Run {
       h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
       h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
     }
-    h.loss_scale_dev = c->loss_scale_dev;
+    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev;
     h.B = B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
     h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
     const Drop dc = drop(D.p_cls, 3);
@@ -473,7 +473,7 @@ struct Run {
     h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
     h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
     h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
-    h.loss_scale_dev = c->loss_scale_dev;
+    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev;
     h.B = b->B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
     h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
     const Drop dc = drop(D.p_cls, 3);

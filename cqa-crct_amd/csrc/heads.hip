@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const CrctHeadArgs a, fl
     n_valid = (int)(block_sum((float)n_valid, red) + 0.5f);
     label = a.labels[b];
   }
-  const float gs = a.grad_scale * (a.loss_scale_dev ? a.loss_scale_dev[0] : 1.0f);
+  // upstream gradients of the two differentiable outputs (nsp_loss scalar, reg_loss rows): either
+  // device tensors handed over by autograd, or the fixed combination of encoder_decorator.py:144-153
+  const float g_nsp = a.g_nsp_dev ? a.g_nsp_dev[0] : a.nsp_coeff * a.grad_scale;
+  const float g_reg = a.g_reg_dev ? a.g_reg_dev[b] : a.reg_coeff * a.grad_scale / (float)a.B;
   // per-row scalars (every thread computes them identically)
   const float mx = fmaxf(l0, l1);
   const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const CrctHeadArgs a, fl
   const bool valid = a.labels && label != -1;
   if (valid) {
     nsp_b = lse - (label == 0 ? l0 : l1);
-    const float w = a.nsp_coeff * gs / (float)max(n_valid, 1);
+    const float w = g_nsp / (float)max(n_valid, 1);
     dl0 = (expf(l0 - lse) - (label == 0 ? 1.f : 0.f)) * w;
     dl1 = (expf(l1 - lse) - (label == 1 ? 1.f : 0.f)) * w;
   }
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const CrctHeadArgs a, fl
   const bool okt = (l1v <= a.tol_margin) && needs;
   if (!a.kind_l1 && fabsf(target) > 1.f) { rl = 0.f; drl = 0.f; }
   if (!needs) { rl = 0.f; drl = 0.f; }
-  const float dz = drl * (a.reg_coeff * gs / (float)a.B) * (1.f - r * r);
+  const float dz = drl * g_reg * (1.f - r * r);
   if (tid == 0) {
     a.logits[b * 2] = l0; a.logits[b * 2 + 1] = l1;
     a.reg[0 * a.B + b] = needs ? r * Rb[3] : 0.f;

@@ -171,7 +171,8 @@ int crct_embed_image_bwd(const void* dy, const void* sum_saved, const float* mea
  *  pooled_t, pooled_v  bf16 [B][Hb] (relu'd pooler outputs), fus_h bf16 [B][256] (LeakyReLU(fusion.4(..)))
  *  outputs: logits fp32 [B][2]; reg fp32 [5][B] = pred*scale, reg_loss, reg_l1, raw tanh output, dist5;
  *           stats fp32 [8] = loss, nsp_loss, mean_B reg_loss, n_needs, n_right5, n_rightT, n_valid_labels, 0
- *  gradient seeds, already multiplied by grad_scale (* *loss_scale_dev): d_pooled_t / d_pooled_v
+ *  gradient seeds (upstream gradients: g_nsp_dev / g_reg_dev when given, else nsp_coeff*grad_scale and
+ *  reg_coeff*grad_scale/B as in encoder_decorator.py:144-153): d_pooled_t / d_pooled_v
  *  bf16 [B][Hb] = gradient w.r.t. the poolers' PRE-activations (dropout and ReLU undone),
  *  d_fus_h bf16 [B][256] = gradient w.r.t. fusion.4's pre-activation; parameter gradients of
  *  bi_seq_relationship / fusion.6 are ACCUMULATED into d_w_cls[2][Hb], d_b_cls[2], d_w_f6[256], d_b_f6[1].
@@ -185,7 +186,8 @@ typedef struct CrctHeadArgs {
   float* scratch;                 /* fp32 [B][8] per-row records (dlogits, dz, loss terms) */
   void* d_pooled_t; void* d_pooled_v; void* d_fus_h;   /* NULL in evaluation */
   float* d_w_cls; float* d_b_cls; float* d_w_f6; float* d_b_f6;
-  const float* loss_scale_dev;    /* optional device scalar multiplied into every gradient */
+  const float* g_nsp_dev;         /* optional device scalar: dLoss/d nsp_loss */
+  const float* g_reg_dev;         /* optional device [B]:    dLoss/d reg_loss[b] */
   int32_t B, Hb;
   int32_t fusion_sum;             /* 0 = 'mul' (default, vilbert.py:163), 1 = 'sum' */
   int32_t use_l1;                 /* params['L1'] : L1Loss vs SmoothL1Loss(beta=0.5), vilbert.py:1525-1528 */
@@ -248,7 +250,8 @@ typedef struct CrctStepCfg {
   int32_t use_l1, kind_l1;
   float tol_margin, nsp_coeff, reg_coeff, grad_scale;
   uint64_t seed;
-  const float* loss_scale_dev;
+  const float* g_nsp_dev;    /* optional upstream gradients from autograd (device) */
+  const float* g_reg_dev;
 } CrctStepCfg;
 
 int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,

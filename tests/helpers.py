@@ -24,7 +24,8 @@ def load_case(name):
 def param_shapes(cfg, params):
     """{state_dict key (no prefix): shape} for every parameter of the model (SURVEY.md 8b schema)."""
     from crct.layout import parameter_table
-    return {e.name: e.shape for e in parameter_table(cfg, params)}
+    table, _ = parameter_table(cfg, params)
+    return {e.name: e.shape for e in table}
 
 
 def seeded_weights(cfg, params, base_seed=7, requires_grad=True):

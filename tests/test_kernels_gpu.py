@@ -154,7 +154,7 @@ def test_layernorm_fwd_bwd(M, H):
     assert rel_err(dx, xr.grad) < 1e-2
     assert rel_err(dg, gr.grad) < 2e-3
     assert rel_err(db, br.grad) < 2e-3
-    assert rel_err(dbias, dx.float().sum(0)) < 2e-3
+    assert rel_err(dbias, xr.grad.sum(0)) < 2e-3      # column sum of the fp32 dx (before bf16 rounding)
     # accumulate flag
     dg2 = dg.clone()
     ops.layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=dg2, dbeta=db.clone(), dbias=dbias.clone(), accumulate=True)
