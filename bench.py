@@ -1,0 +1,190 @@
+"""bench.py -- QA-pairs/sec of the CRCT co-attention training step on MI355X.
+
+One "step" = forward + joint CE/L1 loss + backward (+ RCCL gradient all-reduce, overlapped, when
+N > 1) + fused AdamW + LR-schedule step, on one batch of synthetic PlotQA-shaped inputs that is already
+resident in HBM (a pool of 8 pre-staged batches is rotated), dropout ENABLED (p = 0.1), config
+``config/vilbert.json`` with ``v_feature_size = 2048`` (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (metric contract in the task statement), carrying
+  roofline     : the GEMM variant with the largest share of step time; achieved = algorithmic FLOPs per
+                 launch / average launch duration, measured with HIP events on the launch stream
+                 over extra profiled steps in this process; peak = 2.5 PFLOP/s dense bf16 MFMA.
+  cpu_baseline : the CPU oracle (fp32 PyTorch restatement, ``kind: port``) doing forward+backward of the
+                 same batch shape on this node's host cores (rank 0, N = 1 only, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "cqa-crct_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch                              # noqa: E402
+import torch.distributed as dist          # noqa: E402
+
+from crct import config as CFG            # noqa: E402
+from crct import synthetic as S           # noqa: E402
+from crct import lib as L                 # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9}   # SURVEY.md 8d, fwd+bwd
+VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
+TILE_NAMES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=80)
+    ap.add_argument("--vis", type=int, default=36)
+    ap.add_argument("--tokens", type=int, default=20)
+    ap.add_argument("--feat", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=80)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--bucket-mb", type=int, default=64)
+    return ap.parse_args()
+
+
+def stage(batch, dev):
+    return {k: v.to(dev) for k, v in batch.items()}
+
+
+def gemm_profile(model, run_step, n_steps):
+    """HIP-event timing of every GEMM launch over `n_steps` extra steps (same process, same stream)."""
+    lib = L.load()
+    lib.crct_prof_reset()
+    lib.crct_prof_enable(1)
+    for _ in range(n_steps):
+        run_step()
+    torch.cuda.synchronize()
+    lib.crct_prof_enable(0)
+    rows = []
+    for v in range(12):
+        cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
+        if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0:
+            continue
+        rows.append(dict(kernel="gemm_kernel<%s,%s>" % (TILE_NAMES[v // 3], VARIANT_NAMES[v % 3]), launches_per_step=cnt.value / n_steps,
+                         gflop_per_launch=fl.value / cnt.value / 1e9, us_per_launch=ms.value * 1e3 / cnt.value,
+                         ms_per_step=ms.value / n_steps, tflops=fl.value / (ms.value * 1e-3) / 1e12))
+    lib.crct_prof_reset()
+    return rows
+
+
+def cpu_baseline(core, cfg, params, B, T, V, Fv):
+    """Oracle forward+backward on the host cores (bounded: one warm-up at B=4, one timed step)."""
+    from oracle import crct_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: p.detach().float().cpu().clone().requires_grad_(True) for k, p in core.named_parameters()}
+    cpu_params = dict(params, device=torch.device("cpu"))
+    small = S.make_batch(4, T, V, Fv, seed=99)
+    O.oracle_step(sd, cfg, cpu_params, small)[0].backward()
+    batch = S.make_batch(B, T, V, Fv, seed=1234)
+    t0 = time.time()
+    O.oracle_step(sd, cfg, cpu_params, batch)[0].backward()
+    dt = time.time() - t0
+    return dict(value=B / dt, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 forward+backward of the fp32 CPU oracle (oracle/crct_oracle.py) at B=%d, V=%d, T=%d, F_v=%d, "
+                       "dropout on, after one B=4 warm-up; %.1f s" % (B, V, T, Fv, dt))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from crct.model import VisualDialogEncoder
+    from crct.optim import get_optimizer, WarmupLinearScheduleNonZero
+    from crct.step_adapter import forward as step_forward
+    from crct.ddp import FlatGradDDP
+
+    cfg = CFG.vilbert_config(v_feature_size=a.feat)
+    params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0)
+    model = VisualDialogEncoder(params, config=cfg)
+    core = model.bert_pretrained
+    core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
+    model.train()
+    opt = get_optimizer(params, model)
+    sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
+    ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb) if world > 1 else None
+    pool = [stage(S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i), dev) for i in range(8)]
+    it = [0]
+
+    def run_step():
+        batch = pool[it[0] % len(pool)]
+        it[0] += 1
+        loss = step_forward(model, batch, params)[0]
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        run_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = run_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    final_loss = float(loss)
+    qa_per_s = a.batch * world * a.steps / dt
+
+    out = None
+    if rank == 0:
+        rows = gemm_profile(model, run_step, a.profile_steps) if a.profile_steps > 0 else []
+        flop_qa = FLOP_PER_QA.get((a.vis, a.tokens, a.feat))
+        out = {"metric": "QA-pairs/sec training step (whole node)", "value": qa_per_s, "unit": "QA-pairs/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
+                                      "%d text tokens, dropout 0.1, L1 regression loss" % (a.feat, a.batch, a.vis, a.feat, a.tokens),
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                          "gemm_variants": rows}}
+        if flop_qa:
+            out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
+        if rows:
+            dom = max(rows, key=lambda r: r["ms_per_step"])
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "gflop_per_launch": dom["gflop_per_launch"], "us_per_launch": dom["us_per_launch"]}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(core, cfg, params, a.cpu_batch, a.tokens, a.vis, a.feat)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,10 @@ PROTOTYPES = {
     "crct_last_error": (C.c_char_p, []),
     "crct_abi_version": (C.c_int, []),
     "crct_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
+    "crct_prof_enable": (C.c_int, [C.c_int]),
+    "crct_prof_reset": (C.c_int, []),
+    "crct_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "crct_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp]),
     "crct_layernorm_bwd_blocks": (C.c_int, [C.c_int]),
     "crct_layernorm_bwd": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, c_u32, c_f32, c_u32, c_u32, c_f32, c_u32, c_u64, vp]),

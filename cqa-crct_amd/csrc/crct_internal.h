@@ -21,4 +21,3 @@ void crct_set_error(const char* fmt, ...);
   } while (0)
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s);
-int crct_gemm_pick_tile(int M, int N);

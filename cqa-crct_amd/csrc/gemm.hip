@@ -18,6 +18,8 @@
 // [k][row], and read with ds_read_b64_tr_b16 (gfx950 transposed LDS read) from the 8x32-subtile
 // image of cdna_hip_programming.md T10(a) -- no transposed copies of weights or activations
 // exist anywhere in HBM.
+#include <vector>
+
 #include "common.cuh"
 #include "crct_internal.h"
 
@@ -236,7 +238,7 @@ hipError_t launch_cfg(const CrctGemmArgs& g, hipStream_t s) {
 
 // Tile choice: the CRCT GEMMs are small against 256 CUs (M = 1600 / 2880 rows); take the largest
 // tile that still yields at least ~1 workgroup per CU.
-int crct_gemm_pick_tile(int M, int N) {
+extern "C" int crct_gemm_pick_tile(int M, int N) {
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   if (tiles(128, 128) >= 224) return 0;
   if (tiles(128, 64) >= 224) return 1;
@@ -244,13 +246,66 @@ int crct_gemm_pick_tile(int M, int N) {
   return 3;
 }
 
+// ---- optional live profiling: HIP events around every GEMM launch, on the launch stream ----------
+// (bench.py: roofline.achieved = algorithmic FLOPs per launch / average launch duration per variant)
+namespace {
+struct ProfSlot { hipEvent_t a, b; int variant; };
+struct Prof {
+  bool on = false;
+  std::vector<ProfSlot> slots;
+  size_t used = 0;
+  double flops[12] = {0}; long count[12] = {0};
+} g_prof;
+}  // namespace
+
+extern "C" int crct_prof_enable(int on) {
+  g_prof.on = on != 0;
+  return 0;
+}
+extern "C" int crct_prof_reset(void) {
+  g_prof.used = 0;
+  for (int i = 0; i < 12; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
+  return 0;
+}
+// variant = tile * 3 + {0: fwd (NT), 1: dgrad (tb), 2: wgrad (ta, tb)}.  Synchronises the events.
+extern "C" int crct_prof_read(int variant, long* count, double* flops, double* ms) {
+  if (variant < 0 || variant >= 12) return 1;
+  double t = 0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    if (g_prof.slots[i].variant != variant) continue;
+    float e = 0;
+    if (hipEventSynchronize(g_prof.slots[i].b) != hipSuccess) return 1;
+    if (hipEventElapsedTime(&e, g_prof.slots[i].a, g_prof.slots[i].b) != hipSuccess) return 1;
+    t += e;
+  }
+  *count = g_prof.count[variant]; *flops = g_prof.flops[variant]; *ms = t;
+  return 0;
+}
+
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
   int t = g.tile >= 0 ? g.tile : crct_gemm_pick_tile(g.M, g.N);
-  switch (t) {
-    case 0: return launch_cfg<4, 4>(g, s);
-    case 1: return launch_cfg<4, 2>(g, s);
-    case 2: return launch_cfg<2, 4>(g, s);
-    default: return launch_cfg<2, 2>(g, s);
+  if (t > 3) t = 3;
+  ProfSlot* slot = nullptr;
+  if (g_prof.on) {
+    if (g_prof.used == g_prof.slots.size()) {
+      ProfSlot ns;
+      if (hipEventCreate(&ns.a) != hipSuccess || hipEventCreate(&ns.b) != hipSuccess) return hipErrorOutOfMemory;
+      g_prof.slots.push_back(ns);
+    }
+    slot = &g_prof.slots[g_prof.used++];
+    slot->variant = t * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
+    g_prof.count[slot->variant] += 1;
+    g_prof.flops[slot->variant] += 2.0 * g.M * g.N * g.K;
+    hipEventRecord(slot->a, s);
   }
+  hipError_t e;
+  switch (t) {
+    case 0: e = launch_cfg<4, 4>(g, s); break;
+    case 1: e = launch_cfg<4, 2>(g, s); break;
+    case 2: e = launch_cfg<2, 4>(g, s); break;
+    default: e = launch_cfg<2, 2>(g, s); break;
+  }
+  if (slot) hipEventRecord(slot->b, s);
+  return e;
 }

@@ -57,6 +57,16 @@ typedef struct CrctGemmArgs {
 } CrctGemmArgs;
 
 int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
+/* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
+int crct_gemm_pick_tile(int M, int N);
+
+/* Live measurement for bench.py: when enabled, every GEMM launch is bracketed by HIP events on its
+ * launch stream.  variant = tile*3 + {0 forward, 1 dgrad (tb), 2 wgrad (ta,tb)}.  crct_prof_read
+ * synchronises on the recorded events and returns launches, summed algorithmic FLOPs (2MNK) and
+ * summed elapsed milliseconds of that variant since the last reset. */
+int crct_prof_enable(int on);
+int crct_prof_reset(void);
+int crct_prof_read(int variant, long* count, double* flops, double* ms);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm (TF style, eps inside sqrt) -- BertLayerNorm, vilbert.py:281-294 -- over rows that
