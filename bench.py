@@ -82,21 +82,29 @@ def gemm_profile(model, run_step, n_steps):
     return rows
 
 
-def cpu_baseline(core, cfg, params, B, T, V, Fv):
-    """Oracle forward+backward on the host cores (bounded: one warm-up at B=4, one timed step)."""
+def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
+    """Oracle forward+backward on the host cores, bounded to ~budget_s of CPU work: one warm-up and one
+    probe at B=4 size the timed sample (B <= the benchmark batch) so that it fits the budget.
+    Thread count is capped: PyTorch's CPU ops get slower, not faster, far beyond ~16 threads on these shapes."""
     from oracle import crct_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = max(1, min(os.cpu_count() or 1, max_threads))
+    torch.set_num_threads(threads)
     sd = {k: p.detach().float().cpu().clone().requires_grad_(True) for k, p in core.named_parameters()}
     cpu_params = dict(params, device=torch.device("cpu"))
     small = S.make_batch(4, T, V, Fv, seed=99)
+    O.oracle_step(sd, cfg, cpu_params, small)[0].backward()            # warm-up (page-in, thread pool)
+    t0 = time.time()
     O.oracle_step(sd, cfg, cpu_params, small)[0].backward()
-    batch = S.make_batch(B, T, V, Fv, seed=1234)
+    probe = time.time() - t0
+    Bs = int(max(4, min(B, 4 * budget_s / max(probe, 1e-3))))
+    batch = S.make_batch(Bs, T, V, Fv, seed=1234)
     t0 = time.time()
     O.oracle_step(sd, cfg, cpu_params, batch)[0].backward()
     dt = time.time() - t0
-    return dict(value=B / dt, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample="1 forward+backward of the fp32 CPU oracle (oracle/crct_oracle.py) at B=%d, V=%d, T=%d, F_v=%d, "
-                       "dropout on, after one B=4 warm-up; %.1f s" % (B, V, T, Fv, dt))
+    return dict(value=Bs / dt, unit="QA-pairs/s", cores=threads, kind="port",
+                sample="1 forward+backward of the fp32 CPU oracle (oracle/crct_oracle.py) at B=%d (sized from a B=4 probe of %.2f s "
+                       "to ~%.0f s), V=%d, T=%d, F_v=%d, dropout on; %.1f s on %d threads (of %d cores)"
+                       % (Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1))
 
 
 def main():
@@ -157,7 +165,7 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     qa_per_s = a.batch * world * a.steps / dt
 
     out = None

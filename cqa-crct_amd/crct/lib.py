@@ -97,6 +97,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libcrct_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "-- there is no CPU fallback for the CRCT step" % LIB_PATH)
+    import torch  # noqa: F401  -- torch must load ITS libamdhip64 first; a second HIP runtime in the process sees no device
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
