@@ -38,7 +38,10 @@ from crct import lib as L                 # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9}   # SURVEY.md 8d, fwd+bwd
 VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
-TILE_NAMES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64"}
+TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
+              5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x256w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
+              10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "reg128x128", 14: "reg128x64",
+              15: "reg64x128", 16: "reg64x64"}
 
 
 def parse():
@@ -71,11 +74,11 @@ def gemm_profile(model, run_step, n_steps):
     torch.cuda.synchronize()
     lib.crct_prof_enable(0)
     rows = []
-    for v in range(12):
+    for v in range(48):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
-        if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0:
+        if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue
-        rows.append(dict(kernel="gemm_kernel<%s,%s>" % (TILE_NAMES[v // 3], VARIANT_NAMES[v % 3]), launches_per_step=cnt.value / n_steps,
+        rows.append(dict(kernel="gemm<%s,%s>" % (TILE_NAMES.get(v // 3, "?"), VARIANT_NAMES[v % 3]), launches_per_step=cnt.value / n_steps,
                          gflop_per_launch=fl.value / cnt.value / 1e9, us_per_launch=ms.value * 1e3 / cnt.value,
                          ms_per_step=ms.value / n_steps, tflops=fl.value / (ms.value * 1e-3) / 1e12))
     lib.crct_prof_reset()

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "crct_abi_version": (C.c_int, []),
     "crct_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
+    "crct_gemm_force_generic": (C.c_int, [C.c_int]),
     "crct_prof_enable": (C.c_int, [C.c_int]),
     "crct_prof_reset": (C.c_int, []),
     "crct_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

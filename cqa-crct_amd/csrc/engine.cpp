@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -107,8 +108,14 @@ struct crct_engine {
   LinearP t_pool, v_pool, cls, tp[4], vp[4], fu[4];
   struct { size_t pooled_t, pooled_v, t[3], v[3], cat, f[3], scratch, d_pt, d_pv, g[4]; } ha;
   StreamScratch st, sv;
-  size_t partials, colsum_part;
+  size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
   size_t ws_bytes = 0;
+  // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
+  // streams, ordered against the caller's stream by events (fork / join inside every call)
+  bool use_vis_stream = true, use_wgrad_stream = true;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
+  std::vector<hipEvent_t> evpool;
+  size_t evnext = 0;
   std::vector<std::pair<int64_t, int64_t>> seg_range;
   std::vector<Tap> taps;
   size_t final_t = 0, final_v = 0;   // offsets of the last-layer outputs
@@ -165,11 +172,34 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
 }
 
 // ================================================================================ per-call context
+hipEvent_t ev_new(crct_engine* e) {
+  if (e->evnext == e->evpool.size()) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    e->evpool.push_back(ev);
+  }
+  return e->evpool[e->evnext++];
+}
+// everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+int order_streams(crct_engine* e, hipStream_t from, hipStream_t to) {
+  if (from == to) return 0;
+  hipEvent_t ev = ev_new(e);
+  if (!ev || hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+    crct_set_error("engine: event ordering between internal streams failed");
+    return 1;
+  }
+  return 0;
+}
+
 struct Run {
   crct_engine* e;
   const float* p32; const bf16_t* p16; float* g32; char* ws; hipStream_t s;
   const CrctBatch* b; const CrctStepCfg* c;
+  hipStream_t sw;                      // stream of this data stream's weight-gradient GEMMs (== s when disabled)
+  size_t partials, colsum_part, colsum_part_w;
   int rc = 0;
+  void wgrad_after_main() { if (!rc && sw != s) fail(order_streams(e, s, sw)); }     // sw sees what s produced
+  void main_after_wgrad() { if (!rc && sw != s) fail(order_streams(e, sw, s)); }     // s may now overwrite what sw read
 
   template <class T> T* W(size_t o) const { return reinterpret_cast<T*>(ws + o); }
   bf16_t* A(size_t o) const { return W<bf16_t>(o); }
@@ -189,15 +219,16 @@ struct Run {
     const void* addend = nullptr; int64_t ld_aux = 0, ld_add = 0; Drop drop; bool f32 = false; bool acc = false;
   };
   void gemm(const void* Ap, int64_t lda, bool ta, const void* Bp, int64_t ldb, bool tb, void* C, int64_t ldc, int M, int N,
-            int K, const Opt& o) {
+            int K, const Opt& o, hipStream_t st = nullptr) {
     if (rc) return;
+    if (!st) st = s;
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = Ap; g.B = Bp; g.C = C; g.bias = o.bias; g.preact_out = o.preact; g.dact_src = o.dact_src; g.addend = o.addend;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
-    fail(crct_gemm_bf16(&g, s));
+    fail(crct_gemm_bf16(&g, st));
   }
   // y[M][out] = x W^T + b (+ epilogue)
   void lin_fwd(const void* x, int64_t ldx, const LinearP& l, int M, void* y, int64_t ldy, Opt o) {
@@ -207,15 +238,17 @@ struct Run {
   // dW[out][in] += dy^T x
   void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M) {
     Opt o; o.f32 = true; o.acc = true;
-    gemm(dy, lddy, true, x, ldx, true, G(l.w), l.in, l.out, l.in, M, o);
+    wgrad_after_main();
+    gemm(dy, lddy, true, x, ldx, true, G(l.w), l.in, l.out, l.in, M, o, sw);
   }
   // dx[M][in] = dy W (+ epilogue)
   void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, const Opt& o) {
     gemm(dy, lddy, false, PB(l.w), l.in, true, dx, lddx, M, l.in, l.out, o);
   }
   void bias_grad(const void* dy, int64_t lddy, const LinearP& l, int M) {
+    wgrad_after_main();
     if (rc) return;
-    fail(crct_colsum_bf16(dy, lddy, G(l.b), F(e->colsum_part), M, l.out, 1, s));
+    fail(crct_colsum_bf16(dy, lddy, G(l.b), F(sw != s ? colsum_part_w : colsum_part), M, l.out, 1, sw));
   }
   void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H) {
     if (rc) return;
@@ -226,7 +259,7 @@ struct Run {
                 int M, int H, const Drop& dr) {
     if (rc) return dres;
     fail(crct_layernorm_bwd(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, G(ln.g), G(ln.b),
-                            G(lin.b), F(e->partials), M, H, 1, 0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
+                            G(lin.b), F(partials), M, H, 1, 0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
     return dr.thr ? dlin : dres;
   }
   void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
@@ -287,6 +320,7 @@ struct Run {
   void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc,
                 const uint8_t* km, int B, int T) {
     const int M = B * T, H = p.H, d = H / p.heads;
+    main_after_wgrad();      // the previous layer's weight-gradient GEMMs still read this stream's scratch
     ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
     proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, M, drop(p.p_hid, p.site + 1));
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
@@ -298,41 +332,49 @@ struct Run {
   }
 
   // ---------------------------------------------------------------- connection layer (vilbert.py:774-788)
-  void conn_fwd(const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt) {
+  // `this` drives the TEXT stream, `V` the VISUAL stream (they may share one HIP stream).
+  void conn_fwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt) {
     const CrctModelDims& D = e->d;
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
-    lin_fwd(A(xv), D.Hv, p.qkv1, Mv, A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
-    lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());      // query2/key2/value2  :673-675
+    V.lin_fwd(V.A(xv), D.Hv, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
+    lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());            // query2/key2/value2  :673-675
+    if (!rc) fail(order_streams(e, V.s, s));          // text needs k1, v1
+    if (!V.rc) V.fail(order_streams(e, s, V.s));      // visual needs k2, v2
     // text queries over visual keys/values -> ctx1 [B,T,Hb]  :684-701 (dropout1 = v_attention prob)
     attn_fwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(a.ctx1), Hb, B, D.b_heads,
              b->T, b->V, d, drop(D.p_v_attn, p.site));
     // visual queries over text keys/values -> ctx2 [B,V,Hb]  :704-723
-    attn_fwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(a.ctx2), Hb, B, D.b_heads,
-             b->V, b->T, d, drop(D.p_attn, p.site + 1));
+    V.attn_fwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(a.ctx2), Hb, B, D.b_heads,
+               b->V, b->T, d, drop(D.p_attn, p.site + 1));
     // cross wiring :780 -- visual stream takes ctx2, text stream takes ctx1
-    proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2));
+    V.proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2));
     proj_fwd(p.proj_t, a.proj_t, a.ctx1, xt, Mt, drop(D.p_hidden, p.site + 3));
-    ffn_fwd(p.ffn_v, a.ffn_v, a.proj_v.a, Mv, drop(D.p_v_hidden, p.site + 4));
+    V.ffn_fwd(p.ffn_v, a.ffn_v, a.proj_v.a, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_fwd(p.ffn_t, a.ffn_t, a.proj_t.a, Mt, drop(D.p_hidden, p.site + 5));
   }
-  void conn_bwd(const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
+  void conn_bwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
     const CrctModelDims& D = e->d;
     const StreamScratch& sv = e->sv; const StreamScratch& st = e->st;
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
-    ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
+    V.main_after_wgrad();
+    main_after_wgrad();
+    V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
-    proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
-    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, Mt, drop(D.p_hidden, p.site + 3));     // dctx1 [Mt,Hb]
-    // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]
+    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
+    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, Mt, drop(D.p_hidden, p.site + 3));       // dctx1 [Mt,Hb]
+    // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]            (text stream)
     attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
              3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site));
-    // ctx2 = attn(q1, k2, v2): dq1 -> dqkv1[:, 0:Hb], dk2/dv2 -> dqkv2[:, Hb:3Hb]
-    attn_bwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(sv.dctx), Hb, A(sv.dqkv),
-             3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1));
-    bias_grad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv);
-    lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv);
+    // ctx2 = attn(q1, k2, v2): dq1 -> dqkv1[:, 0:Hb], dk2/dv2 -> dqkv2[:, Hb:3Hb]            (visual stream)
+    V.attn_bwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(sv.dctx), Hb, A(sv.dqkv),
+               3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1));
+    // each stream's dqkv buffer has been written by BOTH attention backward kernels
+    if (!rc) fail(order_streams(e, V.s, s));
+    if (!V.rc) V.fail(order_streams(e, s, V.s));
+    V.bias_grad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv);
+    V.lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv);
     Opt ov; ov.addend = A(sv.dres_b); ov.ld_add = D.Hv;
-    lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
+    V.lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
     bias_grad(A(st.dqkv), 3 * Hb, p.qkv2, Mt);
     lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt);
     Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
@@ -340,30 +382,40 @@ struct Run {
   }
 
   // ---------------------------------------------------------------- embeddings
-  void embed_fwd() {
+  void embed_text_fwd() {
     const CrctModelDims& D = e->d;
-    const int B = b->B, Mv = B * b->V;
-    const Drop dt = drop(D.p_hidden, 1), dv = drop(D.p_hidden, 2);   // both use hidden_dropout_prob (vilbert.py:315,1470)
+    const Drop dt = drop(D.p_hidden, 1);       // hidden_dropout_prob (vilbert.py:315)
     if (!rc) fail(crct_embed_text_fwd(b->tokens, b->segments, b->loc, P(e->et.word), P(e->et.pos), P(e->et.type), P(e->et.wloc),
                                       P(e->et.bloc), P(e->et.ln.g), P(e->et.ln.b), A(e->eta.sum), A(e->eta.y), F(e->eta.mean),
-                                      F(e->eta.rstd), B, b->T, D.H, D.n_pos, 1e-12f, dt.thr, dt.scale, dt.site, c->seed, s));
+                                      F(e->eta.rstd), b->B, b->T, D.H, D.n_pos, 1e-12f, dt.thr, dt.scale, dt.site, c->seed, s));
+  }
+  void embed_image_fwd() {
+    const CrctModelDims& D = e->d;
+    const int Mv = b->B * b->V;
+    const Drop dv = drop(D.p_hidden, 2);       // also the TEXT probability (vilbert.py:1470)
     if (!rc) fail(crct_softmax_rows_f32_bf16(b->image_feat, A(e->eva.soft), Mv, D.Fv, s));
     lin_fwd(A(e->eva.soft), D.Fv, e->ev.img, Mv, A(e->eva.lin), D.Hv, Opt());
     if (!rc) fail(crct_embed_image_fwd(A(e->eva.lin), b->image_loc, b->image_target, P(e->ev.wloc), P(e->ev.bloc), P(e->ev.color),
                                        P(e->ev.ln.g), P(e->ev.ln.b), A(e->eva.sum), A(e->eva.y), F(e->eva.mean), F(e->eva.rstd),
                                        Mv, D.Hv, 1e-12f, dv.thr, dv.scale, dv.site, c->seed, s));
   }
-  void embed_bwd(size_t gt, size_t gv) {
+  void embed_text_bwd(size_t gt) {
     const CrctModelDims& D = e->d;
-    const int B = b->B, Mv = B * b->V;
-    const Drop dt = drop(D.p_hidden, 1), dv = drop(D.p_hidden, 2);
+    const Drop dt = drop(D.p_hidden, 1);
+    main_after_wgrad();
     if (!rc) fail(crct_embed_text_bwd(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
                                       P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
-                                      G(e->et.ln.g), G(e->et.ln.b), F(e->partials), B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
+                                      G(e->et.ln.g), G(e->et.ln.b), F(partials), b->B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
                                       dt.site, c->seed, s));
+  }
+  void embed_image_bwd(size_t gv) {
+    const CrctModelDims& D = e->d;
+    const int Mv = b->B * b->V;
+    const Drop dv = drop(D.p_hidden, 2);
+    main_after_wgrad();
     if (!rc) fail(crct_embed_image_bwd(A(gv), A(e->eva.sum), F(e->eva.mean), F(e->eva.rstd), b->image_loc, b->image_target,
                                        P(e->ev.ln.g), A(e->sv.gc), G(e->ev.color), G(e->ev.wloc), G(e->ev.bloc), G(e->ev.img.b),
-                                       G(e->ev.ln.g), G(e->ev.ln.b), F(e->partials), Mv, D.Hv, dv.thr, dv.scale, dv.site,
+                                       G(e->ev.ln.g), G(e->ev.ln.b), F(partials), Mv, D.Hv, dv.thr, dv.scale, dv.site,
                                        c->seed, s));
     lin_wgrad(A(e->sv.gc), D.Hv, A(e->eva.soft), D.Fv, e->ev.img, Mv);   // no dgrad: features are inputs
   }
@@ -635,14 +687,14 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->sv = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
   {
     size_t wmax = D.H > D.Hv ? D.H : D.Hv;
-    e->partials = ar.take((size_t)8 * 256 * wmax * 4);
+    for (int k = 0; k < 2; ++k) e->partials[k] = ar.take((size_t)8 * 256 * wmax * 4);
     size_t nmax = 3 * (size_t)D.Hb;
     if ((size_t)D.I > nmax) nmax = D.I;
     if ((size_t)D.Iv > nmax) nmax = D.Iv;
     if (3 * (size_t)D.H > nmax) nmax = 3 * (size_t)D.H;
     if (3 * (size_t)D.Hv > nmax) nmax = 3 * (size_t)D.Hv;
     if (nmax < 1024) nmax = 1024;
-    e->colsum_part = ar.take((size_t)64 * nmax * 4);
+    for (int k = 0; k < 4; ++k) e->colsum_part[k] = ar.take((size_t)64 * nmax * 4);
   }
   e->ws_bytes = ar.top;
 
@@ -693,21 +745,55 @@ extern "C" int crct_engine_segment_range(const crct_engine_t* e, int seg, int64_
   return 0;
 }
 
+namespace {
+
+int ensure_streams(crct_engine* e) {
+  static const char* env = getenv("CRCT_STREAMS");      // "0": single stream, "1": visual stream only, default: all
+  if (env && env[0] == '0') { e->use_vis_stream = false; e->use_wgrad_stream = false; }
+  if (env && env[0] == '1') { e->use_wgrad_stream = false; }
+  for (int k = 0; k < 3; ++k) {
+    const bool need = k == 0 ? e->use_vis_stream : e->use_wgrad_stream;
+    if (need && !e->side[k] && hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) {
+      crct_set_error("engine: cannot create an internal HIP stream");
+      return 1;
+    }
+  }
+  return 0;
+}
+
+// two drivers over one workspace: Rt = text stream on the caller's stream, Rv = visual stream
+void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, void* ws, hipStream_t main, const CrctBatch* batch,
+               const CrctStepCfg* cfg, Run& Rt, Run& Rv) {
+  hipStream_t vis = e->use_vis_stream ? e->side[0] : main;
+  Rt = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, main, batch, cfg, e->use_wgrad_stream ? e->side[1] : main,
+           e->partials[0], e->colsum_part[0], e->colsum_part[2]};
+  Rv = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, vis, batch, cfg, e->use_wgrad_stream ? e->side[2] : vis,
+           e->partials[1], e->colsum_part[1], e->colsum_part[3]};
+}
+
+}  // namespace
+
 extern "C" int crct_engine_forward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
                                    const CrctStepCfg* cfg, void* workspace, float* logits, float* reg, float* stats,
                                    crct_stream_t stream) {
   CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && logits && reg && stats, "engine_forward: null argument");
   if (int r = check_batch(e, batch)) return r;
-  Run R{e, params_f32, (const bf16_t*)params_bf16, nullptr, (char*)workspace, (hipStream_t)stream, batch, cfg};
-  R.embed_fwd();
+  if (int r = ensure_streams(e)) return r;
+  e->evnext = 0;
+  Run Rt, Rv;
+  make_runs(e, params_f32, params_bf16, nullptr, workspace, (hipStream_t)stream, batch, cfg, Rt, Rv);
+  Rv.fail(order_streams(e, Rt.s, Rv.s));                 // fork: the visual stream starts after the caller's prior work
+  Rt.embed_text_fwd();
+  Rv.embed_image_fwd();
   size_t xt = e->eta.y, xv = e->eva.y;
   for (const Step& st : e->sched) {
-    if (st.kind == 't') { R.self_fwd(e->tl[st.idx], e->tla[st.idx], xt, batch->text_keymask, batch->B, batch->T); xt = e->tla[st.idx].ffn.y; }
-    else if (st.kind == 'v') { R.self_fwd(e->vl[st.idx], e->vla[st.idx], xv, batch->image_keymask, batch->B, batch->V); xv = e->vla[st.idx].ffn.y; }
-    else { R.conn_fwd(e->cl[st.idx], e->cla[st.idx], xv, xt); xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
+    if (st.kind == 't') { Rt.self_fwd(e->tl[st.idx], e->tla[st.idx], xt, batch->text_keymask, batch->B, batch->T); xt = e->tla[st.idx].ffn.y; }
+    else if (st.kind == 'v') { Rv.self_fwd(e->vl[st.idx], e->vla[st.idx], xv, batch->image_keymask, batch->B, batch->V); xv = e->vla[st.idx].ffn.y; }
+    else { Rt.conn_fwd(Rv, e->cl[st.idx], e->cla[st.idx], xv, xt); xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
   }
-  R.heads_fwd(xt, xv, logits, reg, stats, false);
-  return R.rc;
+  Rt.fail(order_streams(e, Rv.s, Rt.s));                 // join
+  Rt.heads_fwd(xt, xv, logits, reg, stats, false);
+  return Rt.rc ? Rt.rc : Rv.rc;
 }
 
 extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
@@ -716,7 +802,10 @@ extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, c
   CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && grads_f32 && logits && reg && stats, "engine_backward: null argument");
   CRCT_REQUIRE(batch && batch->labels, "engine_backward: labels are required (training step)");
   if (int r = check_batch(e, batch)) return r;
-  Run R{e, params_f32, (const bf16_t*)params_bf16, grads_f32, (char*)workspace, (hipStream_t)stream, batch, cfg};
+  if (int r = ensure_streams(e)) return r;
+  e->evnext = 0;
+  Run Rt, Rv;
+  make_runs(e, params_f32, params_bf16, grads_f32, workspace, (hipStream_t)stream, batch, cfg, Rt, Rv);
   const int nseg = (int)e->seg_range.size();
   const int s0 = seg < 0 ? 0 : seg, s1 = seg < 0 ? nseg : seg + 1;
   CRCT_REQUIRE(s1 <= nseg, "engine_backward: bad segment %d", seg);
@@ -732,28 +821,38 @@ extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, c
       else { xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
     }
   }
-  for (int sgi = s0; sgi < s1 && !R.rc; ++sgi) {
+  // fork: every internal stream starts after the caller's prior work (previous segment, optimizer, ...)
+  Rv.fail(order_streams(e, Rt.s, Rv.s));
+  Rt.wgrad_after_main();
+  Rv.wgrad_after_main();
+  for (int sgi = s0; sgi < s1 && !Rt.rc && !Rv.rc; ++sgi) {
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
-      R.heads_bwd(e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
+      Rt.heads_bwd(e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
+      Rv.fail(order_streams(e, Rt.s, Rv.s));             // the visual stream picks up d(seq_v) written by the heads
     } else if (sgi == nseg - 1) {
-      R.embed_bwd(e->st.dy[e->cur_t], e->sv.dy[e->cur_v]);
+      Rt.embed_text_bwd(e->st.dy[e->cur_t]);
+      Rv.embed_image_bwd(e->sv.dy[e->cur_v]);
     } else {
       const size_t i = e->sched.size() - (size_t)sgi;
       const Step& st = e->sched[i];
       if (st.kind == 't') {
-        R.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], e->st, batch->text_keymask, batch->B, batch->T);
+        Rt.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], e->st, batch->text_keymask, batch->B, batch->T);
         e->cur_t ^= 1;
       } else if (st.kind == 'v') {
-        R.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], e->sv, batch->image_keymask, batch->B, batch->V);
+        Rv.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], e->sv, batch->image_keymask, batch->B, batch->V);
         e->cur_v ^= 1;
       } else {
-        R.conn_bwd(e->cl[st.idx], e->cla[st.idx], in_v[i], in_t[i], e->sv.dy[e->cur_v], e->st.dy[e->cur_t], e->sv.dy[e->cur_v ^ 1], e->st.dy[e->cur_t ^ 1]);
+        Rt.conn_bwd(Rv, e->cl[st.idx], e->cla[st.idx], in_v[i], in_t[i], e->sv.dy[e->cur_v], e->st.dy[e->cur_t], e->sv.dy[e->cur_v ^ 1], e->st.dy[e->cur_t ^ 1]);
         e->cur_t ^= 1; e->cur_v ^= 1;
       }
     }
   }
-  return R.rc;
+  // join: everything this call enqueued anywhere is ordered before later work on the caller's stream
+  Rt.main_after_wgrad();
+  Rv.main_after_wgrad();
+  Rt.fail(order_streams(e, Rv.s, Rt.s));
+  return Rt.rc ? Rt.rc : Rv.rc;
 }
 
 extern "C" int64_t crct_engine_tap(crct_engine_t* e, const void* workspace, const char* name, int B, int T, int V, void* out,

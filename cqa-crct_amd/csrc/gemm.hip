@@ -93,78 +93,56 @@ struct Stage {
   }
 };
 
-template <int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ldsA = smem;
-  char* ldsB = smem + BM * BK * 2;
+// ------------------------------------------------------------------ XCD-aware tile placement
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group, each with a
+// private 4 MiB L2).  The tile grid is cut into gm x gn = 8 rectangles, one per XCD, chosen so that
+// the A' and B' panels one XCD touches (rm*BM + rn*BN rows of K) are as few as possible and stay
+// L2-resident; block j of XCD x takes the j-th tile of rectangle x.  Placement only affects speed.
+struct TileMap { int tiles_m, tiles_n, gn, rm, rn; };
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+__device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int& tn) {
+  const int x = bid & 7, j = bid >> 3;
+  const int m_lo = (x / t.gn) * t.rm, n_lo = (x % t.gn) * t.rn;
+  const int hm = min(t.rm, t.tiles_m - m_lo), hn = min(t.rn, t.tiles_n - n_lo);
+  if (hm <= 0 || hn <= 0 || j >= hm * hn) return false;
+  tm = m_lo + j / hn;
+  tn = n_lo + j % hn;
+  return true;
+}
 
-  // ---- XCD-aware tile order: blocks that land on one XCD (bid % 8) walk neighbouring tiles of
-  // one row-panel, so the panel of A' stays in that XCD's L2 (cdna_hip_programming.md T1, bijective form)
-  const int nwg = gridDim.x;
-  const int tiles_n = (g.N + BN - 1) / BN;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, j = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid) {
+  TileMap t;
+  t.tiles_m = (M + BM - 1) / BM; t.tiles_n = (N + BN - 1) / BN;
+  long best = -1;
+  int bgm = 1;
+  for (int gm = 1; gm <= 8; gm *= 2) {
+    const int gn = 8 / gm;
+    const int rm = (t.tiles_m + gm - 1) / gm, rn = (t.tiles_n + gn - 1) / gn;
+    // panel rows held per XCD, plus a penalty for padded (idle) blocks
+    const long cost = (long)rm * BM + (long)rn * BN + 4L * ((long)rm * rn * 8 - (long)t.tiles_m * t.tiles_n) * 16;
+    if (best < 0 || cost < best) { best = cost; bgm = gm; }
   }
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  t.gn = 8 / bgm;
+  t.rm = (t.tiles_m + bgm - 1) / bgm; t.rn = (t.tiles_n + t.gn - 1) / t.gn;
+  *grid = 8 * t.rm * t.rn;
+  return t;
+}
 
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
-
-  f4_t acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-  Stage<TA, TM> sa;
-  Stage<TB, TN> sb;
-  const int nk = (g.K + BK - 1) / BK;
-  sa.load(A, g.lda, m0, 0, g.M, g.K, tid);
-  sb.load(B, g.ldb, n0, 0, g.N, g.K, tid);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    sa.store(ldsA, tid);
-    sb.store(ldsB, tid);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
-      sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 32) {
-      bf8_t fm[TM], fn[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fm[i] = load_frag<TA, TM>(ldsA, wm * (BM / 2) + i * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fn[i] = load_frag<TB, TN>(ldsB, wn * (BN / 2) + i * 16, ks, lane);
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[a], fm[b], acc[a][b], 0, 0, 0);
-    }
-  }
-
-  // ------------------------------------------------------------------ epilogue
-  // D rows = n (4 consecutive per lane), D cols = m (lane & 15)
+// ------------------------------------------------------------------ shared epilogue
+// D rows = n (4 consecutive per lane), D cols = m (lane & 15)
+// (mw0, nw0) = origin of this wave's sub-tile; TM x TN = its 16x16 MFMA tiles
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const CrctGemmArgs& g, f4_t (&acc)[TN][TM], int mw0, int nw0, int lane) {
   const float* bias = g.bias;
   const uint32_t thr = g.drop_thr;
   const float dscale = g.drop_scale;
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
-    const int m = m0 + wm * (BM / 2) + b * 16 + (lane & 15);
+    const int m = mw0 + b * 16 + (lane & 15);
     if (m >= g.M) continue;
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
-      const int n = n0 + wn * (BN / 2) + a * 16 + (lane >> 4) * 4;
+      const int n = nw0 + a * 16 + (lane >> 4) * 4;
       if (n >= g.N) continue;
       float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
       if (g.alpha != 1.0f) {
@@ -222,14 +200,224 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g) {
   }
 }
 
+template <int TM, int TN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;
+  char* ldsB = smem + BM * BK * 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int tile_m, tile_n;
+  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+
+  f4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  Stage<TA, TM> sa;
+  Stage<TB, TN> sb;
+  const int nk = (g.K + BK - 1) / BK;
+  sa.load(A, g.lda, m0, 0, g.M, g.K, tid);
+  sb.load(B, g.ldb, n0, 0, g.N, g.K, tid);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    sa.store(ldsA, tid);
+    sb.store(ldsB, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+      sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 32) {
+      bf8_t fm[TM], fn[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fm[i] = load_frag<TA, TM>(ldsA, wm * (BM / 2) + i * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fn[i] = load_frag<TB, TN>(ldsB, wn * (BN / 2) + i * 16, ks, lane);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[a], fm[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  gemm_epilogue<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane);
+}
+
+// ====================================================================================== pipelined
+// LDS-DMA variant (K % 64 == 0): operand tiles go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds
+// (no VGPR staging, no ds_write), NS stages deep, ONE raw s_barrier per K-step and a counted
+// s_waitcnt vmcnt(N) that leaves the younger tiles in flight across the barrier
+// (cdna_hip_programming.md section 5, "Pipelining across barriers").  The CRCT GEMMs give each CU
+// about one tile, so there are no other workgroups to hide HBM/L2 latency behind: the prefetch depth
+// inside the workgroup is what matters.  LDS images are identical to the generic kernel's; because
+// the DMA writes lane-linearly, the swizzle is applied to each lane's SOURCE address (rule 21).
+// Rows beyond M / N are fetched through an out-of-range buffer offset (hardware returns zeros).
+constexpr unsigned OOB_OFF = 0x80000000u;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <bool T, int RC>
+__device__ __forceinline__ unsigned dma_src_offset(int slot, int r0, int R, long ld) {
+  // slot = 16-byte slot index inside the operand image; returns the byte offset of its source chunk at k0 = 0
+  if constexpr (!T) {
+    const int r = slot >> 3, ch = (slot & 7) ^ (r & 7);
+    return (r0 + r < R) ? (unsigned)((((long)(r0 + r)) * ld + ch * 8) * 2) : OOB_OFF;
+  } else {
+    const int byte = slot << 4;
+    const int grp = byte / (RC * 512), rem = byte % (RC * 512);
+    const int sub = rem >> 9, rem2 = rem & 511;
+    const int k = grp * 8 + (rem2 >> 6);
+    const int c3 = (rem2 & 63) >> 4;
+    const int ch = sub * 4 + (c3 ^ ((k >> 2) & 3));
+    return (r0 + ch * 8 < R) ? (unsigned)(((long)k * ld + r0 + ch * 8) * 2) : OOB_OFF;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#define CRCT_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+  if constexpr (N < 0) {}
+  CRCT_VMCNT_CASE(0) CRCT_VMCNT_CASE(1) CRCT_VMCNT_CASE(2) CRCT_VMCNT_CASE(3) CRCT_VMCNT_CASE(4) CRCT_VMCNT_CASE(5)
+  CRCT_VMCNT_CASE(6) CRCT_VMCNT_CASE(7) CRCT_VMCNT_CASE(8) CRCT_VMCNT_CASE(9) CRCT_VMCNT_CASE(10) CRCT_VMCNT_CASE(11)
+  CRCT_VMCNT_CASE(12) CRCT_VMCNT_CASE(13) CRCT_VMCNT_CASE(14) CRCT_VMCNT_CASE(15) CRCT_VMCNT_CASE(16) CRCT_VMCNT_CASE(18)
+  CRCT_VMCNT_CASE(20) CRCT_VMCNT_CASE(24)
+  else static_assert(N == 0, "add the vmcnt literal");
+#undef CRCT_VMCNT_CASE
+}
+
+// Block tile (32*TM) x (32*TN), WM x WN waves (4 or 8), each wave owning a (BM/WM) x (BN/WN) sub-tile.
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave per K tile
+  constexpr int L = PA + PB;
+  constexpr int WTM = BM / WM / 16, WTN = BN / WN / 16;                  // 16x16 MFMA tiles per wave
+  static_assert(PA >= 1 && PB >= 1 && PA * NW * 1024 == A_BYTES && PB * NW * 1024 == B_BYTES, "tile / wave-grid mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int tile_m, tile_n;
+  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)OOB_OFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)OOB_OFF, 0x00020000);
+  unsigned offA[PA], offB[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) offA[i] = dma_src_offset<TA, TM>((i * NW + wave) * 64 + lane, m0, g.M, g.lda);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) offB[i] = dma_src_offset<TB, TN>((i * NW + wave) * 64 + lane, n0, g.N, g.ldb);
+  const int stepA = TA ? (int)(64 * g.lda * 2) : 128;     // bytes per K tile
+  const int stepB = TB ? (int)(64 * g.ldb * 2) : 128;
+
+  f4_t acc[WTN][WTM];
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  auto issue = [&](int kt, int st) {
+    char* base = smem + st * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + i * NW * 1024), 16, (int)offA[i], kt * stepA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NW * 1024), 16, (int)offB[i], kt * stepB, 0, 0);
+  };
+
+  const int npre = nk < NS - 1 ? nk : NS - 1;
+  for (int t = 0; t < npre; ++t) issue(t, t);
+
+  int st = 0, st_next = NS - 1;      // stage holding tile kt; stage the next prefetch goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = (nk - 1 < kt + NS - 2 ? nk - 1 : kt + NS - 2) - kt;     // younger tiles that may stay in flight
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
+    const char* ldsA = smem + st * STAGE;
+    const char* ldsB = ldsA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 32) {
+      bf8_t fm[WTM], fn[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) fm[i] = load_frag<TA, TM>(ldsA, wm * (BM / WM) + i * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) fn[i] = load_frag<TB, TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
+#pragma unroll
+      for (int a = 0; a < WTN; ++a)
+#pragma unroll
+        for (int b = 0; b < WTM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[a], fm[b], acc[a][b], 0, 0, 0);
+    }
+    st_next = st;
+    st = st + 1 == NS ? 0 : st + 1;
+  }
+  gemm_epilogue<WTM, WTN>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  int tiles = 0;
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
+  const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_PIPE(TA_, TB_)                                                                                         \
+  do {                                                                                                                     \
+    auto kern = gemm_pipe_kernel<TM, TN, WM, WN, TA_, TB_, NS>;                                                            \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                            \
+  } while (0)
+  if (!g.ta && !g.tb) CRCT_LAUNCH_PIPE(false, false);
+  else if (!g.ta && g.tb) CRCT_LAUNCH_PIPE(false, true);
+  else if (g.ta && g.tb) CRCT_LAUNCH_PIPE(true, true);
+  else return hipErrorInvalidValue;
+#undef CRCT_LAUNCH_PIPE
+  return hipGetLastError();
+}
+
+// the DMA path needs whole K tiles, 32-bit source offsets, and 16-byte aligned rows
+inline bool pipe_ok(const CrctGemmArgs& g) {
+  if (g.K % BK != 0 || g.K < BK) return false;
+  const long spanA = g.ta ? (long)g.K * g.lda : (long)g.M * g.lda;
+  const long spanB = g.tb ? (long)g.K * g.ldb : (long)g.N * g.ldb;
+  return spanA * 2 < 0x7f000000L && spanB * 2 < 0x7f000000L;
+}
+
 template <int TM, int TN>
 hipError_t launch_cfg(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  int tiles = 0;
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)(BM + BN) * BK * 2;
-  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(tiles), dim3(256), lds, s, g);
-  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(tiles), dim3(256), lds, s, g);
-  else if (g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(tiles), dim3(256), lds, s, g);
+  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(tiles), dim3(256), lds, s, g, tmap);
+  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(tiles), dim3(256), lds, s, g, tmap);
+  else if (g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(tiles), dim3(256), lds, s, g, tmap);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -246,6 +434,17 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
   return 3;
 }
 
+// Configuration of the LDS-DMA kernel per call, from tools/gemm_lab measurements on MI355X at the
+// CRCT shapes (profiles/gemm_lab_r1.txt): every GEMM here is a 1-2 wave problem whose time is set by
+// L2->LDS traffic and prefetch latency, so 8-wave workgroups with 2 resident per CU win.
+//   12: 128x64, 8 waves (4x2), 2 stages    11: 64x128, 8 waves, 3 stages    3: 64x64, 4 waves, 4 stages
+static int pick_pipe_config(const CrctGemmArgs& g) {
+  if (g.M <= 96) return 3;                                          // head / regressor GEMMs: B rows
+  if (g.ta) return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 12;     // wgrad
+  if (g.N <= 1024 && g.K >= 2048) return g.tb ? 3 : 11;             // narrow output, long K
+  return 12;
+}
+
 // ---- optional live profiling: HIP events around every GEMM launch, on the launch stream ----------
 // (bench.py: roofline.achieved = algorithmic FLOPs per launch / average launch duration per variant)
 namespace {
@@ -254,9 +453,13 @@ struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
-  double flops[12] = {0}; long count[12] = {0};
+  double flops[48] = {0}; long count[48] = {0};
 } g_prof;
 }  // namespace
+
+static bool g_force_generic = false;
+// test hook: route every GEMM through the register-staged kernel (parity of both code paths)
+extern "C" int crct_gemm_force_generic(int on) { g_force_generic = on != 0; return 0; }
 
 extern "C" int crct_prof_enable(int on) {
   g_prof.on = on != 0;
@@ -264,12 +467,13 @@ extern "C" int crct_prof_enable(int on) {
 }
 extern "C" int crct_prof_reset(void) {
   g_prof.used = 0;
-  for (int i = 0; i < 12; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
+  for (int i = 0; i < 48; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
   return 0;
 }
-// variant = tile * 3 + {0: fwd (NT), 1: dgrad (tb), 2: wgrad (ta, tb)}.  Synchronises the events.
+// variant = config * 3 + {0: fwd (NT), 1: dgrad (tb), 2: wgrad (ta, tb)}; config 0..12 = LDS-DMA kernel
+// configurations, 13..16 = register-staged kernel tiles 0..3.  Synchronises the events.
 extern "C" int crct_prof_read(int variant, long* count, double* flops, double* ms) {
-  if (variant < 0 || variant >= 12) return 1;
+  if (variant < 0 || variant >= 48) return 1;
   double t = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     if (g_prof.slots[i].variant != variant) continue;
@@ -284,8 +488,11 @@ extern "C" int crct_prof_read(int variant, long* count, double* flops, double* m
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
-  int t = g.tile >= 0 ? g.tile : crct_gemm_pick_tile(g.M, g.N);
-  if (t > 3) t = 3;
+  const bool pipe = pipe_ok(g) && !g_force_generic;
+  int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
+  if (t > 12) t = 12;
+  if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
+  if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
   ProfSlot* slot = nullptr;
   if (g_prof.on) {
     if (g_prof.used == g_prof.slots.size()) {
@@ -294,17 +501,35 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       g_prof.slots.push_back(ns);
     }
     slot = &g_prof.slots[g_prof.used++];
-    slot->variant = t * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
+    slot->variant = (pipe ? t : 13 + (t & 3)) * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
     g_prof.count[slot->variant] += 1;
     g_prof.flops[slot->variant] += 2.0 * g.M * g.N * g.K;
     hipEventRecord(slot->a, s);
   }
   hipError_t e;
-  switch (t) {
-    case 0: e = launch_cfg<4, 4>(g, s); break;
-    case 1: e = launch_cfg<4, 2>(g, s); break;
-    case 2: e = launch_cfg<2, 4>(g, s); break;
-    default: e = launch_cfg<2, 2>(g, s); break;
+  if (pipe) {
+    switch (t) {
+      case 0: e = launch_pipe<4, 4, 2, 2, 3>(g, s); break;
+      case 1: e = launch_pipe<4, 2, 2, 2, 4>(g, s); break;
+      case 2: e = launch_pipe<2, 4, 2, 2, 4>(g, s); break;
+      case 3: e = launch_pipe<2, 2, 2, 2, 4>(g, s); break;
+      case 4: e = launch_pipe<4, 4, 2, 4, 3>(g, s); break;     // 128x128, 8 waves
+      case 5: e = launch_pipe<4, 8, 2, 4, 3>(g, s); break;     // 128x256, 8 waves
+      case 6: e = launch_pipe<8, 4, 4, 2, 3>(g, s); break;     // 256x128, 8 waves
+      case 7: e = launch_pipe<8, 8, 2, 4, 2>(g, s); break;     // 256x256, 8 waves, 2 stages
+      case 8: e = launch_pipe<4, 4, 2, 4, 4>(g, s); break;     // 128x128, 8 waves, 4 stages
+      case 9: e = launch_pipe<4, 4, 2, 4, 2>(g, s); break;     // 128x128, 8 waves, 2 stages (2 blocks / CU)
+      case 10: e = launch_pipe<4, 2, 2, 4, 3>(g, s); break;    // 128x64, 8 waves
+      case 11: e = launch_pipe<2, 4, 2, 4, 3>(g, s); break;    // 64x128, 8 waves
+      default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
+    }
+  } else {
+    switch (t) {
+      case 0: e = launch_cfg<4, 4>(g, s); break;
+      case 1: e = launch_cfg<4, 2>(g, s); break;
+      case 2: e = launch_cfg<2, 4>(g, s); break;
+      default: e = launch_cfg<2, 2>(g, s); break;
+    }
   }
   if (slot) hipEventRecord(slot->b, s);
   return e;

@@ -293,17 +293,35 @@ struct FinalizeArgs {
   int Q, nblk, H, accumulate;
   const float* partials;
 };
-__global__ void finalize_partials_kernel(const FinalizeArgs a) {
+// 32 columns x 8 row-groups per 256-thread block: each thread sums nblk/8 partial rows (independent
+// loads, unrolled), then an LDS tree over the 8 groups.
+__global__ __launch_bounds__(256) void finalize_partials_kernel(const FinalizeArgs a) {
+  __shared__ float red[8][33];
   const int q = blockIdx.y;
   float* o = a.out[q];
   if (!o) return;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.H) return;
-  const float* p = a.partials + ((long)q * a.nblk) * a.H + c;
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int b = 0; b < a.nblk; ++b) s += p[(long)b * a.H];
-  const long oi = (long)c * a.stride[q];
-  o[oi] = a.accumulate ? o[oi] + s : s;
+  if (c < a.H) {
+    const float* p = a.partials + ((long)q * a.nblk) * a.H + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = rg;
+    for (; b + 24 < a.nblk; b += 32) {
+      s0 += p[(long)b * a.H]; s1 += p[(long)(b + 8) * a.H]; s2 += p[(long)(b + 16) * a.H]; s3 += p[(long)(b + 24) * a.H];
+    }
+    for (; b < a.nblk; b += 8) s0 += p[(long)b * a.H];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < a.H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    const long oi = (long)c * a.stride[q];
+    o[oi] = a.accumulate ? o[oi] + t : t;
+  }
 }
 
 // ------------------------------------------------------------------------------ column sum
@@ -531,7 +549,7 @@ inline int row_grid(long M, int cap) {
   }
 
 int launch_finalize(const FinalizeArgs& fa, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_partials_kernel, dim3((fa.H + 127) / 128, fa.Q), dim3(128), 0, s, fa);
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3((fa.H + 31) / 32, fa.Q), dim3(256), 0, s, fa);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

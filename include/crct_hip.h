@@ -60,8 +60,13 @@ int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 
+/* Test hook: on != 0 routes every GEMM through the register-staged kernel (any K % 8 == 0) instead of
+ * the LDS-DMA pipelined kernel (K % 64 == 0), so the parity tests can cover both code paths. */
+int crct_gemm_force_generic(int on);
+
 /* Live measurement for bench.py: when enabled, every GEMM launch is bracketed by HIP events on its
- * launch stream.  variant = tile*3 + {0 forward, 1 dgrad (tb), 2 wgrad (ta,tb)}.  crct_prof_read
+ * launch stream.  variant = config*3 + {0 forward, 1 dgrad (tb), 2 wgrad (ta,tb)}, config 0..12 = LDS-DMA
+ * kernel configurations (tile / waves / stages, see gemm.hip), 13..16 = register-staged kernel tiles.  crct_prof_read
  * synchronises on the recorded events and returns launches, summed algorithmic FLOPs (2MNK) and
  * summed elapsed milliseconds of that variant since the last reset. */
 int crct_prof_enable(int on);

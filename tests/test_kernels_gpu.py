@@ -34,6 +34,16 @@ def rand(*shape, scale=1.0, seed=0):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=["pipelined", "generic"], autouse=True)
+def gemm_path(request):
+    """Every test runs with the LDS-DMA pipelined kernel (default for K % 64 == 0) and with every GEMM forced
+    through the register-staged generic kernel."""
+    lib = L.load()
+    lib.crct_gemm_force_generic(int(request.param == "generic"))
+    yield request.param
+    lib.crct_gemm_force_generic(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(1600, 3072, 768), (2880, 1024, 2048), (1600, 768, 3072), (80, 1024, 768),
                                    (21, 64, 96), (15, 128, 32), (300, 2304, 768)])
 @pytest.mark.parametrize("tile", [-1, 0, 3])
