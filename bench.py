@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=80)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--graph", action="store_true", help="experimental: replay forward / backward from captured hipGraphs "
+                    "(measured: no gain -- the step is GPU-bound -- and not yet supported with the wgrad side streams)")
     return ap.parse_args()
 
 
@@ -69,9 +71,12 @@ def gemm_profile(model, run_step, n_steps):
     lib = L.load()
     lib.crct_prof_reset()
     lib.crct_prof_enable(1)
+    core = model.bert_pretrained
+    graph_mode, core.use_graph = core.use_graph, False      # timing events cannot be recorded inside a captured graph
     for _ in range(n_steps):
         run_step()
     torch.cuda.synchronize()
+    core.use_graph = graph_mode
     lib.crct_prof_enable(0)
     rows = []
     for v in range(48):
@@ -133,6 +138,7 @@ def main():
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
+    core.use_graph = bool(a.graph)
     model.train()
     opt = get_optimizer(params, model)
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])

@@ -38,7 +38,8 @@ class StepEngine(object):
         self.max = (int(max_B), int(max_T), int(max_V))
         names = "\n".join(e.name for e in self.table).encode()
         offs = (C.c_int64 * len(self.table))(*[e.offset for e in self.table])
-        sizes = (C.c_int64 * len(self.table))(*[e.numel for e in self.table])
+        # size 0 marks the tensors that never receive a gradient: they are left out of the backward segments' ranges
+        sizes = (C.c_int64 * len(self.table))(*[e.numel if e.used else 0 for e in self.table])
         dims = model_dims(cfg, params, cls_dropout)
         self.handle = self.lib.crct_engine_create(C.byref(dims), names, offs, sizes, len(self.table), *self.max)
         if not self.handle:
@@ -59,6 +60,13 @@ class StepEngine(object):
         self.reg = torch.zeros(5, B, device=self.device)
         self.stats = torch.zeros(8, device=self.device)
         self._keep = None
+        # hipGraph mode: kernel arguments are baked at capture, so everything that changes per step lives in
+        # persistent device buffers: the dropout seed, the batch (staged copies), the upstream loss gradients
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.g_nsp_dev = torch.zeros(1, device=self.device)
+        self.g_reg_dev = torch.zeros(B, device=self.device)
+        self._stage = {}
+        self.gstream = torch.cuda.Stream(device=self.device)     # stream capture is illegal on the default (NULL) stream
 
     def __del__(self):
         try:
@@ -78,30 +86,72 @@ class StepEngine(object):
         b.B, b.T, b.V = t["tokens"].shape[0], t["tokens"].shape[1], t["image_feat"].shape[1]
         return b
 
-    @staticmethod
-    def _cfg(step):
+    def stage_batch(self, tensors):
+        """Copy a device batch into persistent buffers (stable addresses for graph replay)."""
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items()))
+        st = self._stage.get(key)
+        if st is None:
+            st = {k: torch.empty_like(v) for k, v in tensors.items()}
+            self._stage[key] = st
+        for k, v in tensors.items():
+            st[k].copy_(v, non_blocking=True)
+        return st
+
+    def _cfg(self, step):
         c = L.StepCfg()
         c.training, c.use_l1, c.kind_l1 = int(step["training"]), int(step["use_l1"]), int(step["kind_l1"])
         c.tol_margin, c.nsp_coeff, c.reg_coeff = step["tol_margin"], step["nsp_coeff"], step["reg_coeff"]
-        c.grad_scale, c.seed = step.get("grad_scale", 1.0), int(step["seed"])
-        c.g_nsp_dev, c.g_reg_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg"))
+        c.grad_scale = step.get("grad_scale", 1.0)
+        c.use_graph = int(bool(step.get("use_graph", False)))
+        g_nsp, g_reg = step.get("g_nsp"), step.get("g_reg")
+        if c.use_graph:
+            if not step.get("_seed_set"):
+                self.seed_dev.fill_(int(step["seed"]))
+                step["_seed_set"] = True
+            c.seed = (1 << 63) | self.seed_dev.data_ptr()
+            if g_nsp is not None:
+                self.g_nsp_dev.copy_(g_nsp.reshape(1))
+                g_nsp = self.g_nsp_dev
+            if g_reg is not None:
+                n = g_reg.numel()
+                self.g_reg_dev[:n].copy_(g_reg)
+                g_reg = self.g_reg_dev
+        else:
+            c.seed = int(step["seed"])
+        c.g_nsp_dev, c.g_reg_dev = L.ptr(g_nsp), L.ptr(g_reg)
         return c
+
+    def _enter(self, graph):
+        """Stream the engine call is enqueued on: the caller's current stream, or (graph mode) the engine's own
+        capturable stream, ordered after the current stream."""
+        if not graph:
+            return L.current_stream()
+        self.gstream.wait_stream(torch.cuda.current_stream())
+        return self.gstream.cuda_stream
+
+    def _leave(self, graph):
+        if graph:
+            torch.cuda.current_stream().wait_stream(self.gstream)
 
     def forward(self, p32, p16, tensors, step):
         B = tensors["tokens"].shape[0]
         b, c = self._batch(tensors), self._cfg(step)
         self._keep = (tensors, step)
+        stream = self._enter(c.use_graph)
         L.check(self.lib.crct_engine_forward(self.handle, p32.data_ptr(), p16.data_ptr(), C.byref(b), C.byref(c),
                                              self.workspace.data_ptr(), self.logits.data_ptr(), self.reg.data_ptr(),
-                                             self.stats.data_ptr(), L.current_stream()), "engine_forward")
+                                             self.stats.data_ptr(), stream), "engine_forward")
+        self._leave(c.use_graph)
         return self.logits[:B], self.reg.view(-1)[:5 * B].view(5, B), self.stats
 
     def backward(self, p32, p16, g32, tensors, step, seg=-1):
         b, c = self._batch(tensors), self._cfg(step)
+        stream = self._enter(c.use_graph)
         L.check(self.lib.crct_engine_backward(self.handle, p32.data_ptr(), p16.data_ptr(), C.byref(b), C.byref(c),
                                               self.workspace.data_ptr(), g32.data_ptr(), self.logits.data_ptr(),
-                                              self.reg.data_ptr(), self.stats.data_ptr(), int(seg), L.current_stream()),
+                                              self.reg.data_ptr(), self.stats.data_ptr(), int(seg), stream),
                 "engine_backward")
+        self._leave(c.use_graph)
 
     def tap(self, name, B, T, V):
         n_max = B * max(T * self.cfg.hidden_size, V * self.cfg.v_hidden_size)

@@ -268,9 +268,11 @@ inline int tile_class(int T) { return T <= 32 ? 2 : (T <= 48 ? 3 : (T <= 112 ? 7
 template <bool BWD, int AQ, int AK>
 hipError_t launch_one(const AttnArgs& a, size_t lds, hipStream_t s) {
   auto kern = BWD ? attn_bwd_kernel<AQ, AK> : attn_fwd_kernel<AQ, AK>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t attr_lds = 0;        // raised once per instantiation, outside any stream capture (1st call is eager)
+  if (lds > 64 * 1024 && lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    attr_lds = 160 * 1024;
   }
   hipLaunchKernelGGL(kern, dim3(a.B * a.heads), dim3(256), lds, s, a);
   return hipGetLastError();

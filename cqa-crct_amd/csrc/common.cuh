@@ -38,7 +38,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // Dropout masks are never stored: forward and backward regenerate them from
 // (seed, site, element index).  One call yields 4 x u32 for elements idx..idx+3 (idx % 4 == 0).
 struct Philox4 { uint32_t x, y, z, w; };
+// `seed` is either the value itself or, with bit 63 set, the device address of a u64 holding it:
+// a captured hipGraph bakes kernel arguments, so the per-step seed is then read from memory that the
+// host refreshes before every replay (uniform address -> one scalar load).
+#define CRCT_SEED_IN_MEMORY 0x8000000000000000ull
 __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, uint64_t idx4) {
+  if (seed & CRCT_SEED_IN_MEMORY) seed = *reinterpret_cast<const uint64_t*>(seed & ~CRCT_SEED_IN_MEMORY);
   uint32_t c0 = (uint32_t)idx4, c1 = (uint32_t)(idx4 >> 32), c2 = site, c3 = 0x9E3779B9u;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll

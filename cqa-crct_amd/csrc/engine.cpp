@@ -116,6 +116,10 @@ struct crct_engine {
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
   std::vector<hipEvent_t> evpool;
   size_t evnext = 0;
+  // hipGraph cache: one executable graph per distinct (call kind, pointers, sizes, flags)
+  struct GraphEntry { std::vector<char> key; int seen = 0; hipGraphExec_t exec = nullptr; };
+  std::vector<GraphEntry> graphs;
+  bool graph_broken = false;
   std::vector<std::pair<int64_t, int64_t>> seg_range;
   std::vector<Tap> taps;
   size_t final_t = 0, final_v = 0;   // offsets of the last-layer outputs
@@ -198,8 +202,9 @@ struct Run {
   hipStream_t sw;                      // stream of this data stream's weight-gradient GEMMs (== s when disabled)
   size_t partials, colsum_part, colsum_part_w;
   int rc = 0;
-  void wgrad_after_main() { if (!rc && sw != s) fail(order_streams(e, s, sw)); }     // sw sees what s produced
-  void main_after_wgrad() { if (!rc && sw != s) fail(order_streams(e, sw, s)); }     // s may now overwrite what sw read
+  bool sw_dirty = false;               // sw has work that s has not been ordered after yet (no empty forks / joins)
+  void wgrad_after_main() { if (!rc && sw != s) { fail(order_streams(e, s, sw)); sw_dirty = true; } }     // sw sees what s produced
+  void main_after_wgrad() { if (!rc && sw != s && sw_dirty) { fail(order_streams(e, sw, s)); sw_dirty = false; } }   // s may overwrite what sw read
 
   template <class T> T* W(size_t o) const { return reinterpret_cast<T*>(ws + o); }
   bf16_t* A(size_t o) const { return W<bf16_t>(o); }
@@ -718,7 +723,7 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     int64_t lo = INT64_MAX, hi = -1;
     for (auto& kv : e->off)
       for (auto& pf : prefixes)
-        if (kv.first.compare(0, pf.size(), pf) == 0) {
+        if (kv.first.compare(0, pf.size(), pf) == 0 && e->size[kv.first] > 0) {    // size 0 = never receives a gradient
           if (kv.second < lo) lo = kv.second;
           const int64_t end = kv.second + e->size[kv.first];
           if (end > hi) hi = end;
@@ -736,7 +741,13 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   return e;
 }
 
-extern "C" void crct_engine_destroy(crct_engine_t* e) { delete e; }
+extern "C" void crct_engine_destroy(crct_engine_t* e) {
+  if (!e) return;
+  for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  for (auto ev : e->evpool) (void)hipEventDestroy(ev);
+  for (auto st : e->side) if (st) (void)hipStreamDestroy(st);
+  delete e;
+}
 extern "C" size_t crct_engine_workspace_bytes(const crct_engine_t* e) { return e ? e->ws_bytes : 0; }
 extern "C" int crct_engine_num_segments(const crct_engine_t* e) { return e ? (int)e->seg_range.size() : 0; }
 extern "C" int crct_engine_segment_range(const crct_engine_t* e, int seg, int64_t* lo, int64_t* hi) {
@@ -773,9 +784,9 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
 
 }  // namespace
 
-extern "C" int crct_engine_forward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
-                                   const CrctStepCfg* cfg, void* workspace, float* logits, float* reg, float* stats,
-                                   crct_stream_t stream) {
+static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
+                               const CrctStepCfg* cfg, void* workspace, float* logits, float* reg, float* stats,
+                               crct_stream_t stream) {
   CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && logits && reg && stats, "engine_forward: null argument");
   if (int r = check_batch(e, batch)) return r;
   if (int r = ensure_streams(e)) return r;
@@ -796,9 +807,9 @@ extern "C" int crct_engine_forward(crct_engine_t* e, const float* params_f32, co
   return Rt.rc ? Rt.rc : Rv.rc;
 }
 
-extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
-                                    const CrctStepCfg* cfg, void* workspace, float* grads_f32, float* logits, float* reg,
-                                    float* stats, int seg, crct_stream_t stream) {
+static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
+                                const CrctStepCfg* cfg, void* workspace, float* grads_f32, float* logits, float* reg,
+                                float* stats, int seg, crct_stream_t stream) {
   CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && grads_f32 && logits && reg && stats, "engine_backward: null argument");
   CRCT_REQUIRE(batch && batch->labels, "engine_backward: labels are required (training step)");
   if (int r = check_batch(e, batch)) return r;
@@ -823,8 +834,6 @@ extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, c
   }
   // fork: every internal stream starts after the caller's prior work (previous segment, optimizer, ...)
   Rv.fail(order_streams(e, Rt.s, Rv.s));
-  Rt.wgrad_after_main();
-  Rv.wgrad_after_main();
   for (int sgi = s0; sgi < s1 && !Rt.rc && !Rv.rc; ++sgi) {
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
@@ -853,6 +862,95 @@ extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, c
   Rv.main_after_wgrad();
   Rt.fail(order_streams(e, Rv.s, Rt.s));
   return Rt.rc ? Rt.rc : Rv.rc;
+}
+
+// ---- hipGraph front-end: 1st call with a given key runs eagerly (lazy one-time setup such as
+// hipFuncSetAttribute happens there), the 2nd is captured (fork / join of the internal streams
+// included) and instantiated, later ones are a single hipGraphLaunch.
+namespace {
+template <class F>
+int run_graphed(crct_engine* e, const std::vector<char>& key, hipStream_t stream, F&& body) {
+  crct_engine::GraphEntry* ent = nullptr;
+  for (auto& g : e->graphs)
+    if (g.key == key) { ent = &g; break; }
+  if (!ent) {
+    if (e->graphs.size() > 64) e->graphs.erase(e->graphs.begin());
+    e->graphs.emplace_back();
+    ent = &e->graphs.back();
+    ent->key = key;
+  }
+  if (ent->exec) {
+    if (hipGraphLaunch(ent->exec, stream) != hipSuccess) { crct_set_error("engine: hipGraphLaunch failed"); return 1; }
+    return 0;
+  }
+  if (ent->seen++ == 0 || e->graph_broken) return body();
+  static const bool dbg = getenv("CRCT_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[crct] begin capture on stream %p\n", (void*)stream);
+  if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->graph_broken = true; (void)hipGetLastError(); return body(); }
+  const int rc = body();
+  if (dbg) fprintf(stderr, "[crct] body rc=%d (%s)\n", rc, crct_last_error());
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(stream, &graph);
+  if (dbg) fprintf(stderr, "[crct] end capture: %s graph=%p\n", hipGetErrorString(ec), (void*)graph);
+  if (rc || ec != hipSuccess || !graph) {
+    e->graph_broken = true;
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc) return rc;
+    crct_set_error("engine: stream capture failed (%s); falling back to direct launches", hipGetErrorString(ec));
+    return body();
+  }
+  hipGraphExec_t exec = nullptr;
+  if (dbg) { size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn); fprintf(stderr, "[crct] instantiating graph with %zu nodes\n", nn); }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    e->graph_broken = true;
+    return body();
+  }
+  (void)hipGraphDestroy(graph);
+  ent->exec = exec;
+  if (dbg) fprintf(stderr, "[crct] launching graph\n");
+  if (hipGraphLaunch(exec, stream) != hipSuccess) { crct_set_error("engine: hipGraphLaunch failed"); return 1; }
+  return 0;
+}
+template <class T>
+void key_put(std::vector<char>& k, const T& v) { const char* p = reinterpret_cast<const char*>(&v); k.insert(k.end(), p, p + sizeof(T)); }
+}  // namespace
+
+extern "C" int crct_engine_forward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
+                                   const CrctStepCfg* cfg, void* workspace, float* logits, float* reg, float* stats,
+                                   crct_stream_t stream) {
+  if (!e || !cfg || !batch || !cfg->use_graph)
+    return engine_forward_impl(e, params_f32, params_bf16, batch, cfg, workspace, logits, reg, stats, stream);
+  std::vector<char> key;
+  key_put(key, (int)1); key_put(key, params_f32); key_put(key, params_bf16); key_put(key, *batch); key_put(key, *cfg);
+  key_put(key, workspace); key_put(key, logits); key_put(key, reg); key_put(key, stats);
+  return run_graphed(e, key, (hipStream_t)stream, [&]() {
+    return engine_forward_impl(e, params_f32, params_bf16, batch, cfg, workspace, logits, reg, stats, stream);
+  });
+}
+
+extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
+                                    const CrctStepCfg* cfg, void* workspace, float* grads_f32, float* logits, float* reg,
+                                    float* stats, int seg, crct_stream_t stream) {
+  if (!e || !cfg || !batch || !cfg->use_graph)
+    return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
+  std::vector<char> key;
+  key_put(key, (int)2); key_put(key, params_f32); key_put(key, params_bf16); key_put(key, *batch); key_put(key, *cfg);
+  key_put(key, workspace); key_put(key, grads_f32); key_put(key, logits); key_put(key, reg); key_put(key, stats); key_put(key, seg);
+  return run_graphed(e, key, (hipStream_t)stream, [&]() {
+    return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
+  });
+}
+
+extern "C" int crct_engine_graph_stats(const crct_engine_t* e, int* n_keys, int* n_instantiated, int* broken) {
+  if (!e) return 1;
+  int k = 0, x = 0;
+  for (auto& g : e->graphs) { ++k; if (g.exec) ++x; }
+  if (n_keys) *n_keys = k;
+  if (n_instantiated) *n_instantiated = x;
+  if (broken) *broken = e->graph_broken ? 1 : 0;
+  return 0;
 }
 
 extern "C" int64_t crct_engine_tap(crct_engine_t* e, const void* workspace, const char* name, int B, int T, int V, void* out,

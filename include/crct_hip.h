@@ -243,7 +243,8 @@ typedef struct CrctModelDims {
 typedef struct crct_engine crct_engine_t;
 
 /* names: '\n'-joined parameter keys (reference state_dict names without 'bert_pretrained.'),
- * offsets / sizes: element offset and element count of each in the flat buffers. */
+ * offsets / sizes: element offset and element count of each in the flat buffers; pass size 0 for a tensor
+ * that never receives a gradient (it is then excluded from the backward segments' gradient ranges). */
 crct_engine_t* crct_engine_create(const CrctModelDims* dims, const char* names, const int64_t* offsets,
                                   const int64_t* sizes, int n_params, int max_B, int max_T, int max_V);
 void crct_engine_destroy(crct_engine_t*);
@@ -264,9 +265,11 @@ typedef struct CrctStepCfg {
   int32_t training;          /* dropout on/off */
   int32_t use_l1, kind_l1;
   float tol_margin, nsp_coeff, reg_coeff, grad_scale;
-  uint64_t seed;
+  uint64_t seed;             /* dropout seed: the value, or (1<<63 | device address of a u64 holding it) */
   const float* g_nsp_dev;    /* optional upstream gradients from autograd (device) */
   const float* g_reg_dev;
+  int32_t use_graph;         /* != 0: capture the call into a hipGraph on its 2nd occurrence and replay it afterwards;
+                                every pointer argument (and a memory-resident seed) must then be stable across calls */
 } CrctStepCfg;
 
 int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange (crct/ddp.py) -- bucket planning over
+the engine's backward segments, all-reduce launched as segments finish, 1/world averaging, and the
+reference's 9-float stats all-reduce (train.py:181-189).  The GPU path only swaps the segment runner
+(native backward) and the backend (RCCL)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from crct import config as CFG
+from crct import layout as LY
+from crct.ddp import plan_buckets, reduce_while_running, all_reduce_stats
+
+
+def _segments(cfg, params):
+    """Backward-ordered gradient ranges, as crct_engine_segment_range reports them."""
+    table, _ = LY.parameter_table(cfg, params)
+
+    def rng(prefixes):
+        es = [e for e in table if e.used and any(e.name.startswith(p) for p in prefixes)]
+        return (min(e.offset for e in es), max(e.offset + e.numel for e in es))
+    segs = [rng(["bert.t_pooler.", "bert.v_pooler.", "cls.bi_seq_relationship.", "regressor."])]
+    for kind, i in reversed(LY.encoder_schedule(cfg)):
+        segs.append(rng([{"t": "bert.encoder.layer.%d.", "v": "bert.encoder.v_layer.%d.", "c": "bert.encoder.c_layer.%d."}[kind] % i]))
+    segs.append(rng(["bert.embeddings.", "bert.v_embeddings."]))
+    return segs, table
+
+
+def test_bucket_plan_covers_every_used_gradient_once():
+    cfg, params = CFG.vilbert_config(), CFG.default_params()
+    segs, table = _segments(cfg, params)
+    assert len(segs) == 26
+    # backward order = descending offsets, contiguous ranges that do not overlap
+    for (lo0, hi0), (lo1, hi1) in zip(segs, segs[1:]):
+        assert hi1 <= lo0
+    buckets = plan_buckets(segs, 64 * (1 << 20) // 4)
+    assert 8 <= len(buckets) <= 20
+    covered = torch.zeros(max(hi for _, hi in segs), dtype=torch.int8)
+    for _, lo, hi in buckets:
+        covered[lo:hi] += 1
+    assert int(covered.max()) == 1
+    for e in table:
+        c = covered[e.offset:e.offset + e.numel]
+        if e.used:
+            assert c.numel() == e.numel and bool((c == 1).all()), e.name
+        else:
+            assert not bool((c == 1).any()), e.name
+    # a bucket becomes ready exactly when its last segment has run
+    assert [b[0] for b in buckets] == sorted(b[0] for b in buckets) and buckets[-1][0] == len(segs) - 1
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, params = CFG.tiny_config(), CFG.default_params(categories=9)
+    segs, table = _segments(cfg, params)
+    total = max(hi for _, hi in segs)
+    flat = torch.zeros(total)
+    order = []
+
+    def run_segment(i):                       # stand-in for crct_engine_backward(seg=i): local grads scaled by 1/world
+        lo, hi = segs[i]
+        flat[lo:hi] += (rank + 1.0) * (i + 1) / world
+        order.append(i)
+
+    buckets = plan_buckets(segs, 200000)
+    reduce_while_running(flat, segs, buckets, run_segment)
+    ok = order == list(range(len(segs)))
+    for i, (lo, hi) in enumerate(segs):       # SUM of (r+1)(i+1)/world over ranks = (i+1) * mean(r+1)
+        ok = ok and bool(torch.allclose(flat[lo:hi], torch.full((hi - lo,), (i + 1) * (world + 1) / 2.0)))
+    stats = torch.tensor([1.0 + rank, 2, 3, 4, 5, 6, 7 + rank, 8, 9])
+    all_reduce_stats(stats, world)
+    ok = ok and bool(torch.allclose(stats, torch.tensor([1.5, 2, 3, 4, 5, 6, 15.0, 16, 18])))
+    q.put((rank, ok, len(buckets)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_over_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] >= 2
