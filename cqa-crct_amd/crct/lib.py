@@ -84,6 +84,8 @@ PROTOTYPES = {
     "crct_engine_segment_range": (C.c_int, [vp, C.c_int, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "crct_engine_forward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp]),
     "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
+    "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
+    "crct_engine_graph_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crct_engine_tap": (c_i64, [vp, vp, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),
 }
 

@@ -112,7 +112,7 @@ struct crct_engine {
   size_t ws_bytes = 0;
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
-  bool use_vis_stream = true, use_wgrad_stream = true;
+  bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
   std::vector<hipEvent_t> evpool;
   size_t evnext = 0;
@@ -367,6 +367,11 @@ struct Run {
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
     V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
     proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, Mt, drop(D.p_hidden, p.site + 3));       // dctx1 [Mt,Hb]
+    // each attention backward also writes into the OTHER stream's dqkv scratch, which that stream's previous
+    // layer (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading: both data
+    // streams have waited for their own wgrad stream above, so ordering them against each other closes the hazard
+    if (!rc) fail(order_streams(e, V.s, s));
+    if (!V.rc) V.fail(order_streams(e, s, V.s));
     // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]            (text stream)
     attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
              3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site));
@@ -493,6 +498,10 @@ struct Run {
     const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;
     // the loss kernel is re-run with gradient outputs enabled (cheap: B rows) so that forward can
     // be called alone for evaluation
+    // the head's small GEMM chain recycles two scratch buffers every other call: keep its weight-gradient
+    // GEMMs on this stream (in order) instead of the side stream
+    struct SwGuard { Run* r; hipStream_t keep; ~SwGuard() { r->sw = keep; } } guard{this, sw};
+    sw = s;
     heads_fwd_grad_only(logits, reg, stats);
     if (rc) return;
     if (hipMemsetAsync(A(gt), 0, (size_t)B * b->T * D.H * 2, s) != hipSuccess ||
@@ -760,8 +769,10 @@ namespace {
 
 int ensure_streams(crct_engine* e) {
   static const char* env = getenv("CRCT_STREAMS");      // "0": single stream, "1": visual stream only, default: all
-  if (env && env[0] == '0') { e->use_vis_stream = false; e->use_wgrad_stream = false; }
-  if (env && env[0] == '1') { e->use_wgrad_stream = false; }
+  if (!e->streams_forced) {
+    if (env && env[0] == '0') { e->use_vis_stream = false; e->use_wgrad_stream = false; }
+    if (env && env[0] == '1') { e->use_wgrad_stream = false; }
+  }
   for (int k = 0; k < 3; ++k) {
     const bool need = k == 0 ? e->use_vis_stream : e->use_wgrad_stream;
     if (need && !e->side[k] && hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) {
@@ -941,6 +952,14 @@ extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, c
   return run_graphed(e, key, (hipStream_t)stream, [&]() {
     return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
   });
+}
+
+extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, int use_wgrad_streams) {
+  if (!e) return 1;
+  e->use_vis_stream = use_visual_stream != 0;
+  e->use_wgrad_stream = use_wgrad_streams != 0;
+  e->streams_forced = true;
+  return 0;
 }
 
 extern "C" int crct_engine_graph_stats(const crct_engine_t* e, int* n_keys, int* n_instantiated, int* broken) {

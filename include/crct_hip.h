@@ -283,6 +283,13 @@ int crct_engine_backward(crct_engine_t*, const float* params_f32, const void* pa
                          const CrctBatch* batch, const CrctStepCfg* cfg, void* workspace,
                          float* grads_f32, float* logits, float* reg, float* stats, int seg,
                          crct_stream_t stream);
+/* Internal concurrency (default: both on): the visual stream's layers run on a second HIP stream and all
+ * weight-gradient GEMMs / bias column sums on two more, forked from and joined to `stream` inside every call.
+ * Results do not depend on the setting (tests compare them bit for bit). */
+int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
+/* hipGraph cache counters (experimental graph mode, CrctStepCfg.use_graph). */
+int crct_engine_graph_stats(const crct_engine_t*, int* n_keys, int* n_instantiated, int* broken);
+
 /* Debug taps: copy a named bf16 activation ("emb.t", "t3.t", "c0.v", "seq_t" ...) of the last
  * forward (batch B, T, V) into `out` (device, bf16); returns the element count or -1. */
 int64_t crct_engine_tap(crct_engine_t*, const void* workspace, const char* name, int B, int T, int V,
