@@ -119,6 +119,11 @@ class StepEngine(object):
         else:
             c.seed = int(step["seed"])
         c.g_nsp_dev, c.g_reg_dev = L.ptr(g_nsp), L.ptr(g_reg)
+        evs = step.get("seg_events")
+        if evs is not None:
+            arr = (C.c_void_p * len(evs))(*[ev.cuda_event for ev in evs])
+            step["_seg_events_keepalive"] = arr
+            c.seg_ready_events = C.cast(arr, C.c_void_p)
         return c
 
     def _enter(self, graph):

@@ -80,6 +80,8 @@ class CrctModel(nn.Module):
         self.sync_stats = True                       # reg[3] as python ints (host sync) like the reference
         self.use_graph = False                       # replay the step's ~900 launches from captured hipGraphs
         self._ddp = None
+        self._param_events = None                    # set by FusedAdamW in overlap mode
+        self._opt_stream = None
         self.init_weights(int(params.get("seed", 0)))
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate_shadow())
 
@@ -207,6 +209,8 @@ class CrctModel(nn.Module):
         return self._engine
 
     def _run_backward(self, tensors, step):
+        if self._opt_stream is not None:             # overlapped optimizer update / gradient memset of the previous step
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
         self._ensure_grad_views()
         eng = self._engine
         if self._ddp is None:
@@ -261,7 +265,8 @@ class CrctModel(nn.Module):
         step = dict(training=self.training, use_l1=bool(p["L1"]), kind_l1=(kind == "L1"), tol_margin=float(p["tol_margin"]),
                     nsp_coeff=float(p.get("nsp_loss_coeff", 1.0)), reg_coeff=float(p.get("reg_loss_coeff", 1.0)),
                     seed=(self._seed + self._calls * 7919 + int(p.get("rank", 0)) * 104729) & 0x3FFFFFFFFFFFFFFF,
-                    use_graph=self.use_graph)
+                    use_graph=self.use_graph, seg_events=self._param_events)
+        self._param_events = None
         dev = self._flat_p.device
         if train_branch and torch.is_grad_enabled():
             nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)

@@ -66,7 +66,7 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in g["params"]:
                 if id(p) in ids:
                     self._group_of[ids[id(p)].name] = gi
-        self._segs = [e for e in self._used if e.name in self._group_of]
+        self._segs = sorted([e for e in self._used if e.name in self._group_of], key=lambda e: e.offset)
         to_dev = lambda v, dt: torch.as_tensor(v, dtype=dt).to(dev)   # noqa: E731
         self._seg_off = to_dev([e.offset for e in self._segs], torch.int64)
         self._seg_len = to_dev([e.numel for e in self._segs], torch.int64)
@@ -77,6 +77,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._lr_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
         self._wd_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
         self._last = None
+        # overlap mode: the update runs as one launch per engine backward-segment on its own stream, in first-use
+        # order, each followed by an event; the next forward waits for segment s right before it needs it, so
+        # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
+        self.overlap = False
+        self._opt_stream = None
+        self._seg_blocks = None
+        self._events = None
         # expose the moments the way torch.optim.AdamW does (views of the flat buffers)
         for e in self._segs:
             p = byname[e.name]
@@ -95,25 +102,72 @@ class FusedAdamW(torch.optim.Optimizer):
             self._wd_dev.copy_(self._wd_host, non_blocking=True)
             self._last = key
 
+    def _launch(self, b0, b1, inv_scale, stream):
+        core, g0 = self.core, self.param_groups[0]
+        L.check(L.load().crct_adamw_step(core.flat_params.data_ptr(), core.flat_grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                         core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
+                                         self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr() + 4 * b0,
+                                         self._blk_off.data_ptr() + 8 * b0, b1 - b0, g0["betas"][0], g0["betas"][1], g0["eps"],
+                                         self._step, L.ptr(inv_scale), stream), "adamw_step")
+
+    def _plan_overlap(self):
+        """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
+        eng = self.core._engine
+        if eng is None:
+            return False
+        import bisect
+        blk_seg = self._blk_seg.cpu().tolist()
+        first_blk = {}
+        for i, sgi in enumerate(blk_seg):
+            first_blk.setdefault(sgi, i)
+        offs = [e.offset for e in self._segs]
+        self._seg_blocks = []
+        for lo, hi in eng.segments:
+            s0, s1 = bisect.bisect_left(offs, lo), bisect.bisect_left(offs, hi)
+            b0 = first_blk[s0] if s0 < len(offs) and s0 in first_blk else len(blk_seg)
+            b1 = first_blk[s1] if s1 < len(offs) and s1 in first_blk else len(blk_seg)
+            self._seg_blocks.append((b0, b1))
+        covered = sum(b1 - b0 for b0, b1 in self._seg_blocks)
+        if covered != len(blk_seg):
+            raise RuntimeError("optimizer overlap plan does not cover every block (%d of %d)" % (covered, len(blk_seg)))
+        self._opt_stream = torch.cuda.Stream(device=self.core.flat_params.device)
+        self._events = [torch.cuda.Event() for _ in eng.segments]
+        return True
+
     @torch.no_grad()
     def step(self, closure=None, inv_scale=None):
         loss = closure() if closure is not None else None
         core = self.core
         self._upload_hyper()
         self._step += 1
-        g0 = self.param_groups[0]
-        lib = L.load()
-        L.check(lib.crct_adamw_step(core.flat_params.data_ptr(), core.flat_grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
-                                    core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
-                                    self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr(),
-                                    self._blk_off.data_ptr(), self._blk_seg.numel(), g0["betas"][0], g0["betas"][1], g0["eps"],
-                                    self._step, L.ptr(inv_scale), L.current_stream()), "adamw_step")
+        if self.overlap and (self._seg_blocks is not None or self._plan_overlap()):
+            cur = torch.cuda.current_stream()
+            self._opt_stream.wait_stream(cur)                 # gradients (and the hyper-parameter upload) are final
+            n = len(self._seg_blocks)
+            for sgi in range(n - 1, -1, -1):                  # first-use order: embeddings ... heads
+                b0, b1 = self._seg_blocks[sgi]
+                if b1 > b0:
+                    self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream)
+                self._events[sgi].record(self._opt_stream)
+            core._param_events = self._events                # the next forward waits segment by segment
+            core._opt_stream = self._opt_stream               # ... and the next backward for the whole stream
+        else:
+            self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
         core.note_params_updated_natively()
         return loss
 
+    def synchronize(self):
+        """Order the current stream after an in-flight overlapped update (before reading weights outside forward)."""
+        if self._opt_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+
     def zero_grad(self, set_to_none=True):
         # one memset; .grad views stay attached (set_to_none would only force a re-attach next step)
-        self.core.zero_flat_grads()
+        if self.overlap and self._opt_stream is not None:
+            with torch.cuda.stream(self._opt_stream):        # after the update that is still reading the gradients
+                self.core.zero_flat_grads()
+        else:
+            self.core.zero_flat_grads()
 
     def state_dict(self):
         for st in self.state.values():

@@ -107,7 +107,8 @@ struct crct_engine {
   struct { size_t soft, lin, sum, y, mean, rstd; } eva;
   LinearP t_pool, v_pool, cls, tp[4], vp[4], fu[4];
   struct { size_t pooled_t, pooled_v, t[3], v[3], cat, f[3], scratch, d_pt, d_pv, g[4]; } ha;
-  StreamScratch st, sv;
+  StreamScratch st, sv;          // backward scratch per data stream (dy ping-pong lives in these)
+  StreamScratch st2, sv2;        // second set: layers alternate sets so weight-gradient GEMMs may lag one layer behind
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
   size_t ws_bytes = 0;
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
@@ -203,6 +204,26 @@ struct Run {
   size_t partials, colsum_part, colsum_part_w;
   int rc = 0;
   bool sw_dirty = false;               // sw has work that s has not been ordered after yet (no empty forks / joins)
+  // scratch double-buffering: layer n of this data stream uses scratch set (n & 1); before reusing a set the
+  // data stream waits only for the weight-gradient work of the layer that used it LAST (two layers ago)
+  const StreamScratch* sets[2] = {nullptr, nullptr};
+  hipEvent_t set_free[2] = {nullptr, nullptr};
+  int parity = 0;
+  const StreamScratch& layer_begin() {
+    if (!rc && sw != s && set_free[parity]) {
+      if (hipStreamWaitEvent(s, set_free[parity], 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); rc = 1; }
+      set_free[parity] = nullptr;
+    }
+    return *sets[parity];
+  }
+  void layer_end() {
+    if (!rc && sw != s && sw_dirty) {
+      hipEvent_t ev = ev_new(e);
+      if (!ev || hipEventRecord(ev, sw) != hipSuccess) { crct_set_error("engine: event record failed"); rc = 1; }
+      set_free[parity] = ev;
+    }
+    parity ^= 1;
+  }
   void wgrad_after_main() { if (!rc && sw != s) { fail(order_streams(e, s, sw)); sw_dirty = true; } }     // sw sees what s produced
   void main_after_wgrad() { if (!rc && sw != s && sw_dirty) { fail(order_streams(e, sw, s)); sw_dirty = false; } }   // s may overwrite what sw read
 
@@ -322,10 +343,9 @@ struct Run {
     proj_fwd(p.proj, a.proj, a.ctx, x, M, drop(p.p_hid, p.site + 1));
     ffn_fwd(p.ffn, a.ffn, a.proj.a, M, drop(p.p_hid, p.site + 2));
   }
-  void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc,
-                const uint8_t* km, int B, int T) {
+  void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const uint8_t* km, int B, int T) {
     const int M = B * T, H = p.H, d = H / p.heads;
-    main_after_wgrad();      // the previous layer's weight-gradient GEMMs still read this stream's scratch
+    const StreamScratch& sc = layer_begin();
     ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
     proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, M, drop(p.p_hid, p.site + 1));
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
@@ -334,6 +354,7 @@ struct Run {
     lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M);
     Opt o; o.addend = A(sc.dres_b); o.ld_add = H;
     lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
+    layer_end();
   }
 
   // ---------------------------------------------------------------- connection layer (vilbert.py:774-788)
@@ -359,10 +380,8 @@ struct Run {
   }
   void conn_bwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
     const CrctModelDims& D = e->d;
-    const StreamScratch& sv = e->sv; const StreamScratch& st = e->st;
+    const StreamScratch& sv = V.layer_begin(); const StreamScratch& st = layer_begin();
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
-    V.main_after_wgrad();
-    main_after_wgrad();
     V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
     V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
@@ -389,6 +408,8 @@ struct Run {
     lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt);
     Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
     lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
+    V.layer_end();
+    layer_end();
   }
 
   // ---------------------------------------------------------------- embeddings
@@ -412,7 +433,7 @@ struct Run {
   void embed_text_bwd(size_t gt) {
     const CrctModelDims& D = e->d;
     const Drop dt = drop(D.p_hidden, 1);
-    main_after_wgrad();
+    layer_begin();
     if (!rc) fail(crct_embed_text_bwd(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
                                       P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
                                       G(e->et.ln.g), G(e->et.ln.b), F(partials), b->B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
@@ -422,12 +443,12 @@ struct Run {
     const CrctModelDims& D = e->d;
     const int Mv = b->B * b->V;
     const Drop dv = drop(D.p_hidden, 2);
-    main_after_wgrad();
+    const StreamScratch& sc = layer_begin();
     if (!rc) fail(crct_embed_image_bwd(A(gv), A(e->eva.sum), F(e->eva.mean), F(e->eva.rstd), b->image_loc, b->image_target,
-                                       P(e->ev.ln.g), A(e->sv.gc), G(e->ev.color), G(e->ev.wloc), G(e->ev.bloc), G(e->ev.img.b),
+                                       P(e->ev.ln.g), A(sc.gc), G(e->ev.color), G(e->ev.wloc), G(e->ev.bloc), G(e->ev.img.b),
                                        G(e->ev.ln.g), G(e->ev.ln.b), F(partials), Mv, D.Hv, dv.thr, dv.scale, dv.site,
                                        c->seed, s));
-    lin_wgrad(A(e->sv.gc), D.Hv, A(e->eva.soft), D.Fv, e->ev.img, Mv);   // no dgrad: features are inputs
+    lin_wgrad(A(sc.gc), D.Hv, A(e->eva.soft), D.Fv, e->ev.img, Mv);   // no dgrad: features are inputs
   }
 
   // ---------------------------------------------------------------- heads
@@ -699,6 +720,8 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   }
   e->st = scratch_a(ar, Mt, D.H, D.I, D.Hb);
   e->sv = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
+  e->st2 = scratch_a(ar, Mt, D.H, D.I, D.Hb);
+  e->sv2 = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
   {
     size_t wmax = D.H > D.Hv ? D.H : D.Hv;
     for (int k = 0; k < 2; ++k) e->partials[k] = ar.take((size_t)8 * 256 * wmax * 4);
@@ -791,6 +814,8 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
            e->partials[0], e->colsum_part[0], e->colsum_part[2]};
   Rv = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, vis, batch, cfg, e->use_wgrad_stream ? e->side[2] : vis,
            e->partials[1], e->colsum_part[1], e->colsum_part[3]};
+  Rt.sets[0] = &e->st; Rt.sets[1] = &e->st2;
+  Rv.sets[0] = &e->sv; Rv.sets[1] = &e->sv2;
 }
 
 }  // namespace
@@ -805,15 +830,32 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   Run Rt, Rv;
   make_runs(e, params_f32, params_bf16, nullptr, workspace, (hipStream_t)stream, batch, cfg, Rt, Rv);
   Rv.fail(order_streams(e, Rt.s, Rv.s));                 // fork: the visual stream starts after the caller's prior work
+  // parameters of backward-segment `seg` may still be in the hands of an optimizer update running on another
+  // stream (crct.optim overlap mode): wait for its event right before the first kernel that reads them
+  const int nseg = (int)e->seg_range.size();
+  auto wait_params = [&](Run& R, int seg) {
+    if (!cfg->seg_ready_events || R.rc) return;
+    hipEvent_t ev = (hipEvent_t)cfg->seg_ready_events[seg];
+    if (ev && hipStreamWaitEvent(R.s, ev, 0) != hipSuccess) { crct_set_error("engine: wait on a parameter-ready event failed"); R.rc = 1; }
+  };
+  wait_params(Rt, nseg - 1);
+  wait_params(Rv, nseg - 1);
   Rt.embed_text_fwd();
   Rv.embed_image_fwd();
   size_t xt = e->eta.y, xv = e->eva.y;
+  int step_i = 0;
   for (const Step& st : e->sched) {
+    const int seg = (int)e->sched.size() - step_i;       // backward segment of this schedule step
+    ++step_i;
+    if (st.kind == 't') wait_params(Rt, seg);
+    else if (st.kind == 'v') wait_params(Rv, seg);
+    else { wait_params(Rt, seg); wait_params(Rv, seg); }
     if (st.kind == 't') { Rt.self_fwd(e->tl[st.idx], e->tla[st.idx], xt, batch->text_keymask, batch->B, batch->T); xt = e->tla[st.idx].ffn.y; }
     else if (st.kind == 'v') { Rv.self_fwd(e->vl[st.idx], e->vla[st.idx], xv, batch->image_keymask, batch->B, batch->V); xv = e->vla[st.idx].ffn.y; }
     else { Rt.conn_fwd(Rv, e->cl[st.idx], e->cla[st.idx], xv, xt); xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
   }
   Rt.fail(order_streams(e, Rv.s, Rt.s));                 // join
+  wait_params(Rt, 0);
   Rt.heads_fwd(xt, xv, logits, reg, stats, false);
   return Rt.rc ? Rt.rc : Rv.rc;
 }
@@ -857,10 +899,10 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
       const size_t i = e->sched.size() - (size_t)sgi;
       const Step& st = e->sched[i];
       if (st.kind == 't') {
-        Rt.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], e->st, batch->text_keymask, batch->B, batch->T);
+        Rt.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], batch->text_keymask, batch->B, batch->T);
         e->cur_t ^= 1;
       } else if (st.kind == 'v') {
-        Rv.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], e->sv, batch->image_keymask, batch->B, batch->V);
+        Rv.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], batch->image_keymask, batch->B, batch->V);
         e->cur_v ^= 1;
       } else {
         Rt.conn_bwd(Rv, e->cl[st.idx], e->cla[st.idx], in_v[i], in_t[i], e->sv.dy[e->cur_v], e->st.dy[e->cur_t], e->sv.dy[e->cur_v ^ 1], e->st.dy[e->cur_t ^ 1]);

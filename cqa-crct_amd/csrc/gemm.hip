@@ -18,6 +18,8 @@
 // [k][row], and read with ds_read_b64_tr_b16 (gfx950 transposed LDS read) from the 8x32-subtile
 // image of cdna_hip_programming.md T10(a) -- no transposed copies of weights or activations
 // exist anywhere in HBM.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.cuh"
@@ -438,10 +440,21 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 // CRCT shapes (profiles/gemm_lab_r1.txt): every GEMM here is a 1-2 wave problem whose time is set by
 // L2->LDS traffic and prefetch latency, so 8-wave workgroups with 2 resident per CU win.
 //   12: 128x64, 8 waves (4x2), 2 stages    11: 64x128, 8 waves, 3 stages    3: 64x64, 4 waves, 4 stages
+static int env_cfg(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
 static int pick_pipe_config(const CrctGemmArgs& g) {
+  // developer overrides for A/B runs of the whole step: CRCT_GEMM_FWD / _DGRAD / _WGRAD = configuration id
+  static const int ov_f = env_cfg("CRCT_GEMM_FWD"), ov_d = env_cfg("CRCT_GEMM_DGRAD"), ov_w = env_cfg("CRCT_GEMM_WGRAD");
   if (g.M <= 96) return 3;                                          // head / regressor GEMMs: B rows
-  if (g.ta) return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 12;     // wgrad
-  if (g.N <= 1024 && g.K >= 2048) return g.tb ? 3 : 11;             // narrow output, long K
+  if (g.ta) {                                                       // wgrad
+    if (ov_w >= 0) return ov_w;
+    return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 9;
+  }
+  if (g.tb) {
+    if (ov_d >= 0) return ov_d;
+    return 12;
+  }
+  if (ov_f >= 0) return ov_f;
+  if (g.N <= 1024 && g.K >= 2048) return 11;                        // narrow output, long K
   return 12;
 }
 

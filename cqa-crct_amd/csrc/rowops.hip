@@ -326,19 +326,36 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const FinalizeAr
 
 // ------------------------------------------------------------------------------ column sum
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ partials, int M, int N) {
-  // block handles a strip of rows; thread handles column pairs
+  // strip blockIdx.y owns rows y, y + nb, y + 2 nb, ...; a thread owns 4 columns (8-byte loads), 4 rows in flight
   const int nb = gridDim.y;
-  const int rows_per = (M + nb - 1) / nb;
-  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= N) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (long)r * ld + c);
-    s0 += bf2f((bf16_t)(u & 0xffff)); s1 += bf2f((bf16_t)(u >> 16));
+  float s[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[u][j] = 0.f;
+  const bf16_t* p = x + c;
+  int r = blockIdx.y;
+  for (; r + 3 * nb < M; r += 4 * nb) {
+    uint2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint2*>(p + (long)(r + u * nb) * ld);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[u][0] += bf2f((bf16_t)(v[u].x & 0xffff)); s[u][1] += bf2f((bf16_t)(v[u].x >> 16));
+      s[u][2] += bf2f((bf16_t)(v[u].y & 0xffff)); s[u][3] += bf2f((bf16_t)(v[u].y >> 16));
+    }
   }
-  partials[(long)blockIdx.y * N + c] = s0;
-  partials[(long)blockIdx.y * N + c + 1] = s1;
+  for (; r < M; r += nb) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + (long)r * ld);
+    s[0][0] += bf2f((bf16_t)(v.x & 0xffff)); s[0][1] += bf2f((bf16_t)(v.x >> 16));
+    s[0][2] += bf2f((bf16_t)(v.y & 0xffff)); s[0][3] += bf2f((bf16_t)(v.y >> 16));
+  }
+  float4 o;
+  o.x = (s[0][0] + s[1][0]) + (s[2][0] + s[3][0]); o.y = (s[0][1] + s[1][1]) + (s[2][1] + s[3][1]);
+  o.z = (s[0][2] + s[1][2]) + (s[2][2] + s[3][2]); o.w = (s[0][3] + s[1][3]) + (s[2][3] + s[3][3]);
+  *reinterpret_cast<float4*>(partials + (long)blockIdx.y * N + c) = o;
 }
 
 // ------------------------------------------------------------------------------ row softmax f32 -> bf16
@@ -592,15 +609,15 @@ int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const f
   return launch_finalize(fa, s);
 }
 
-int crct_colsum_blocks(int M) { int b = (M + 31) / 32; return b < 1 ? 1 : (b > 64 ? 64 : b); }
+int crct_colsum_blocks(int M) { int b = (M + 7) / 8; return b < 1 ? 1 : (b > 64 ? 64 : b); }
 
 int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int M, int N, int accumulate,
                      crct_stream_t stream) {
-  CRCT_REQUIRE(N % 2 == 0 && ld % 2 == 0, "colsum: N=%d and ld must be even", N);
+  CRCT_REQUIRE(N % 4 == 0 && ld % 4 == 0, "colsum: N=%d and ld must be multiples of 4", N);
   if (N <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int nb = crct_colsum_blocks(M);
-  hipLaunchKernelGGL(colsum_kernel, dim3((N / 2 + 255) / 256, nb), dim3(256), 0, s, (const bf16_t*)x, (long)ld, partials, M, N);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + 255) / 256, nb), dim3(256), 0, s, (const bf16_t*)x, (long)ld, partials, M, N);
   CRCT_CHECK_HIP(hipGetLastError());
   FinalizeArgs fa = {};
   fa.out[0] = out; fa.stride[0] = 1; fa.Q = 1; fa.nblk = nb; fa.H = N; fa.accumulate = accumulate; fa.partials = partials;

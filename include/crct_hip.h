@@ -268,6 +268,9 @@ typedef struct CrctStepCfg {
   uint64_t seed;             /* dropout seed: the value, or (1<<63 | device address of a u64 holding it) */
   const float* g_nsp_dev;    /* optional upstream gradients from autograd (device) */
   const float* g_reg_dev;
+  const void* const* seg_ready_events;   /* optional HOST array [crct_engine_num_segments] of hipEvent_t (or NULL entries):
+                                forward makes the stream(s) of the layers of segment s wait for event s before they run --
+                                lets a per-segment optimizer update of step n overlap the forward of step n+1 */
   int32_t use_graph;         /* != 0: capture the call into a hipGraph on its 2nd occurrence and replay it afterwards;
                                 every pointer argument (and a memory-resident seed) must then be stable across calls */
 } CrctStepCfg;
