@@ -22,53 +22,69 @@ struct AttnArgs {
   float scale;
 };
 
-// cooperative load of rows [T][d] (bf16, row stride ld) into LDS fp32 [T][d+1]
+// LDS tiles: fp32 [T4][st], st = d + 4 floats (rows 16-byte aligned; 16 consecutive rows land on 16 distinct
+// 16-byte bank slots for d = 32 / 48 / 64), T4 = T rounded up to 4 with the padding rows zero-filled, so that
+// every inner loop runs in steps of 4 with vector LDS reads and no tail.
+__device__ __forceinline__ int up4(int v) { return (v + 3) & ~3; }
+
+// cooperative load of rows [T][d] (bf16, row stride ld) into the LDS tile; rows T..T4-1 are zeroed
 __device__ __forceinline__ void load_tile(float* dst, const bf16_t* src, long ld, int T, int d, int tid) {
-  const int cpr = d >> 3;   // 16-byte chunks per row
-  for (int c = tid; c < T * cpr; c += 256) {
+  const int cpr = d >> 3, st = d + 4, T4 = up4(T);
+  for (int c = tid; c < T4 * cpr; c += 256) {
     const int r = c / cpr, cc = (c % cpr) << 3;
-    const uint4 u = *reinterpret_cast<const uint4*>(src + (long)r * ld + cc);
-    float* o = dst + r * (d + 1) + cc;
-    o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16));
-    o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16));
-    o[4] = bf2f((bf16_t)(u.z & 0xffff)); o[5] = bf2f((bf16_t)(u.z >> 16));
-    o[6] = bf2f((bf16_t)(u.w & 0xffff)); o[7] = bf2f((bf16_t)(u.w >> 16));
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (r < T) {
+      const uint4 u = *reinterpret_cast<const uint4*>(src + (long)r * ld + cc);
+      lo = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+      hi = make_float4(bf2f((bf16_t)(u.z & 0xffff)), bf2f((bf16_t)(u.z >> 16)), bf2f((bf16_t)(u.w & 0xffff)), bf2f((bf16_t)(u.w >> 16)));
+    }
+    float* o = dst + r * st + cc;
+    *reinterpret_cast<float4*>(o) = lo;
+    *reinterpret_cast<float4*>(o + 4) = hi;
   }
 }
-// cooperative store LDS fp32 [T][d+1] * mul -> bf16 rows
+// cooperative store LDS tile * mul -> bf16 rows
 __device__ __forceinline__ void store_tile(bf16_t* dst, long ld, const float* src, int T, int d, int tid, float mul) {
-  const int cpr = d >> 3;
+  const int cpr = d >> 3, st = d + 4;
   for (int c = tid; c < T * cpr; c += 256) {
     const int r = c / cpr, cc = (c % cpr) << 3;
-    const float* s = src + r * (d + 1) + cc;
+    const float4 lo = *reinterpret_cast<const float4*>(src + r * st + cc), hi = *reinterpret_cast<const float4*>(src + r * st + cc + 4);
     uint4 u;
-    u.x = pack2bf(s[0] * mul, s[1] * mul); u.y = pack2bf(s[2] * mul, s[3] * mul);
-    u.z = pack2bf(s[4] * mul, s[5] * mul); u.w = pack2bf(s[6] * mul, s[7] * mul);
+    u.x = pack2bf(lo.x * mul, lo.y * mul); u.y = pack2bf(lo.z * mul, lo.w * mul);
+    u.z = pack2bf(hi.x * mul, hi.y * mul); u.w = pack2bf(hi.z * mul, hi.w * mul);
     *reinterpret_cast<uint4*>(dst + (long)r * ld + cc) = u;
   }
 }
 
-// C[i][j] = sum_c X[i][c] * Y[j][c]   (X: [TX][d+1], Y: [TY][d+1]) -> out[i*ldo + j]
-// 16x16 thread grid, each thread owns an AX x AY register tile (rows ty+16a, cols tx+16b).
+// C[i][j] = sum_c X[i][c] * Y[j][c] -> out[i*ldo + j].  16x16 thread grid, AX x AY register tile per thread
+// (rows ty + 16a, cols tx + 16b); the contraction runs 4 wide on float4 LDS reads, two steps in flight.
 template <int AX, int AY>
 __device__ __forceinline__ void mm_nt(float* out, int ldo, const float* X, const float* Y, int TX, int TY, int d, int tid) {
-  const int ty = tid >> 4, tx = tid & 15;
+  const int ty = tid >> 4, tx = tid & 15, st = d + 4;
+  const int TX4 = up4(TX), TY4 = up4(TY);
+  const float* xp[AX];
+  const float* yp[AY];
+#pragma unroll
+  for (int a = 0; a < AX; ++a) xp[a] = X + min(ty + 16 * a, TX4 - 1) * st;
+#pragma unroll
+  for (int b = 0; b < AY; ++b) yp[b] = Y + min(tx + 16 * b, TY4 - 1) * st;
   float acc[AX][AY];
 #pragma unroll
   for (int a = 0; a < AX; ++a)
 #pragma unroll
     for (int b = 0; b < AY; ++b) acc[a][b] = 0.f;
-  const int st = d + 1;
-  for (int c = 0; c < d; ++c) {
-    float xv[AX], yv[AY];
+#pragma unroll 2
+  for (int c = 0; c < d; c += 4) {
+    float4 xv[AX], yv[AY];
 #pragma unroll
-    for (int a = 0; a < AX; ++a) { const int i = ty + 16 * a; xv[a] = i < TX ? X[i * st + c] : 0.f; }
+    for (int a = 0; a < AX; ++a) xv[a] = *reinterpret_cast<const float4*>(xp[a] + c);
 #pragma unroll
-    for (int b = 0; b < AY; ++b) { const int j = tx + 16 * b; yv[b] = j < TY ? Y[j * st + c] : 0.f; }
+    for (int b = 0; b < AY; ++b) yv[b] = *reinterpret_cast<const float4*>(yp[b] + c);
 #pragma unroll
     for (int a = 0; a < AX; ++a)
 #pragma unroll
-      for (int b = 0; b < AY; ++b) acc[a][b] += xv[a] * yv[b];
+      for (int b = 0; b < AY; ++b)
+        acc[a][b] += xv[a].x * yv[b].x + xv[a].y * yv[b].y + xv[a].z * yv[b].z + xv[a].w * yv[b].w;
   }
 #pragma unroll
   for (int a = 0; a < AX; ++a)
@@ -79,26 +95,36 @@ __device__ __forceinline__ void mm_nt(float* out, int ldo, const float* X, const
     }
 }
 
-// O[i][c] = sum_j P[i][j] * Y[j][c]    (P: [TX][ldp], Y: [TJ][d+1]) -> out [TX][d+1];  c = tx + 16 b, b < d/16
+// O[i][c] = sum_j P[i][j] * Y[j][c]  (P: [TX4][ldp], columns >= TJ zero; Y: [TJ4][st], rows >= TJ zero) -> out tile
 template <int AX>
 __device__ __forceinline__ void mm_nn(float* out, const float* P, int ldp, const float* Y, int TX, int TJ, int d, int tid) {
-  const int ty = tid >> 4, tx = tid & 15;
+  const int ty = tid >> 4, tx = tid & 15, st = d + 4;
+  const int TX4 = up4(TX), TJ4 = up4(TJ);
+  const float* pp[AX];
+  int cb[4];
+#pragma unroll
+  for (int a = 0; a < AX; ++a) pp[a] = P + min(ty + 16 * a, TX4 - 1) * ldp;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cb[b] = min(tx + 16 * b, d - 1);
   float acc[AX][4];
 #pragma unroll
   for (int a = 0; a < AX; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  const int st = d + 1;
-  for (int j = 0; j < TJ; ++j) {
-    float pv[AX], yv[4];
+  for (int j = 0; j < TJ4; j += 4) {
+    float4 pv[AX];
+    float yv[4][4];
 #pragma unroll
-    for (int a = 0; a < AX; ++a) { const int i = ty + 16 * a; pv[a] = i < TX ? P[i * ldp + j] : 0.f; }
+    for (int a = 0; a < AX; ++a) pv[a] = *reinterpret_cast<const float4*>(pp[a] + j);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const int c = tx + 16 * b; yv[b] = c < d ? Y[j * st + c] : 0.f; }
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) yv[jj][b] = Y[(j + jj) * st + cb[b]];
 #pragma unroll
     for (int a = 0; a < AX; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] += pv[a] * yv[b];
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] += pv[a].x * yv[0][b] + pv[a].y * yv[1][b] + pv[a].z * yv[2][b] + pv[a].w * yv[3][b];
   }
 #pragma unroll
   for (int a = 0; a < AX; ++a)
@@ -109,26 +135,35 @@ __device__ __forceinline__ void mm_nn(float* out, const float* P, int ldp, const
     }
 }
 
-// O[j][c] = sum_i P[i][j] * Y[i][c]    (contraction over the ROWS of P) -> out [TJ][d+1]
+// O[j][c] = sum_i P[i][j] * Y[i][c]  (contraction over the ROWS of P; rows >= TI of P and Y are zero) -> out tile
 template <int AJ>
-__device__ __forceinline__ void mm_tn(float* out, const float* P, int ldp, const float* Y, int TI, int TJ, int d, int tid, bool absval) {
-  const int ty = tid >> 4, tx = tid & 15;
+__device__ __forceinline__ void mm_tn(float* out, const float* P, int ldp, const float* Y, int TI, int TJ, int d, int tid) {
+  const int ty = tid >> 4, tx = tid & 15, st = d + 4;
+  const int TI4 = up4(TI);
+  int ja[AJ], cb[4];
+#pragma unroll
+  for (int a = 0; a < AJ; ++a) ja[a] = min(ty + 16 * a, ldp - 1);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cb[b] = min(tx + 16 * b, d - 1);
   float acc[AJ][4];
 #pragma unroll
   for (int a = 0; a < AJ; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  const int st = d + 1;
-  for (int i = 0; i < TI; ++i) {
-    float pv[AJ], yv[4];
+  for (int i = 0; i < TI4; i += 4) {
+    float pv[4][AJ], yv[4][4];
 #pragma unroll
-    for (int a = 0; a < AJ; ++a) { const int j = ty + 16 * a; pv[a] = j < TJ ? P[i * ldp + j] : 0.f; }
+    for (int ii = 0; ii < 4; ++ii) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const int c = tx + 16 * b; yv[b] = c < d ? Y[i * st + c] : 0.f; }
+      for (int a = 0; a < AJ; ++a) pv[ii][a] = P[(i + ii) * ldp + ja[a]];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) yv[ii][b] = Y[(i + ii) * st + cb[b]];
+    }
 #pragma unroll
     for (int a = 0; a < AJ; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] += pv[a] * yv[b];
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] += pv[0][a] * yv[0][b] + pv[1][a] * yv[1][b] + pv[2][a] * yv[2][b] + pv[3][a] * yv[3][b];
   }
 #pragma unroll
   for (int a = 0; a < AJ; ++a)
@@ -170,8 +205,8 @@ __device__ __forceinline__ void softmax_rows(float* S, int ldS, const uint8_t* k
       if (mode == 0) { p0 = k0 ? p0 * dscale : 0.f; p1 = k1 ? p1 * dscale : 0.f; }
       else { p0 = k0 ? p0 : -p0; p1 = k1 ? p1 : -p1; }
     }
-    if (j0 < Tk) row[j0] = p0;
-    if (j1 < Tk) row[j1] = p1;
+    if (j0 < ldS) row[j0] = j0 < Tk ? p0 : 0.f;      // columns Tk..ldS-1 are padding for the 4-wide loops
+    if (j1 < ldS) row[j1] = j1 < Tk ? p1 : 0.f;
   }
 }
 
@@ -180,11 +215,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-  const int d = a.d, st = d + 1, ldS = a.Tk + 1;
+  const int d = a.d, st = d + 4, ldS = up4(a.Tk), Tq4 = up4(a.Tq), Tk4 = up4(a.Tk);
   float* Q = reinterpret_cast<float*>(smem);
-  float* K = Q + a.Tq * st;
-  float* V = K + a.Tk * st;
-  float* S = V + a.Tk * st;
+  float* K = Q + Tq4 * st;
+  float* V = K + Tk4 * st;
+  float* S = V + Tk4 * st;
   load_tile(Q, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, d, tid);
   load_tile(K, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, d, tid);
   load_tile(V, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, d, tid);
@@ -203,13 +238,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-  const int d = a.d, st = d + 1, ldS = a.Tk + 1;
-  const int Tmax = a.Tq > a.Tk ? a.Tq : a.Tk;
+  const int d = a.d, st = d + 4, ldS = up4(a.Tk), Tq4 = up4(a.Tq);
+  const int Tmax4 = up4(a.Tq > a.Tk ? a.Tq : a.Tk);
   float* X = reinterpret_cast<float*>(smem);      // operand buffer 1: Q, then dO, then Q again
-  float* Y = X + Tmax * st;                       // operand buffer 2: K, then V, then K again
-  float* Pm = Y + Tmax * st;                      // +-P  (sign = dropout keep mask)
-  float* dS = Pm + a.Tq * ldS;                    // dP, then dS
-  float* O = dS + a.Tq * ldS;                     // output staging [Tmax][d+1]
+  float* Y = X + Tmax4 * st;                      // operand buffer 2: K, then V, then K again
+  float* O = Y + Tmax4 * st;                      // output staging tile
+  float* Pm = O + Tmax4 * st;                     // +-P  (sign = dropout keep mask)
+  float* dS = Pm + Tq4 * ldS;                     // dP, then dS
+  for (int i = a.Tq * ldS + tid; i < Tq4 * ldS; i += 256) { Pm[i] = 0.f; dS[i] = 0.f; }   // padding rows of the score tiles
   const bf16_t* qg = a.q + (long)b * a.Tq * a.ldq + h * d;
   const bf16_t* kg = a.k + (long)b * a.Tk * a.ldk + h * d;
   const bf16_t* vg = a.v + (long)b * a.Tk * a.ldv + h * d;
@@ -241,13 +277,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
       p0 = fabsf(p0); p1 = fabsf(p1);
       g0 = k0 ? g0 * ds : 0.f; g1 = k1 ? g1 * ds : 0.f;          // gradient w.r.t. P (through dropout)
       const float delta = wave_sum(g0 * p0 + g1 * p1);
-      if (j0 < a.Tk) { gr[j0] = p0 * (g0 - delta); pr[j0] = k0 ? p0 * ds : 0.f; }
-      if (j1 < a.Tk) { gr[j1] = p1 * (g1 - delta); pr[j1] = k1 ? p1 * ds : 0.f; }
+      if (j0 < ldS) { gr[j0] = j0 < a.Tk ? p0 * (g0 - delta) : 0.f; pr[j0] = (j0 < a.Tk && k0) ? p0 * ds : 0.f; }
+      if (j1 < ldS) { gr[j1] = j1 < a.Tk ? p1 * (g1 - delta) : 0.f; pr[j1] = (j1 < a.Tk && k1) ? p1 * ds : 0.f; }
     }
   }
   __syncthreads();
   // dV[j][c] = sum_i Pd[i][j] dO[i][c]
-  mm_tn<AK>(O, Pm, ldS, X, a.Tq, a.Tk, d, tid, false);
+  mm_tn<AK>(O, Pm, ldS, X, a.Tq, a.Tk, d, tid);
   __syncthreads();
   store_tile(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, O, a.Tk, d, tid, 1.0f);
   // ---- phase e: dQ = dS k * scale ; dK = dS^T q * scale
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   __syncthreads();
   store_tile(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, O, a.Tq, d, tid, a.scale);
   __syncthreads();
-  mm_tn<AK>(O, dS, ldS, X, a.Tq, a.Tk, d, tid, false);
+  mm_tn<AK>(O, dS, ldS, X, a.Tq, a.Tk, d, tid);
   __syncthreads();
   store_tile(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, O, a.Tk, d, tid, a.scale);
 }
@@ -307,7 +343,8 @@ extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, c
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
-  const size_t lds = sizeof(float) * ((size_t)(Tq + 2 * Tk) * (d + 1) + (size_t)Tq * (Tk + 1));
+  const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3;
+  const size_t lds = sizeof(float) * ((size_t)(Tq4 + 2 * Tk4) * (d + 4) + (size_t)Tq4 * Tk4);
   CRCT_CHECK_HIP(dispatch<false>(a, lds, (hipStream_t)stream));
   return 0;
 }
@@ -326,8 +363,8 @@ extern "C" int crct_attention_bwd(const void* q, const void* k, const void* v, c
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
-  const int Tmax = Tq > Tk ? Tq : Tk;
-  const size_t lds = sizeof(float) * ((size_t)3 * Tmax * (d + 1) + (size_t)2 * Tq * (Tk + 1));
+  const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3, Tmax4 = Tq4 > Tk4 ? Tq4 : Tk4;
+  const size_t lds = sizeof(float) * ((size_t)3 * Tmax4 * (d + 4) + (size_t)2 * Tq4 * Tk4);
   CRCT_REQUIRE(lds <= 160 * 1024, "attention_bwd: Tq=%d Tk=%d d=%d needs %zu B of LDS (> 160 KiB)", Tq, Tk, d, lds);
   CRCT_CHECK_HIP(dispatch<true>(a, lds, (hipStream_t)stream));
   return 0;

@@ -100,7 +100,7 @@ struct Stage {
 // private 4 MiB L2).  The tile grid is cut into gm x gn = 8 rectangles, one per XCD, chosen so that
 // the A' and B' panels one XCD touches (rm*BM + rn*BN rows of K) are as few as possible and stay
 // L2-resident; block j of XCD x takes the j-th tile of rectangle x.  Placement only affects speed.
-struct TileMap { int tiles_m, tiles_n, gn, rm, rn; };
+struct TileMap { int tiles_m, tiles_n, gn, rm, rn, dbg; };   // dbg: developer ablation bits (tools/gemm_lab), 0 in production
 
 __device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int& tn) {
   const int x = bid & 7, j = bid >> 3;
@@ -127,6 +127,8 @@ inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid) {
   t.gn = 8 / bgm;
   t.rm = (t.tiles_m + bgm - 1) / bgm; t.rn = (t.tiles_n + t.gn - 1) / t.gn;
   *grid = 8 * t.rm * t.rn;
+  static const int dbg = getenv("CRCT_GEMM_DBG") ? atoi(getenv("CRCT_GEMM_DBG")) : 0;
+  t.dbg = dbg;
   return t;
 }
 
@@ -258,6 +260,106 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g, const T
   gemm_epilogue<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane);
 }
 
+// ------------------------------------------------------------------ LDS-staged epilogue (pipelined kernel)
+// The MFMA accumulator layout gives a lane 4 consecutive columns of ONE row, so storing straight from
+// registers issues 8-byte accesses scattered over 16 rows per instruction (measured: 5 of 17 us on the
+// text FFN-up GEMM).  Instead each wave row-group parks its fp32 accumulators in the (now idle) operand
+// ring, and all threads walk the tile as (row, 8-column chunk): every global access of the epilogue --
+// bias, saved pre-activation, activation-derivative source, residual / upstream-gradient addend, fp32
+// accumulate and the output itself -- is then 16 bytes per lane, consecutive lanes on consecutive chunks
+// of a row (full 128-byte row segments).  Same arithmetic, same Philox element indexing as gemm_epilogue.
+template <int BM, int BN, int WM, int WN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
+                                                     int wm, int wn, int lane, int tid) {
+  constexpr int R = BM / WM;                 // rows staged per pass (one wave-row of the wave grid)
+  constexpr int LDC = BN + 4;                // floats; 16-byte aligned rows, +4 breaks the power-of-two stride
+  constexpr int CPR = BN / 8;                // 8-column chunks per row
+  constexpr int NT = WM * WN * 64;
+  float* ct = reinterpret_cast<float*>(smem);
+  const float* bias = g.bias;
+  const uint32_t thr = g.drop_thr;
+  const float dscale = g.drop_scale;
+  __syncthreads();                           // every wave is done reading the operand ring
+#pragma unroll 1
+  for (int pass = 0; pass < WM; ++pass) {
+    if (wm == pass) {
+#pragma unroll
+      for (int b = 0; b < WTM; ++b)
+#pragma unroll
+        for (int a = 0; a < WTN; ++a) {
+          const int r = b * 16 + (lane & 15), c = wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
+          *reinterpret_cast<f4_t*>(ct + r * LDC + c) = acc[a][b];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < R * CPR; idx += NT) {
+      const int r = idx / CPR, ch = idx % CPR;
+      const int m = m0 + pass * R + r, n = n0 + ch * 8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(ct + r * LDC + ch * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(ct + r * LDC + ch * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (g.alpha != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= g.alpha;
+      }
+      if (bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (g.preact_out) {
+        const uint4 pk = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.preact_out) + (long)m * g.ld_aux + n) = pk;
+      }
+      if (g.act != ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_apply(g.act, v[j]);
+      }
+      if (g.dact_src) {
+        const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.dact_src) + (long)m * g.ld_aux + n);
+        const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] *= act_grad(g.dact, bf2f((bf16_t)(w[j] & 0xffff)));
+          v[2 * j + 1] *= act_grad(g.dact, bf2f((bf16_t)(w[j] >> 16)));
+        }
+      }
+      if (thr) {
+        const uint64_t i4 = ((uint64_t)m * (uint64_t)g.N + (uint64_t)n) >> 2;
+        const Philox4 r0 = philox4x32_10(g.seed, g.drop_site, i4), r1 = philox4x32_10(g.seed, g.drop_site, i4 + 1);
+        const uint32_t u[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = u[j] >= thr ? v[j] * dscale : 0.f;
+      }
+      if (g.addend) {
+        const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.addend) + (long)m * g.ld_add + n);
+        const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16)); }
+      }
+      if (g.c_is_f32) {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n);
+        float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+        if (g.accumulate) {
+          const float4 p0 = dst[0], p1 = dst[1];
+          o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        }
+        dst[0] = o0; dst[1] = o1;
+      } else {
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n);
+        if (g.accumulate) {
+          const uint4 sv = *dst;
+          const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16)); }
+        }
+        *dst = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+      }
+    }
+    if (pass + 1 < WM) __syncthreads();      // the staging tile is rewritten by the next wave row
+  }
+}
+
 // ====================================================================================== pipelined
 // LDS-DMA variant (K % 64 == 0): operand tiles go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds
 // (no VGPR staging, no ds_write), NS stages deep, ONE raw s_barrier per K-step and a counted
@@ -355,7 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
+    if (kt + NS - 1 < nk && !(tmap.dbg & 2)) issue(kt + NS - 1, st_next);
     const char* ldsA = smem + st * STAGE;
     const char* ldsB = ldsA + A_BYTES;
 #pragma unroll
@@ -374,7 +476,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
   }
-  gemm_epilogue<WTM, WTN>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+  if (tmap.dbg & 1) {      // ablation: keep the accumulators alive, skip the epilogue
+#pragma unroll
+    for (int a = 0; a < WTN; ++a)
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) asm volatile("" ::"v"(acc[a][b]));
+    return;
+  }
+  static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "staging tile must fit into the operand ring");
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -406,6 +516,9 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
 // the DMA path needs whole K tiles, 32-bit source offsets, and 16-byte aligned rows
 inline bool pipe_ok(const CrctGemmArgs& g) {
   if (g.K % BK != 0 || g.K < BK) return false;
+  if (g.N % 8 != 0 || g.ldc % 8 != 0) return false;                       // 16-byte epilogue accesses
+  if ((g.preact_out || g.dact_src) && g.ld_aux % 8 != 0) return false;
+  if (g.addend && g.ld_add % 8 != 0) return false;
   const long spanA = g.ta ? (long)g.K * g.lda : (long)g.M * g.lda;
   const long spanB = g.tb ? (long)g.K * g.ldb : (long)g.N * g.ldb;
   return spanA * 2 < 0x7f000000L && spanB * 2 < 0x7f000000L;
@@ -529,7 +642,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       case 4: e = launch_pipe<4, 4, 2, 4, 3>(g, s); break;     // 128x128, 8 waves
       case 5: e = launch_pipe<4, 8, 2, 4, 3>(g, s); break;     // 128x256, 8 waves
       case 6: e = launch_pipe<8, 4, 4, 2, 3>(g, s); break;     // 256x128, 8 waves
-      case 7: e = launch_pipe<8, 8, 2, 4, 2>(g, s); break;     // 256x256, 8 waves, 2 stages
+      case 7: e = launch_pipe<8, 4, 4, 2, 2>(g, s); break;     // 256x128, 8 waves, 2 stages
       case 8: e = launch_pipe<4, 4, 2, 4, 4>(g, s); break;     // 128x128, 8 waves, 4 stages
       case 9: e = launch_pipe<4, 4, 2, 4, 2>(g, s); break;     // 128x128, 8 waves, 2 stages (2 blocks / CU)
       case 10: e = launch_pipe<4, 2, 2, 4, 3>(g, s); break;    // 128x64, 8 waves
