@@ -64,6 +64,8 @@ PROTOTYPES = {
     "crct_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp]),
     "crct_layernorm_bwd_blocks": (C.c_int, [C.c_int]),
     "crct_layernorm_bwd": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, c_u32, c_f32, c_u32, c_u32, c_f32, c_u32, c_u64, vp]),
+    "crct_layernorm_bwd_rows": (C.c_int, [vp] * 8 + [C.c_int, C.c_int, c_u32, c_f32, c_u32, c_u32, c_f32, c_u32, c_u64, vp]),
+    "crct_layernorm_bwd_finalize": (C.c_int, [vp] * 4 + [C.c_int, C.c_int, C.c_int, vp]),
     "crct_colsum_blocks": (C.c_int, [C.c_int]),
     "crct_colsum_bf16": (C.c_int, [vp, c_i64, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

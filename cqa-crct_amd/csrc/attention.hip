@@ -7,6 +7,8 @@
 // BertBiAttention :684-723 (both directions are two calls with q and k/v from different streams).
 // The backward pass recomputes P from q, k (nothing but q/k/v is kept from the forward) and
 // regenerates the dropout mask from (seed, site, element index).
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "crct_internal.h"
 
@@ -20,6 +22,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   uint32_t thr; float dscale; uint32_t site; uint64_t seed;
   float scale;
+  int dbg;      // developer ablation bits (tools/attn_lab), 0 in production
 };
 
 // LDS tiles: fp32 [T4][st], st = d + 4 floats (rows 16-byte aligned; 16 consecutive rows land on 16 distinct
@@ -180,33 +183,105 @@ __device__ __forceinline__ uint32_t philox_one(uint64_t seed, uint32_t site, uin
   return k == 0 ? p.x : (k == 1 ? p.y : (k == 2 ? p.z : p.w));
 }
 
-// row softmax over S[Tq][ldS] in place (+ additive key mask), wave per row.
+// 8-lane group reductions (3 butterfly steps instead of 6 for a whole wave)
+__device__ __forceinline__ float group8_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+  return v;
+}
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// row softmax over S[Tq][ldS] in place (+ additive key mask).  Eight lanes share a row (32 rows per
+// 256-thread pass); lane g of the group owns the C = 4*ceil(Tk/32) consecutive columns g*C .. g*C+C-1, so one
+// Philox call covers 4 of its elements and the row reductions are 3 shuffle steps.
 // mode 0 (forward):  S <- dropout(P)           (scaled by 1/(1-p))
 // mode 1 (backward): S <- +P if kept, -P if dropped  (sign carries the mask; P >= 0)
+template <int CQ>     // CQ = C / 4 (1..4)
+__device__ __forceinline__ void softmax_rows_c(float* S, int ldS, const uint8_t* km, int Tq, int Tk, float scale,
+                                               long bh, uint32_t thr, float dscale, uint32_t site, uint64_t seed,
+                                               int tid, int mode) {
+  constexpr int C = 4 * CQ;
+  const int g = tid & 7;
+  const long Tkp = (Tk + 3) & ~3;
+  for (int i = tid >> 3; i < ((Tq + 31) & ~31); i += 32) {      // whole groups stay converged for the shuffles
+    const bool live = i < Tq;
+    float* row = S + (live ? i : 0) * ldS;
+    float v[C];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = g * C + c;
+      v[c] = (live && j < Tk) ? row[j] * scale + (km[j] ? 0.f : -10000.f) : -INFINITY;
+      mx = fmaxf(mx, v[c]);
+    }
+    mx = group8_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { v[c] = v[c] == -INFINITY ? 0.f : expf(v[c] - mx); sum += v[c]; }
+    const float inv = 1.0f / group8_sum(sum);
+    if (!live) continue;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = g * C + 4 * q;
+      if (j >= ldS) continue;
+      float p[4] = {v[4 * q] * inv, v[4 * q + 1] * inv, v[4 * q + 2] * inv, v[4 * q + 3] * inv};
+      if (thr && j < Tk) {
+        const Philox4 r = philox4x32_10(seed, site, ((uint64_t)(bh * Tq + i) * (uint64_t)Tkp + (uint64_t)j) >> 2);
+        const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool keep = u[c] >= thr;
+          p[c] = mode == 0 ? (keep ? p[c] * dscale : 0.f) : (keep ? p[c] : -p[c]);
+        }
+      }
+      // columns Tk..ldS-1 are zero padding for the 4-wide loops (exp of -inf above gave 0)
+      *reinterpret_cast<float4*>(row + j) = make_float4(p[0], p[1], p[2], p[3]);
+    }
+  }
+}
 __device__ __forceinline__ void softmax_rows(float* S, int ldS, const uint8_t* km, int Tq, int Tk, float scale,
                                              long bh, uint32_t thr, float dscale, uint32_t site, uint64_t seed,
                                              int tid, int mode) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const long Tkp = (Tk + 3) & ~3;
-  for (int i = wave; i < Tq; i += 4) {
-    float* row = S + i * ldS;
-    const int j0 = lane, j1 = lane + 64;
-    float s0 = -INFINITY, s1 = -INFINITY;
-    if (j0 < Tk) s0 = row[j0] * scale + (km[j0] ? 0.f : -10000.f);
-    if (j1 < Tk) s1 = row[j1] * scale + (km[j1] ? 0.f : -10000.f);
-    const float mx = wave_max(fmaxf(s0, s1));
-    const float e0 = j0 < Tk ? expf(s0 - mx) : 0.f, e1 = j1 < Tk ? expf(s1 - mx) : 0.f;
-    const float inv = 1.0f / wave_sum(e0 + e1);
-    float p0 = e0 * inv, p1 = e1 * inv;
-    if (thr) {
-      const uint64_t base = (uint64_t)(bh * Tq + i) * (uint64_t)Tkp;
-      const bool k0 = j0 < Tk ? philox_one(seed, site, base + j0) >= thr : true;
-      const bool k1 = j1 < Tk ? philox_one(seed, site, base + j1) >= thr : true;
-      if (mode == 0) { p0 = k0 ? p0 * dscale : 0.f; p1 = k1 ? p1 * dscale : 0.f; }
-      else { p0 = k0 ? p0 : -p0; p1 = k1 ? p1 : -p1; }
+  if (Tk <= 32) softmax_rows_c<1>(S, ldS, km, Tq, Tk, scale, bh, thr, dscale, site, seed, tid, mode);
+  else if (Tk <= 64) softmax_rows_c<2>(S, ldS, km, Tq, Tk, scale, bh, thr, dscale, site, seed, tid, mode);
+  else if (Tk <= 96) softmax_rows_c<3>(S, ldS, km, Tq, Tk, scale, bh, thr, dscale, site, seed, tid, mode);
+  else softmax_rows_c<4>(S, ldS, km, Tq, Tk, scale, bh, thr, dscale, site, seed, tid, mode);
+}
+
+// backward: per row  delta = sum_j dP*P ; dS = P (dP - delta) ; Pm <- P*mask/keep (for dV).  Same 8-lane mapping.
+template <int CQ>
+__device__ __forceinline__ void softmax_bwd_rows_c(float* Pm, float* dS, int ldS, int Tq, int Tk, float ds, int tid) {
+  constexpr int C = 4 * CQ;
+  const int g = tid & 7;
+  for (int i = tid >> 3; i < ((Tq + 31) & ~31); i += 32) {
+    const bool live = i < Tq;
+    float* pr = Pm + (live ? i : 0) * ldS;
+    float* gr = dS + (live ? i : 0) * ldS;
+    float p[C], gq[C];
+    bool kp[C];
+    float part = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = g * C + c;
+      const bool in = live && j < Tk;
+      const float pv = in ? pr[j] : 0.f, gv = in ? gr[j] : 0.f;
+      kp[c] = !(__float_as_uint(pv) >> 31);
+      p[c] = fabsf(pv);
+      gq[c] = kp[c] ? gv * ds : 0.f;                 // gradient w.r.t. P (through dropout)
+      part += gq[c] * p[c];
     }
-    if (j0 < ldS) row[j0] = j0 < Tk ? p0 : 0.f;      // columns Tk..ldS-1 are padding for the 4-wide loops
-    if (j1 < ldS) row[j1] = j1 < Tk ? p1 : 0.f;
+    const float delta = group8_sum(part);
+    if (!live) continue;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = g * C + c;
+      if (j < ldS) {
+        gr[j] = j < Tk ? p[c] * (gq[c] - delta) : 0.f;
+        pr[j] = (j < Tk && kp[c]) ? p[c] * ds : 0.f;
+      }
+    }
   }
 }
 
@@ -224,11 +299,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   load_tile(K, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, d, tid);
   load_tile(V, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, d, tid);
   __syncthreads();
-  mm_nt<AQ, AK>(S, ldS, Q, K, a.Tq, a.Tk, d, tid);
+  if (!(a.dbg & 1)) mm_nt<AQ, AK>(S, ldS, Q, K, a.Tq, a.Tk, d, tid);
   __syncthreads();
-  softmax_rows(S, ldS, a.keymask + (long)b * a.Tk, a.Tq, a.Tk, a.scale, (long)b * a.heads + h, a.thr, a.dscale, a.site, a.seed, tid, 0);
+  if (!(a.dbg & 2)) softmax_rows(S, ldS, a.keymask + (long)b * a.Tk, a.Tq, a.Tk, a.scale, (long)b * a.heads + h, a.thr, a.dscale, a.site, a.seed, tid, 0);
   __syncthreads();
-  mm_nn<AQ>(Q, S, ldS, V, a.Tq, a.Tk, d, tid);     // ctx tile overwrites Q (no longer needed)
+  if (!(a.dbg & 4)) mm_nn<AQ>(Q, S, ldS, V, a.Tq, a.Tk, d, tid);     // ctx tile overwrites Q (no longer needed)
   __syncthreads();
   store_tile(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Q, a.Tq, d, tid, 1.0f);
 }
@@ -265,21 +340,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   __syncthreads();
   // ---- phase c/d: per row: delta = sum_j dP*P ; dS = P (dP - delta); Pd = P*mask/keep (for dV) kept in Pm
   {
-    const int lane = tid & 63, wave = tid >> 6;
     const float ds = a.thr ? a.dscale : 1.0f;
-    for (int i = wave; i < a.Tq; i += 4) {
-      float* pr = Pm + i * ldS;
-      float* gr = dS + i * ldS;
-      const int j0 = lane, j1 = lane + 64;
-      float p0 = j0 < a.Tk ? pr[j0] : 0.f, p1 = j1 < a.Tk ? pr[j1] : 0.f;
-      float g0 = j0 < a.Tk ? gr[j0] : 0.f, g1 = j1 < a.Tk ? gr[j1] : 0.f;
-      const bool k0 = !(__float_as_uint(p0) >> 31), k1 = !(__float_as_uint(p1) >> 31);
-      p0 = fabsf(p0); p1 = fabsf(p1);
-      g0 = k0 ? g0 * ds : 0.f; g1 = k1 ? g1 * ds : 0.f;          // gradient w.r.t. P (through dropout)
-      const float delta = wave_sum(g0 * p0 + g1 * p1);
-      if (j0 < ldS) { gr[j0] = j0 < a.Tk ? p0 * (g0 - delta) : 0.f; pr[j0] = (j0 < a.Tk && k0) ? p0 * ds : 0.f; }
-      if (j1 < ldS) { gr[j1] = j1 < a.Tk ? p1 * (g1 - delta) : 0.f; pr[j1] = (j1 < a.Tk && k1) ? p1 * ds : 0.f; }
-    }
+    if (a.Tk <= 32) softmax_bwd_rows_c<1>(Pm, dS, ldS, a.Tq, a.Tk, ds, tid);
+    else if (a.Tk <= 64) softmax_bwd_rows_c<2>(Pm, dS, ldS, a.Tq, a.Tk, ds, tid);
+    else if (a.Tk <= 96) softmax_bwd_rows_c<3>(Pm, dS, ldS, a.Tq, a.Tk, ds, tid);
+    else softmax_bwd_rows_c<4>(Pm, dS, ldS, a.Tq, a.Tk, ds, tid);
   }
   __syncthreads();
   // dV[j][c] = sum_i Pd[i][j] dO[i][c]
@@ -343,6 +408,8 @@ extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, c
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
+  static const int dbg = getenv("CRCT_ATTN_DBG") ? atoi(getenv("CRCT_ATTN_DBG")) : 0;
+  a.dbg = dbg;
   const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3;
   const size_t lds = sizeof(float) * ((size_t)(Tq4 + 2 * Tk4) * (d + 4) + (size_t)Tq4 * Tk4);
   CRCT_CHECK_HIP(dispatch<false>(a, lds, (hipStream_t)stream));

@@ -85,7 +85,7 @@ struct FfnA { size_t u, h, s, y, mean, rstd; };
 struct ProjA { size_t s, a, mean, rstd; };
 struct SelfLayerA { size_t qkv, ctx; ProjA proj; FfnA ffn; };
 struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
-struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv; };
+struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b; };
 
 struct Step { char kind; int idx; };
 struct Tap { std::string name; size_t off; char stream; };
@@ -173,6 +173,8 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
   s.dres_a = ar.take(M * H * 2); s.dlin_a = ar.take(M * H * 2); s.dres_b = ar.take(M * H * 2); s.dlin_b = ar.take(M * H * 2);
   s.gc = ar.take(M * H * 2); s.du = ar.take(M * (size_t)I * 2); s.dctx = ar.take(M * (size_t)Hm * 2);
   s.dqkv = ar.take(M * (size_t)3 * Hm * 2);
+  s.part_a = ar.take((size_t)3 * 256 * H * 4);      // LayerNorm-backward column partials of the layer's two norms
+  s.part_b = ar.take((size_t)3 * 256 * H * 4);
   return s;
 }
 
@@ -282,10 +284,14 @@ struct Run {
   }
   // returns the buffer that holds the gradient of the producing Linear's output
   size_t ln_bwd(size_t dy, size_t x, size_t mean, size_t rstd, const LnP& ln, const LinearP& lin, size_t dres, size_t dlin,
-                int M, int H, const Drop& dr) {
+                size_t part, int M, int H, const Drop& dr) {
     if (rc) return dres;
-    fail(crct_layernorm_bwd(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, G(ln.g), G(ln.b),
-                            G(lin.b), F(partials), M, H, 1, 0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
+    // rows pass on the data stream; the column pass (dgamma, dbeta, bias gradient of the producing Linear) joins the
+    // weight-gradient work on the side stream -- `part` belongs to this layer's scratch set
+    fail(crct_layernorm_bwd_rows(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
+                                 0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
+    wgrad_after_main();
+    if (!rc) fail(crct_layernorm_bwd_finalize(F(part), G(ln.g), G(ln.b), G(lin.b), M, H, 1, sw));
     return dr.thr ? dlin : dres;
   }
   void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
@@ -309,8 +315,8 @@ struct Run {
     ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out);
   }
   // in: g = grad of a.  out: dres (residual gradient), dctx.  Parameter gradients accumulated.
-  void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, int M, const Drop& dr) {
-    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.dense, dres, dlin, M, p.dense.out, dr);
+  void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, size_t part, int M, const Drop& dr) {
+    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.dense, dres, dlin, part, M, p.dense.out, dr);
     lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M);
     lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
   }
@@ -325,7 +331,7 @@ struct Run {
   // in: g = grad of a.y.  out: gx = grad of x.
   void ffn_bwd(const FfnP& p, const FfnA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc, int M, const Drop& dr) {
     const int H = p.down.out, I = p.up.out;
-    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.down, sc.dres_a, sc.dlin_a, M, H, dr);
+    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.down, sc.dres_a, sc.dlin_a, sc.part_a, M, H, dr);
     lin_wgrad(A(dl), H, A(a.h), I, p.down, M);
     Opt o; o.dact_src = A(a.u); o.dact = ACT_GELU; o.ld_aux = I;
     lin_dgrad(A(dl), H, p.down, M, A(sc.du), I, o);
@@ -347,7 +353,7 @@ struct Run {
     const int M = B * T, H = p.H, d = H / p.heads;
     const StreamScratch& sc = layer_begin();
     ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
-    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, M, drop(p.p_hid, p.site + 1));
+    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1));
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
              A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
     bias_grad(A(sc.dqkv), 3 * H, p.qkv, M);
@@ -384,8 +390,8 @@ struct Run {
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
     V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
-    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
-    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, Mt, drop(D.p_hidden, p.site + 3));       // dctx1 [Mt,Hb]
+    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
+    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3));       // dctx1 [Mt,Hb]
     // each attention backward also writes into the OTHER stream's dqkv scratch, which that stream's previous
     // layer (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading: both data
     // streams have waited for their own wgrad stream above, so ordering them against each other closes the hazard

@@ -589,10 +589,11 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
 
 int crct_layernorm_bwd_blocks(int M) { return row_grid(M, 256); }
 
-int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                       void* dx, void* dx_lin, float* dgamma, float* dbeta, float* dbias_lin, float* partials,
-                       int M, int H, int accumulate, uint32_t post_thr, float post_scale, uint32_t post_site,
-                       uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed, crct_stream_t stream) {
+// rows pass only: dx / dx_lin and the per-workgroup column partials [3][nblk][H]
+int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                            void* dx, void* dx_lin, float* partials, int M, int H, uint32_t post_thr, float post_scale,
+                            uint32_t post_site, uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
+                            crct_stream_t stream) {
   CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm_bwd: H=%d must be a positive multiple of 8", H);
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -602,11 +603,27 @@ int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const f
                                      (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin, partials, M, H,
                                      post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
   CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// column pass: dgamma / dbeta / dbias_lin (+)= sum over the workgroup partials; may run on another stream
+int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin, int M, int H,
+                                int accumulate, crct_stream_t stream) {
+  if (M <= 0) return 0;
   FinalizeArgs fa = {};
   fa.out[0] = dgamma; fa.out[1] = dbeta; fa.out[2] = dbias_lin;
   fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
-  fa.Q = 3; fa.nblk = nb; fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
-  return launch_finalize(fa, s);
+  fa.Q = 3; fa.nblk = crct_layernorm_bwd_blocks(M); fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
+  return launch_finalize(fa, (hipStream_t)stream);
+}
+
+int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       void* dx, void* dx_lin, float* dgamma, float* dbeta, float* dbias_lin, float* partials,
+                       int M, int H, int accumulate, uint32_t post_thr, float post_scale, uint32_t post_site,
+                       uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed, crct_stream_t stream) {
+  if (int r = crct_layernorm_bwd_rows(dy, x, mean, rstd, gamma, dx, dx_lin, partials, M, H, post_thr, post_scale, post_site,
+                                      lin_thr, lin_scale, lin_site, seed, stream)) return r;
+  return crct_layernorm_bwd_finalize(partials, dgamma, dbeta, dbias_lin, M, H, accumulate, stream);
 }
 
 int crct_colsum_blocks(int M) { int b = (M + 7) / 8; return b < 1 ? 1 : (b > 64 ? 64 : b); }

@@ -102,6 +102,16 @@ int crct_layernorm_bwd(const void* dy, const void* x, const float* mean, const f
                        uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
                        crct_stream_t stream);
 
+/* The same in two launches (rows pass / column pass), so that the column pass can be enqueued on another
+ * stream off the critical path; `partials` must stay untouched until the finalize has run. */
+int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, const float* rstd,
+                            const float* gamma, void* dx, void* dx_lin, float* partials, int M, int H,
+                            uint32_t post_thr, float post_scale, uint32_t post_site,
+                            uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
+                            crct_stream_t stream);
+int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin,
+                                int M, int H, int accumulate, crct_stream_t stream);
+
 /* Column sum of a bf16 [M][ld] matrix into fp32 out[N] (bias gradients).  partials: [nblk][N]. */
 int crct_colsum_blocks(int M);
 int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int M, int N,

@@ -46,7 +46,7 @@ def gemm_path(request):
 
 @pytest.mark.parametrize("M,N,K", [(1600, 3072, 768), (2880, 1024, 2048), (1600, 768, 3072), (80, 1024, 768),
                                    (21, 64, 96), (15, 128, 32), (300, 2304, 768)])
-@pytest.mark.parametrize("tile", [-1, 0, 3])
+@pytest.mark.parametrize("tile", [-1, 0, 3, 9, 11, 12])
 def test_gemm_forward(M, N, K, tile):
     x, w, b = bf(rand(M, K, seed=1)), bf(rand(N, K, scale=0.05, seed=2)), rand(N, seed=3)
     y = ops.gemm(x, w, M, N, K, bias=b, tile=tile)
@@ -66,21 +66,23 @@ def test_gemm_identity_asymmetric():
 
 
 @pytest.mark.parametrize("M,N,K", [(1600, 768, 2304), (2880, 1024, 3072), (21, 64, 192), (80, 768, 1024)])
-def test_gemm_dgrad(M, N, K):
+@pytest.mark.parametrize("tile", [-1, 3, 9, 12])
+def test_gemm_dgrad(M, N, K, tile):
     # dx[M][N=in] = dy[M][K=out] @ W[K=out][N=in]
     dy, w = bf(rand(M, K, seed=4)), bf(rand(K, N, scale=0.05, seed=5))
     add = bf(rand(M, N, seed=6))
-    dx = ops.gemm(dy, w, M, N, K, tb=True, addend=add)
+    dx = ops.gemm(dy, w, M, N, K, tb=True, addend=add, tile=tile)
     ref = dy.float() @ w.float() + add.float()
     assert rel_err(dx, ref) < 1e-2
 
 
 @pytest.mark.parametrize("R,N,K", [(1600, 768, 3072), (2880, 1024, 1024), (21, 64, 128), (80, 1024, 768), (1600, 2304, 768)])
-def test_gemm_wgrad(R, N, K):
+@pytest.mark.parametrize("tile", [-1, 3, 9, 12])
+def test_gemm_wgrad(R, N, K, tile):
     # dW[N=out][K=in] = dy[R][N]^T @ x[R][K]; fp32 output, accumulate
     dy, x = bf(rand(R, N, seed=7)), bf(rand(R, K, seed=8))
     out = torch.ones(N, K, device=DEV)
-    ops.gemm(dy, x, N, K, R, ta=True, tb=True, lda=N, ldb=K, out=out, accumulate=True)
+    ops.gemm(dy, x, N, K, R, ta=True, tb=True, lda=N, ldb=K, out=out, accumulate=True, tile=tile)
     ref = dy.float().t() @ x.float() + 1.0
     assert rel_err(out, ref) < 2e-3
 
