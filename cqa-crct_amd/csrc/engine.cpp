@@ -226,7 +226,14 @@ struct Run {
     }
     parity ^= 1;
   }
-  void wgrad_after_main() { if (!rc && sw != s) { fail(order_streams(e, s, sw)); sw_dirty = true; } }     // sw sees what s produced
+  int tick = 0, ordered_tick = -1;     // launches enqueued on s / the tick sw was last ordered after (skip redundant events)
+  void wgrad_after_main() {            // sw sees what s produced
+    if (rc || sw == s) return;
+    sw_dirty = true;
+    if (ordered_tick == tick) return;  // nothing new on s since the last ordering: sw is already behind it
+    fail(order_streams(e, s, sw));
+    ordered_tick = tick;
+  }
   void main_after_wgrad() { if (!rc && sw != s && sw_dirty) { fail(order_streams(e, sw, s)); sw_dirty = false; } }   // s may overwrite what sw read
 
   template <class T> T* W(size_t o) const { return reinterpret_cast<T*>(ws + o); }
@@ -250,6 +257,7 @@ struct Run {
             int K, const Opt& o, hipStream_t st = nullptr) {
     if (rc) return;
     if (!st) st = s;
+    if (st == s) ++tick;
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = Ap; g.B = Bp; g.C = C; g.bias = o.bias; g.preact_out = o.preact; g.dact_src = o.dact_src; g.addend = o.addend;
@@ -280,6 +288,7 @@ struct Run {
   }
   void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H) {
     if (rc) return;
+    ++tick;
     fail(crct_layernorm_fwd(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, s));
   }
   // returns the buffer that holds the gradient of the producing Linear's output
@@ -288,6 +297,7 @@ struct Run {
     if (rc) return dres;
     // rows pass on the data stream; the column pass (dgamma, dbeta, bias gradient of the producing Linear) joins the
     // weight-gradient work on the side stream -- `part` belongs to this layer's scratch set
+    ++tick;
     fail(crct_layernorm_bwd_rows(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
                                  0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
     wgrad_after_main();
@@ -297,12 +307,14 @@ struct Run {
   void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
                 int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr) {
     if (rc) return;
+    ++tick;
     fail(crct_attention_fwd(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, c->seed, s));
   }
   void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
                 const bf16_t* dctx, int64_t ldo, bf16_t* dq, int64_t lddq, bf16_t* dk, bf16_t* dv, int64_t lddk, int B,
                 int heads, int Tq, int Tk, int d, const Drop& dr) {
     if (rc) return;
+    ++tick;
     fail(crct_attention_bwd(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr,
                             dr.scale, dr.site, c->seed, s));
   }
@@ -440,6 +452,7 @@ struct Run {
     const CrctModelDims& D = e->d;
     const Drop dt = drop(D.p_hidden, 1);
     layer_begin();
+    ++tick;
     if (!rc) fail(crct_embed_text_bwd(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
                                       P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
                                       G(e->et.ln.g), G(e->et.ln.b), F(partials), b->B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
@@ -450,6 +463,7 @@ struct Run {
     const int Mv = b->B * b->V;
     const Drop dv = drop(D.p_hidden, 2);
     const StreamScratch& sc = layer_begin();
+    ++tick;
     if (!rc) fail(crct_embed_image_bwd(A(gv), A(e->eva.sum), F(e->eva.mean), F(e->eva.rstd), b->image_loc, b->image_target,
                                        P(e->ev.ln.g), A(sc.gc), G(e->ev.color), G(e->ev.wloc), G(e->ev.bloc), G(e->ev.img.b),
                                        G(e->ev.ln.g), G(e->ev.ln.b), F(partials), Mv, D.Hv, dv.thr, dv.scale, dv.site,
