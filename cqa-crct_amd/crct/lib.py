@@ -56,6 +56,7 @@ PROTOTYPES = {
     "crct_last_error": (C.c_char_p, []),
     "crct_abi_version": (C.c_int, []),
     "crct_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "crct_gemm_bf16_grouped": (C.c_int, [C.POINTER(GemmArgs), C.c_int, vp]),
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_force_generic": (C.c_int, [C.c_int]),
     "crct_prof_enable": (C.c_int, [C.c_int]),

@@ -53,6 +53,21 @@ def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=No
     return out
 
 
+def gemm_wgrad_grouped(problems):
+    """``problems`` = [(dy[R][N], x[R][K], out[N][K] fp32)]: out += dy^T x for every entry, ONE launch."""
+    lib = L.load()
+    arr = (L.GemmArgs * len(problems))()
+    for g, (dy, x, out) in zip(arr, problems):
+        _chk(dy, torch.bfloat16), _chk(x, torch.bfloat16), _chk(out, torch.float32)
+        R, N = dy.shape
+        K = x.shape[1]
+        g.A, g.B, g.C = L.ptr(dy), L.ptr(x), L.ptr(out)
+        g.lda, g.ldb, g.ldc, g.ld_aux, g.ld_add = N, K, K, K, K
+        g.M, g.N, g.K, g.ta, g.tb = N, K, R, 1, 1
+        g.c_is_f32, g.accumulate, g.tile, g.alpha = 1, 1, -1, 1.0
+    L.check(lib.crct_gemm_bf16_grouped(arr, len(problems), L.current_stream()), "gemm_grouped")
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-12, p_drop=0.0, site=0, seed=0):
     lib = L.load()
     M, H = x.shape

@@ -21,3 +21,4 @@ void crct_set_error(const char* fmt, ...);
   } while (0)
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s);
+hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s);

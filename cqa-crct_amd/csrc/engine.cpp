@@ -55,6 +55,18 @@ extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   return 0;
 }
 
+extern "C" int crct_gemm_bf16_grouped(const CrctGemmArgs* a, int n, crct_stream_t stream) {
+  CRCT_REQUIRE(a != nullptr && n >= 1, "gemm_grouped: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    CRCT_REQUIRE(a[i].A && a[i].B && a[i].C, "gemm_grouped: null operand in problem %d", i);
+    CRCT_REQUIRE(a[i].N % 4 == 0 && a[i].lda % 8 == 0 && a[i].ldb % 8 == 0 && a[i].ldc % 4 == 0, "gemm_grouped: alignment of problem %d", i);
+    CRCT_REQUIRE((a[i].ta && a[i].tb) || a[i].K % 8 == 0, "gemm_grouped: K of problem %d", i);
+    CRCT_REQUIRE(!(a[i].ta && !a[i].tb) && (!a[i].ta || a[i].M % 8 == 0) && (!a[i].tb || a[i].N % 8 == 0), "gemm_grouped: layout of problem %d", i);
+  }
+  CRCT_CHECK_HIP(crct_gemm_launch_grouped(a, n, (hipStream_t)stream));
+  return 0;
+}
+
 namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -219,6 +231,7 @@ struct Run {
     return *sets[parity];
   }
   void layer_end() {
+    flush_wgrads();
     if (!rc && sw != s && sw_dirty) {
       hipEvent_t ev = ev_new(e);
       if (!ev || hipEventRecord(ev, sw) != hipSuccess) { crct_set_error("engine: event record failed"); rc = 1; }
@@ -226,6 +239,7 @@ struct Run {
     }
     parity ^= 1;
   }
+  std::vector<CrctGemmArgs> pending;   // weight-gradient GEMMs of the current layer, launched as ONE grouped grid
   int tick = 0, ordered_tick = -1;     // launches enqueued on s / the tick sw was last ordered after (skip redundant events)
   void wgrad_after_main() {            // sw sees what s produced
     if (rc || sw == s) return;
@@ -234,7 +248,10 @@ struct Run {
     fail(order_streams(e, s, sw));
     ordered_tick = tick;
   }
-  void main_after_wgrad() { if (!rc && sw != s && sw_dirty) { fail(order_streams(e, sw, s)); sw_dirty = false; } }   // s may overwrite what sw read
+  void main_after_wgrad() {            // s may overwrite what sw read
+    flush_wgrads();
+    if (!rc && sw != s && sw_dirty) { fail(order_streams(e, sw, s)); sw_dirty = false; }
+  }
 
   template <class T> T* W(size_t o) const { return reinterpret_cast<T*>(ws + o); }
   bf16_t* A(size_t o) const { return W<bf16_t>(o); }
@@ -273,13 +290,25 @@ struct Run {
   }
   // dW[out][in] += dy^T x
   void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M) {
-    Opt o; o.f32 = true; o.acc = true;
-    wgrad_after_main();
-    gemm(dy, lddy, true, x, ldx, true, G(l.w), l.in, l.out, l.in, M, o, sw);
+    if (rc) return;
+    CrctGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dy; g.B = x; g.C = G(l.w); g.lda = lddy; g.ldb = ldx; g.ldc = l.in; g.M = l.out; g.N = l.in; g.K = M;
+    g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f;
+    if (sw == s) { ++tick; fail(crct_gemm_bf16(&g, s)); return; }     // no side stream: in order, one by one
+    pending.push_back(g);
+    if (pending.size() == 8) flush_wgrads();
   }
   // dx[M][in] = dy W (+ epilogue)
   void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, const Opt& o) {
     gemm(dy, lddy, false, PB(l.w), l.in, true, dx, lddx, M, l.in, l.out, o);
+  }
+  // launch the queued weight-gradient GEMMs on the side stream, ordered after everything enqueued on s so far
+  void flush_wgrads() {
+    if (rc || pending.empty()) return;
+    wgrad_after_main();
+    if (!rc) fail(crct_gemm_bf16_grouped(pending.data(), (int)pending.size(), sw));
+    pending.clear();
   }
   void bias_grad(const void* dy, int64_t lddy, const LinearP& l, int M) {
     wgrad_after_main();

@@ -403,7 +403,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Block tile (32*TM) x (32*TN), WM x WN waves (4 or 8), each wave owning a (BM/WM) x (BN/WN) sub-tile.
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave per K tile
@@ -415,8 +415,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  int tile_m, tile_n;
-  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)OOB_OFF, 0x00020000);
@@ -457,7 +455,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk && !(tmap.dbg & 2)) issue(kt + NS - 1, st_next);
+    if (kt + NS - 1 < nk && !(dbg & 2)) issue(kt + NS - 1, st_next);
     const char* ldsA = smem + st * STAGE;
     const char* ldsB = ldsA + A_BYTES;
 #pragma unroll
@@ -476,7 +474,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
   }
-  if (tmap.dbg & 1) {      // ablation: keep the accumulators alive, skip the epilogue
+  if (dbg & 1) {      // ablation: keep the accumulators alive, skip the epilogue
 #pragma unroll
     for (int a = 0; a < WTN; ++a)
 #pragma unroll
@@ -485,6 +483,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
   }
   static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "staging tile must fit into the operand ring");
   gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN>(g, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  int tile_m, tile_n;
+  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
+  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tile_m, tile_n, tmap.dbg);
+}
+
+// ---- grouped launch: up to 8 independent GEMMs of the same mode in ONE grid (the weight gradients of one
+// layer: 4-6 small problems that individually leave most CUs idle).  Block -> (problem, tile) by prefix table.
+constexpr int GROUP_MAX = 8;
+struct GroupArgs {
+  int n;
+  int tile_begin[GROUP_MAX + 1];
+  int tiles_n[GROUP_MAX];
+  struct P { const void* A; const void* B; void* C; long lda, ldb, ldc; int M, N, K, c_is_f32, accumulate; } p[GROUP_MAX];
+};
+
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArgs ga) {
+  int pi = 0;
+  const int bid = blockIdx.x;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
+  const int t = bid - ga.tile_begin[pi];
+  CrctGemmArgs g = {};
+  g.A = ga.p[pi].A; g.B = ga.p[pi].B; g.C = ga.p[pi].C;
+  g.lda = ga.p[pi].lda; g.ldb = ga.p[pi].ldb; g.ldc = ga.p[pi].ldc;
+  g.M = ga.p[pi].M; g.N = ga.p[pi].N; g.K = ga.p[pi].K; g.ta = TA; g.tb = TB;
+  g.c_is_f32 = ga.p[pi].c_is_f32; g.accumulate = ga.p[pi].accumulate; g.alpha = 1.0f;
+  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, t / ga.tiles_n[pi], t % ga.tiles_n[pi], 0);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  GroupArgs ga = {};
+  ga.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const CrctGemmArgs& g = gs[i];
+    ga.tile_begin[i] = total;
+    ga.tiles_n[i] = (g.N + BN - 1) / BN;
+    total += ((g.M + BM - 1) / BM) * ga.tiles_n[i];
+    ga.p[i] = {g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.M, g.N, g.K, g.c_is_f32, g.accumulate};
+  }
+  ga.tile_begin[n] = total;
+  const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_GROUP(TA_, TB_)                                                                                        \
+  do {                                                                                                                     \
+    auto kern = gemm_group_kernel<TM, TN, WM, WN, TA_, TB_, NS>;                                                           \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(kern, dim3(total), dim3(WM * WN * 64), lds, s, ga);                                                 \
+  } while (0)
+  if (gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(true, true);
+  else if (!gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(false, true);
+  else if (!gs[0].ta && !gs[0].tb) CRCT_LAUNCH_GROUP(false, false);
+  else return hipErrorInvalidValue;
+#undef CRCT_LAUNCH_GROUP
+  return hipGetLastError();
 }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -658,5 +724,40 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
     }
   }
   if (slot) hipEventRecord(slot->b, s);
+  return e;
+}
+
+// Grouped launch of n <= 8 plain GEMMs (no epilogue extras besides fp32 / bf16 output and accumulate) that share
+// (ta, tb) and satisfy the LDS-DMA kernel's requirements; anything else is launched one by one.
+hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s) {
+  bool ok = n >= 2 && n <= GROUP_MAX && !g_force_generic;
+  for (int i = 0; ok && i < n; ++i) {
+    const CrctGemmArgs& g = gs[i];
+    ok = pipe_ok(g) && g.ta == gs[0].ta && g.tb == gs[0].tb && !g.bias && !g.preact_out && !g.dact_src && !g.addend && !g.drop_thr &&
+         g.act == ACT_NONE && g.alpha == 1.0f && g.M > 96;
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) {
+      hipError_t e = crct_gemm_launch(gs[i], s);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  static const int cfg = getenv("CRCT_GEMM_GROUP") ? atoi(getenv("CRCT_GEMM_GROUP")) : 9;
+  ProfSlot* slot = nullptr;
+  if (g_prof.on) {                     // one timed slot for the whole group, FLOPs summed
+    if (g_prof.used == g_prof.slots.size()) {
+      ProfSlot ns;
+      if (hipEventCreate(&ns.a) != hipSuccess || hipEventCreate(&ns.b) != hipSuccess) return hipErrorOutOfMemory;
+      g_prof.slots.push_back(ns);
+    }
+    slot = &g_prof.slots[g_prof.used++];
+    slot->variant = (cfg == 12 ? 12 : 9) * 3 + (gs[0].ta ? 2 : (gs[0].tb ? 1 : 0));
+    g_prof.count[slot->variant] += 1;
+    for (int i = 0; i < n; ++i) g_prof.flops[slot->variant] += 2.0 * gs[i].M * gs[i].N * gs[i].K;
+    (void)hipEventRecord(slot->a, s);
+  }
+  const hipError_t e = cfg == 12 ? launch_group<4, 2, 4, 2, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 2>(gs, n, s);
+  if (slot) (void)hipEventRecord(slot->b, s);
   return e;
 }

@@ -57,6 +57,9 @@ typedef struct CrctGemmArgs {
 } CrctGemmArgs;
 
 int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
+/* n <= 8 independent GEMMs in ONE grid (same ta/tb, no epilogue extras besides the output type and accumulate):
+ * the weight gradients of one layer.  Problems that do not qualify are launched one by one. */
+int crct_gemm_bf16_grouped(const CrctGemmArgs* args, int n, crct_stream_t stream);
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 

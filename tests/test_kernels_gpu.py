@@ -87,6 +87,28 @@ def test_gemm_wgrad(R, N, K, tile):
     assert rel_err(out, ref) < 2e-3
 
 
+@pytest.mark.parametrize("R", [1600, 2880, 80])
+def test_gemm_wgrad_grouped(R):
+    # the weight gradients of one layer as ONE grid (different shapes per problem); small R falls back to single launches
+    shapes = [(768, 768), (2304, 768), (3072, 768), (768, 3072), (1024, 1024)]
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy, x = bf(rand(R, N, seed=20 + i)), bf(rand(R, K, seed=40 + i))
+        out = torch.full((N, K), float(i), device=DEV)
+        probs.append((dy, x, out))
+        refs.append(dy.float().t() @ x.float() + float(i))
+    ops.gemm_wgrad_grouped(probs)
+    for (_, _, out), ref in zip(probs, refs):
+        assert rel_err(out, ref) < 2e-3
+    # and against the one-by-one launches (only the fp32 accumulation order may differ)
+    if R > 96:
+        for i, (dy, x, out) in enumerate(probs):
+            solo = torch.full_like(out, float(i))
+            ops.gemm(dy, x, out.shape[0], out.shape[1], R, ta=True, tb=True, lda=out.shape[0], ldb=out.shape[1], out=solo,
+                     accumulate=True, tile=9)
+            assert rel_err(out, solo) < 2e-5
+
+
 def test_gemm_strided_rows():
     # CLS-row gather: A rows are hidden_states[:, 0] with row stride T*H
     B, T, H, N = 80, 20, 768, 1024
