@@ -56,9 +56,9 @@ class StepEngine(object):
             L.check(self.lib.crct_engine_segment_range(self.handle, s, C.byref(lo), C.byref(hi)), "segment_range")
             self.segments.append((lo.value, hi.value))
         B = self.max[0]
-        self.logits = torch.zeros(B, 2, device=self.device)
-        self.reg = torch.zeros(5, B, device=self.device)
-        self.stats = torch.zeros(8, device=self.device)
+        # step outputs in ONE buffer [stats 8 | reg 5*maxB | logits 2*maxB] so that a snapshot is a single copy
+        self.out = torch.zeros(8 + 7 * B, device=self.device)
+        self.stats, self.reg, self.logits = self.out[:8], self.out[8:8 + 5 * B].view(5, B), self.out[8 + 5 * B:].view(B, 2)
         self._keep = None
         # hipGraph mode: kernel arguments are baked at capture, so everything that changes per step lives in
         # persistent device buffers: the dropout seed, the batch (staged copies), the upstream loss gradients
@@ -147,7 +147,15 @@ class StepEngine(object):
                                              self.workspace.data_ptr(), self.logits.data_ptr(), self.reg.data_ptr(),
                                              self.stats.data_ptr(), stream), "engine_forward")
         self._leave(c.use_graph)
-        return self.logits[:B], self.reg.view(-1)[:5 * B].view(5, B), self.stats
+        return self.outputs_of(self.out, B)
+
+    def outputs_of(self, out, B):
+        """(logits [B,2], reg [5,B], stats [8]) views of an output buffer (``self.out`` or a snapshot of it)."""
+        o = 8 + 5 * self.max[0]
+        return out[o:o + 2 * B].view(B, 2), out[8:8 + 5 * B].view(5, B), out[:8]
+
+    def snapshot(self, B):
+        return self.outputs_of(self.out.clone(), B)
 
     def backward(self, p32, p16, g32, tensors, step, seg=-1):
         b, c = self._batch(tensors), self._cfg(step)

@@ -37,11 +37,11 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, tensors, step):
-        logits, reg, stats = model._engine.forward(model._flat_p, model._flat_b16, tensors, step)
+        model._engine.forward(model._flat_p, model._flat_b16, tensors, step)
         ctx.model, ctx.tensors, ctx.step = model, tensors, step
-        logits, reg_all, stats = logits.clone(), reg.clone(), stats.clone()
+        logits, reg_all, stats = model._engine.snapshot(tensors["tokens"].shape[0])    # one copy; the engine reuses its buffer
         ctx.mark_non_differentiable(logits, reg_all, stats)
-        return stats[1:2].clone(), reg[1].clone(), logits, reg_all, stats
+        return stats[1:2].clone(), reg_all[1].clone(), logits, reg_all, stats
 
     @staticmethod
     def backward(ctx, g_nsp, g_reg, _gl, _gr, _gs):
@@ -271,8 +271,8 @@ class CrctModel(nn.Module):
         if train_branch and torch.is_grad_enabled():
             nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)
         else:
-            logits, reg, stats = self._engine.forward(self._flat_p, self._flat_b16, tensors, step)
-            logits, reg, stats = logits.clone(), reg.clone(), stats.clone()
+            self._engine.forward(self._flat_p, self._flat_b16, tensors, step)
+            logits, reg, stats = self._engine.snapshot(B)
             nsp, reg_loss = stats[1:2], reg[1]
         self.last_stats = stats
         if self.sync_stats:

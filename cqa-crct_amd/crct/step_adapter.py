@@ -6,7 +6,6 @@ combination ``nsp_loss_coeff * nsp + reg_loss_coeff * mean_B(reg_loss)``.  Host 
 are moved to ``params['device']`` with non-blocking copies; the key-length mask is built on the
 host side of the boundary exactly as the reference does (it depends only on integer indices).
 """
-import numpy as np
 import torch
 
 
@@ -20,11 +19,10 @@ def sequence_mask(sequence_length, max_len=None):
 
 def forward(dialog_encoder, batch, params, output_nsp_scores=False, output_lm_scores=False, evaluation=False,
             sample_ids=None):
-    idx = np.arange(batch["tokens"].shape[0]) if sample_ids is None else sample_ids
-    dev = params["device"]
-
     def pick(key):
-        return batch[key][idx]
+        # sample_ids=None selects every row (encoder_decorator.py:76 indexes with arange(B)): the identity gather is
+        # skipped -- on device-resident batches it costs one pageable H2D copy of the index (a host sync) per key
+        return batch[key] if sample_ids is None else batch[key][sample_ids]
 
     tokens, txt_loc, segments = pick("tokens"), pick("loc"), pick("segments")
     sep_indices, mask, hist_len = pick("sep_indices"), pick("mask"), pick("hist_len")
