@@ -73,6 +73,7 @@ PROTOTYPES = {
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
+    "crct_attention_force_valu": (None, [C.c_int]),
     "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),
     "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp]),
     "crct_embed_image_fwd": (C.c_int, [vp] * 12 + [C.c_int] * 2 + [c_f32] + _u8 + [vp]),

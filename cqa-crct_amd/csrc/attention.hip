@@ -11,19 +11,9 @@
 
 #include "common.cuh"
 #include "crct_internal.h"
+#include "attention_args.h"
 
 namespace {
-
-struct AttnArgs {
-  const bf16_t* q; const bf16_t* k; const bf16_t* v; const uint8_t* keymask;
-  bf16_t* ctx;
-  const bf16_t* dctx; bf16_t* dq; bf16_t* dk; bf16_t* dv;
-  int B, heads, Tq, Tk, d;
-  long ldq, ldk, ldv, ldo, lddq, lddk, lddv;
-  uint32_t thr; float dscale; uint32_t site; uint64_t seed;
-  float scale;
-  int dbg;      // developer ablation bits (tools/attn_lab), 0 in production
-};
 
 // LDS tiles: fp32 [T4][st], st = d + 4 floats (rows 16-byte aligned; 16 consecutive rows land on 16 distinct
 // 16-byte bank slots for d = 32 / 48 / 64), T4 = T rounded up to 4 with the padding rows zero-filled, so that
@@ -394,7 +384,17 @@ int check_args(int Tq, int Tk, int d) {
   return 0;
 }
 
+// MFMA path (attention_mfma.hip) for the lengths / head sizes it covers; CRCT_ATTN_VALU=1 or
+// crct_attention_force_valu(1) keep everything on the fp32 kernels of this file
+int g_force_valu = -1;
+bool use_mfma(int Tq, int Tk, int d) {
+  if (g_force_valu < 0) g_force_valu = getenv("CRCT_ATTN_VALU") ? atoi(getenv("CRCT_ATTN_VALU")) : 0;
+  return !g_force_valu && crct_attention_mfma_ok(Tq, Tk, d);
+}
+
 }  // namespace
+
+extern "C" void crct_attention_force_valu(int on) { g_force_valu = on ? 1 : 0; }
 
 extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx, int B,
                                   int heads, int Tq, int Tk, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -410,6 +410,10 @@ extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, c
   a.scale = 1.0f / sqrtf((float)d);
   static const int dbg = getenv("CRCT_ATTN_DBG") ? atoi(getenv("CRCT_ATTN_DBG")) : 0;
   a.dbg = dbg;
+  if (use_mfma(Tq, Tk, d)) {
+    CRCT_CHECK_HIP(crct_attention_mfma_fwd(a, (hipStream_t)stream));
+    return 0;
+  }
   const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3;
   const size_t lds = sizeof(float) * ((size_t)(Tq4 + 2 * Tk4) * (d + 4) + (size_t)Tq4 * Tk4);
   CRCT_CHECK_HIP(dispatch<false>(a, lds, (hipStream_t)stream));
@@ -430,6 +434,10 @@ extern "C" int crct_attention_bwd(const void* q, const void* k, const void* v, c
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
+  if (use_mfma(Tq, Tk, d)) {
+    CRCT_CHECK_HIP(crct_attention_mfma_bwd(a, (hipStream_t)stream));
+    return 0;
+  }
   const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3, Tmax4 = Tq4 > Tk4 ? Tq4 : Tk4;
   const size_t lds = sizeof(float) * ((size_t)3 * Tmax4 * (d + 4) + (size_t)2 * Tq4 * Tk4);
   CRCT_REQUIRE(lds <= 160 * 1024, "attention_bwd: Tq=%d Tk=%d d=%d needs %zu B of LDS (> 160 KiB)", Tq, Tk, d, lds);

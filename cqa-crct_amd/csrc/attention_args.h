@@ -1,0 +1,22 @@
+// Arguments shared by the two attention implementations (attention.hip: fp32 VALU, any length up to 112;
+// attention_mfma.hip: one wave per (batch, head) on MFMA, lengths up to 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.cuh"
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const uint8_t* keymask;
+  bf16_t* ctx;
+  const bf16_t* dctx; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  int B, heads, Tq, Tk, d;
+  long ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  uint32_t thr; float dscale; uint32_t site; uint64_t seed;
+  float scale;
+  int dbg;      // developer ablation bits (tools/attn_lab), 0 in production
+};
+
+bool crct_attention_mfma_ok(int Tq, int Tk, int d);
+hipError_t crct_attention_mfma_fwd(const AttnArgs& a, hipStream_t s);
+hipError_t crct_attention_mfma_bwd(const AttnArgs& a, hipStream_t s);

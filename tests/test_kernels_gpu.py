@@ -219,10 +219,20 @@ def _attn_ref(q, k, v, km, heads, d):
     return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, heads * d)
 
 
+@pytest.fixture(params=["mfma", "valu"])
+def attn_path(request):
+    """Lengths <= 64 with head size 32 / 48 / 64 run on the MFMA kernels by default; 'valu' forces the fp32 kernels."""
+    lib = L.load()
+    lib.crct_attention_force_valu(int(request.param == "valu"))
+    yield request.param
+    lib.crct_attention_force_valu(0)
+
+
 @pytest.mark.parametrize("B,heads,Tq,Tk,d", [(80, 16, 20, 20, 48), (80, 16, 36, 36, 64), (80, 32, 20, 36, 32), (80, 32, 36, 20, 32),
                                              (4, 16, 100, 100, 64), (4, 32, 40, 100, 32), (4, 32, 100, 40, 32), (3, 4, 7, 5, 16),
-                                             (3, 4, 5, 7, 24)])
-def test_attention_fwd_bwd(B, heads, Tq, Tk, d):
+                                             (3, 4, 5, 7, 24), (5, 16, 64, 64, 64), (5, 8, 17, 33, 48), (2, 4, 1, 1, 32),
+                                             (3, 4, 16, 48, 32), (3, 4, 49, 15, 64)])
+def test_attention_fwd_bwd(B, heads, Tq, Tk, d, attn_path):
     Hh = heads * d
     # q / k / v as column slices of fused [*, 3*Hh] buffers, as the step engine passes them
     bufq = bf(rand(B, Tq, 3 * Hh, seed=1))
@@ -243,7 +253,39 @@ def test_attention_fwd_bwd(B, heads, Tq, Tk, d):
     assert rel_err(dv, vr.grad) < 1.5e-2
 
 
-def test_attention_dropout_statistics_and_grad_consistency():
+def test_attention_identity_asymmetric():
+    # v = one-hot columns, one key unmasked per query block: ctx must reproduce v's rows exactly -> catches a transposed
+    # or permuted operand in the MFMA path (cdna_hip_programming.md section 3)
+    B, heads, T, d = 2, 4, 36, 64
+    Hh = heads * d
+    q = bf(torch.zeros(B, T, Hh, device=DEV))
+    k = bf(torch.zeros(B, T, Hh, device=DEV))
+    v = bf((torch.arange(B * T * Hh, device=DEV, dtype=torch.float32).reshape(B, T, Hh) % 251) - 125)
+    for only in (0, 17, 35):
+        km = torch.zeros(B, T, dtype=torch.uint8, device=DEV)
+        km[:, only] = 1
+        ctx = ops.attention_fwd(q, k, v, km, heads, d)
+        assert torch.equal(ctx.float(), v[:, only:only + 1].float().expand(B, T, Hh))
+
+
+def test_attention_paths_share_the_dropout_stream():
+    B, heads, Tq, Tk, d, p = 8, 32, 20, 36, 32, 0.1
+    Hh = heads * d
+    q, k, v = bf(rand(B, Tq, Hh, seed=1)), bf(rand(B, Tk, Hh, seed=2)), bf(rand(B, Tk, Hh, seed=3))
+    km = torch.ones(B, Tk, dtype=torch.uint8, device=DEV)
+    dctx = bf(rand(B, Tq, Hh, seed=4))
+    lib = L.load()
+    outs = []
+    for valu in (0, 1):
+        lib.crct_attention_force_valu(valu)
+        ctx = ops.attention_fwd(q, k, v, km, heads, d, p_drop=p, site=9, seed=4242)
+        outs.append((ctx,) + tuple(ops.attention_bwd(q, k, v, km, dctx, heads, d, p_drop=p, site=9, seed=4242)))
+    lib.crct_attention_force_valu(0)
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 1.5e-2        # a different mask would move whole probabilities (errors of order 1)
+
+
+def test_attention_dropout_statistics_and_grad_consistency(attn_path):
     B, heads, T, d, p = 16, 16, 36, 64, 0.1
     Hh = heads * d
     q, k = bf(rand(B, T, Hh, seed=1)), bf(rand(B, T, Hh, seed=2))
