@@ -23,9 +23,19 @@
 #include "crct_internal.h"
 #include "attention_args.h"
 
+//
+// A workgroup holds W = 1, 2 or 4 independent waves (consecutive (batch, head) pairs), each with its own slice
+// of the dynamic LDS allocation; W is chosen per launch so that a CU's 160 KB hold as many waves as possible.
+// The waves never exchange data, so phases are separated by wave-level fences only (LDS operations of one wave
+// execute in issue order) and a wave past the end of the grid simply exits.
 namespace {
 
 typedef s4_t __attribute__((address_space(3))) * lds_s4_ptr;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ f4_t mma16(s4_t a, s4_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
@@ -79,19 +89,37 @@ __device__ __forceinline__ float xsum2(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// P^T tiles of one 16-query column block `it`: in: raw scores S^T (acc), out: probabilities (before dropout) and
-// the keep bits of the lane's 4 keys per tile
+// bit 4*jt + r of the result: key 16*jt + 4*g + r exists and is attended (keymask != 0); `valid`: it exists
 template <int NK>
-__device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, const uint8_t* km, int Tk, int Tq, int i, long bh,
-                                             const AttnArgs& a, int lane) {
+__device__ __forceinline__ void key_bits(const uint8_t* km, int Tk, int lane, uint32_t& attend, uint32_t& valid) {
   const int g = lane >> 4;
-  float mx = -INFINITY;
+  attend = 0u; valid = 0u;
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = 16 * jt + 4 * g + r;
-      const float v = j < Tk ? s[jt][r] * a.scale + (km[j] ? 0.f : -10000.f) : -INFINITY;
+      if (j < Tk) {
+        valid |= 1u << (4 * jt + r);
+        if (km[j]) attend |= 1u << (4 * jt + r);
+      }
+    }
+}
+
+// P^T tiles of one 16-query column block `it`: in: raw scores S^T (acc), out: probabilities (before dropout) and
+// the keep bits of the lane's 4 keys per tile.  exp(x) is evaluated as exp2(x * log2 e) (one v_exp_f32).
+template <int NK>
+__device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, uint32_t attend, uint32_t valid, int Tk, int Tq, int i,
+                                             long bh, const AttnArgs& a, int lane) {
+  const int g = lane >> 4;
+  const float sc = a.scale * 1.4426950408889634f, off = -10000.f * 1.4426950408889634f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jt = 0; jt < NK; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t bit = 1u << (4 * jt + r);
+      const float v = (valid & bit) ? s[jt][r] * sc + ((attend & bit) ? 0.f : off) : -INFINITY;
       s[jt][r] = v;
       mx = fmaxf(mx, v);
     }
@@ -101,7 +129,7 @@ __device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, cons
   for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = s[jt][r] == -INFINITY ? 0.f : expf(s[jt][r] - mx);
+      const float e = __builtin_amdgcn_exp2f(s[jt][r] - mx);        // exp2(-inf) = 0 for the padding keys
       s[jt][r] = e;
       sum += e;
     }
@@ -123,20 +151,37 @@ __device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, cons
   }
 }
 
-template <int NQ, int NK, int ND>
-__global__ __launch_bounds__(64) void attn_fwd_mfma(const AttnArgs a) {
-  constexpr int STB = 32 * ND + 16;
-  __shared__ __attribute__((aligned(16))) char Qs[16 * NQ * STB];
-  __shared__ __attribute__((aligned(16))) char Ks[16 * NK * STB];
-  __shared__ __attribute__((aligned(16))) char Vs[16 * NK * STB];
-  const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
-  const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads, d = 16 * ND;
-  const long bh = (long)b * a.heads + h;
+// fragment X[r0 + (lane & 15)][c0 + 4 (lane >> 4) + e] straight from global memory (rows >= T read as zero)
+__device__ __forceinline__ s4_t frag_rows_global(const bf16_t* src, long ld, int T, int r0, int c0, int lane) {
+  const int r = r0 + (lane & 15);
+  s4_t v = {0, 0, 0, 0};
+  if (r < T) v = *reinterpret_cast<const s4_t*>(src + (long)r * ld + c0 + 4 * (lane >> 4));
+  return v;
+}
+
+template <int NQ, int NK, int ND> struct FwdLds { static constexpr int STB = 32 * ND + 16, BYTES = 16 * (NQ + 2 * NK) * STB; };
+template <int NQ, int NK, int ND> struct BwdLds {
+  static constexpr int STB = 32 * ND + 16, PSB = 32 * NK + 16, NX = NQ > NK ? NQ : NK;
+  static constexpr int BYTES = 16 * (2 * NQ + NX) * STB + 16 * NQ * PSB;
+};
+
+template <int NQ, int NK, int ND, int W>
+__global__ __launch_bounds__(64 * W) void attn_fwd_mfma(const AttnArgs a) {
+  constexpr int STB = FwdLds<NQ, NK, ND>::STB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, n = lane & 15;
+  const long bh = (long)blockIdx.x * W + (threadIdx.x >> 6);
+  if (bh >= (long)a.B * a.heads) return;
+  char* Qs = smem + (threadIdx.x >> 6) * FwdLds<NQ, NK, ND>::BYTES;
+  char* Ks = Qs + 16 * NQ * STB;
+  char* Vs = Ks + 16 * NK * STB;
+  const int b = (int)(bh / a.heads), h = (int)(bh % a.heads), d = 16 * ND;
   load_rows<ND>(Qs, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, 16 * NQ, lane);
   load_rows<ND>(Ks, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, 16 * NK, lane);
   load_rows<ND>(Vs, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, 16 * NK, lane);
-  __syncthreads();
-  const uint8_t* km = a.keymask + (long)b * a.Tk;
+  uint32_t attend, valid;
+  key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
+  wave_sync();
   s4_t kf[NK][ND];
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt)
@@ -156,13 +201,14 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma(const AttnArgs a) {
       for (int ks = 0; ks < ND; ++ks) s[jt] = mma16(kf[jt][ks], qf[ks], s[jt]);      // S^T[j][i]
     }
     uint32_t keep;
-    softmax_cols<NK>(s, keep, km, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
+    softmax_cols<NK>(s, keep, attend, valid, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
+    const float ds = a.thr ? a.dscale : 1.0f;
     s4_t pb[NK];
 #pragma unroll
     for (int jt = 0; jt < NK; ++jt) {
       f4_t p;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = ((keep >> (4 * jt + r)) & 1u) ? (a.thr ? s[jt][r] * a.dscale : s[jt][r]) : 0.f;
+      for (int r = 0; r < 4; ++r) p[r] = ((keep >> (4 * jt + r)) & 1u) ? s[jt][r] * ds : 0.f;
       pb[jt] = pack4(p);
     }
 #pragma unroll
@@ -172,45 +218,49 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma(const AttnArgs a) {
       for (int jt = 0; jt < NK; ++jt) o[ct][it] = mma16(frag_cols(Vs, STB, 16 * jt, 16 * ct, lane), pb[jt], o[ct][it]);   // ctx^T[c][i]
     }
   }
-  __syncthreads();                      // every fragment of Q has been read: its image becomes the output staging tile
+  wave_sync();                          // every fragment of Q has been read: its image becomes the output staging tile
 #pragma unroll
   for (int it = 0; it < NQ; ++it)
 #pragma unroll
     for (int ct = 0; ct < ND; ++ct) put_tile_t(Qs, STB, 16 * it, 16 * ct, o[ct][it], lane);
-  __syncthreads();
+  wave_sync();
   store_rows<ND>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq, lane);
-  (void)g;
 }
 
-template <int NQ, int NK, int ND>
-__global__ __launch_bounds__(64) void attn_bwd_mfma(const AttnArgs a) {
-  constexpr int STB = 32 * ND + 16, NX = NQ > NK ? NQ : NK, PSB = 32 * NK + 16;
-  __shared__ __attribute__((aligned(16))) char Qs[16 * NQ * STB];
-  __shared__ __attribute__((aligned(16))) char Os[16 * NQ * STB];      // dO
-  __shared__ __attribute__((aligned(16))) char Ks[16 * NK * STB];
-  __shared__ __attribute__((aligned(16))) char Vs[16 * NX * STB];      // V, later the staging tile of dq / dv / dk
-  __shared__ __attribute__((aligned(16))) char Pi[16 * NQ * PSB];      // dropout(P)  [i][j]
-  __shared__ __attribute__((aligned(16))) char Di[16 * NQ * PSB];      // dS          [i][j]
-  const int lane = threadIdx.x, n = lane & 15;
-  const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads, d = 16 * ND;
-  const long bh = (long)b * a.heads + h;
+template <int NQ, int NK, int ND, int W>
+__global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
+  typedef BwdLds<NQ, NK, ND> G;
+  constexpr int STB = G::STB, PSB = G::PSB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, n = lane & 15;
+  const long bh = (long)blockIdx.x * W + (threadIdx.x >> 6);
+  if (bh >= (long)a.B * a.heads) return;
+  char* Qs = smem + (threadIdx.x >> 6) * G::BYTES;
+  char* Os = Qs + 16 * NQ * STB;        // dO
+  char* Ks = Os + 16 * NQ * STB;        // K (16 * max(NQ, NK) rows: later the staging tile of dq / dv / dk)
+  char* Pi = Ks + 16 * G::NX * STB;     // dropout(P) [i][j], then dS [i][j]
+  const int b = (int)(bh / a.heads), h = (int)(bh % a.heads), d = 16 * ND;
+  const bf16_t* vg = a.v + (long)b * a.Tk * a.ldv + h * d;
   load_rows<ND>(Qs, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, 16 * NQ, lane);
   load_rows<ND>(Os, a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, 16 * NQ, lane);
   load_rows<ND>(Ks, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, 16 * NK, lane);
-  load_rows<ND>(Vs, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, 16 * NK, lane);
-  __syncthreads();
-  const uint8_t* km = a.keymask + (long)b * a.Tk;
+  s4_t vf[NK][ND];                      // V is only ever contracted along its columns: fragments straight from global
+#pragma unroll
+  for (int jt = 0; jt < NK; ++jt)
+#pragma unroll
+    for (int ks = 0; ks < ND; ++ks) vf[jt][ks] = frag_rows_global(vg, a.ldv, a.Tk, 16 * jt, 16 * ks, lane);
+  uint32_t attend, valid;
+  key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
+  wave_sync();
   const float ds = a.thr ? a.dscale : 1.0f;
   f4_t dq[ND][NQ];
+  s4_t dsb[NQ][NK];                     // dS^T tiles (bf16): B operand of dq now, written to the image for dk later
   {
-    s4_t kf[NK][ND], vf[NK][ND];
+    s4_t kf[NK][ND];
 #pragma unroll
     for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
-      for (int ks = 0; ks < ND; ++ks) {
-        kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
-        vf[jt][ks] = frag_rows(Vs, STB, 16 * jt, 16 * ks, lane);
-      }
+      for (int ks = 0; ks < ND; ++ks) kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
 #pragma unroll
     for (int it = 0; it < NQ; ++it) {
       s4_t qf[ND], of[ND];
@@ -231,7 +281,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma(const AttnArgs a) {
         }
       }
       uint32_t keep;
-      softmax_cols<NK>(p, keep, km, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
+      softmax_cols<NK>(p, keep, attend, valid, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
       float part = 0.f;
 #pragma unroll
       for (int jt = 0; jt < NK; ++jt)
@@ -241,7 +291,6 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma(const AttnArgs a) {
           part += gp[jt][r] * p[jt][r];
         }
       const float delta = xsum2(part);
-      s4_t dsb[NK];
 #pragma unroll
       for (int jt = 0; jt < NK; ++jt) {
         f4_t dsv, pd;
@@ -250,67 +299,94 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma(const AttnArgs a) {
           dsv[r] = p[jt][r] * (gp[jt][r] - delta);
           pd[r] = ((keep >> (4 * jt + r)) & 1u) ? p[jt][r] * ds : 0.f;
         }
-        dsb[jt] = pack4(dsv);
+        dsb[it][jt] = pack4(dsv);
         put_tile_t(Pi, PSB, 16 * it, 16 * jt, pd, lane);
-        put_tile_t(Di, PSB, 16 * it, 16 * jt, dsv, lane);
       }
       // dq^T[c][i] = sum_j k[j][c] dS^T[j][i]
 #pragma unroll
       for (int ct = 0; ct < ND; ++ct) {
         dq[ct][it] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jt = 0; jt < NK; ++jt) dq[ct][it] = mma16(frag_cols(Ks, STB, 16 * jt, 16 * ct, lane), dsb[jt], dq[ct][it]);
+        for (int jt = 0; jt < NK; ++jt) dq[ct][it] = mma16(frag_cols(Ks, STB, 16 * jt, 16 * ct, lane), dsb[it][jt], dq[ct][it]);
       }
     }
   }
-  __syncthreads();                      // V fragments are consumed; P / dS images are complete
+  wave_sync();                          // K is consumed (its image becomes the staging tile); the P image is complete
 #pragma unroll
   for (int it = 0; it < NQ; ++it)
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Vs, STB, 16 * it, 16 * ct, dq[ct][it] * a.scale, lane);
-  __syncthreads();
-  store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Vs, a.Tq, lane);
-  // dv^T[c][j] = sum_i dO[i][c] Pd[i][j] ; dk^T[c][j] = sum_i q[i][c] dS[i][j]
-  f4_t dv[ND][NK], dk[ND][NK];
+    for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * it, 16 * ct, dq[ct][it] * a.scale, lane);
+  wave_sync();
+  store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane);
+  // dv^T[c][j] = sum_i dO[i][c] Pd[i][j]
+  f4_t acc[ND][NK];
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt) {
-    s4_t pf[NQ], sf[NQ];
+    s4_t pf[NQ];
 #pragma unroll
-    for (int it = 0; it < NQ; ++it) {
-      pf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
-      sf[it] = frag_cols(Di, PSB, 16 * it, 16 * jt, lane);
-    }
+    for (int it = 0; it < NQ; ++it) pf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
 #pragma unroll
     for (int ct = 0; ct < ND; ++ct) {
-      dv[ct][jt] = f4_t{0.f, 0.f, 0.f, 0.f};
-      dk[ct][jt] = f4_t{0.f, 0.f, 0.f, 0.f};
+      acc[ct][jt] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int it = 0; it < NQ; ++it) {
-        dv[ct][jt] = mma16(frag_cols(Os, STB, 16 * it, 16 * ct, lane), pf[it], dv[ct][jt]);
-        dk[ct][jt] = mma16(frag_cols(Qs, STB, 16 * it, 16 * ct, lane), sf[it], dk[ct][jt]);
-      }
+      for (int it = 0; it < NQ; ++it) acc[ct][jt] = mma16(frag_cols(Os, STB, 16 * it, 16 * ct, lane), pf[it], acc[ct][jt]);
     }
   }
-  __syncthreads();                      // dq has left the staging tile
+  wave_sync();                          // dq has left the staging tile, P has been read: the image now takes dS
+#pragma unroll
+  for (int it = 0; it < NQ; ++it)
+#pragma unroll
+    for (int jt = 0; jt < NK; ++jt)
+      *reinterpret_cast<s4_t*>(Pi + (16 * it + n) * PSB + (16 * jt + 4 * (lane >> 4)) * 2) = dsb[it][jt];
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Vs, STB, 16 * jt, 16 * ct, dv[ct][jt], lane);
-  __syncthreads();
-  store_rows<ND>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, Vs, a.Tk, lane);
-  __syncthreads();
+    for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * jt, 16 * ct, acc[ct][jt], lane);
+  wave_sync();
+  store_rows<ND>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, Ks, a.Tk, lane);
+  // dk^T[c][j] = sum_i q[i][c] dS[i][j]
+#pragma unroll
+  for (int jt = 0; jt < NK; ++jt) {
+    s4_t sf[NQ];
+#pragma unroll
+    for (int it = 0; it < NQ; ++it) sf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
+#pragma unroll
+    for (int ct = 0; ct < ND; ++ct) {
+      acc[ct][jt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < NQ; ++it) acc[ct][jt] = mma16(frag_cols(Qs, STB, 16 * it, 16 * ct, lane), sf[it], acc[ct][jt]);
+    }
+  }
+  wave_sync();                          // dv has left the staging tile
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Vs, STB, 16 * jt, 16 * ct, dk[ct][jt] * a.scale, lane);
-  __syncthreads();
-  store_rows<ND>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, Vs, a.Tk, lane);
+    for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * jt, 16 * ct, acc[ct][jt] * a.scale, lane);
+  wave_sync();
+  store_rows<ND>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, Ks, a.Tk, lane);
+}
+
+// waves per workgroup: the largest of 4 / 2 / 1 that does not lower the number of waves a CU's LDS can hold
+constexpr int waves_per_group(int bytes_per_wave) {
+  const int cap = 160 * 1024;
+  const int w1 = cap / bytes_per_wave, w2 = cap / (2 * bytes_per_wave) * 2, w4 = cap / (4 * bytes_per_wave) * 4;
+  return (w4 >= w1 && w4 >= w2) ? 4 : (w2 >= w1 ? 2 : 1);
 }
 
 template <bool BWD, int NQ, int NK, int ND>
 hipError_t launch(const AttnArgs& a, hipStream_t s) {
-  if constexpr (BWD) hipLaunchKernelGGL((attn_bwd_mfma<NQ, NK, ND>), dim3(a.B * a.heads), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((attn_fwd_mfma<NQ, NK, ND>), dim3(a.B * a.heads), dim3(64), 0, s, a);
+  constexpr int BYTES = BWD ? BwdLds<NQ, NK, ND>::BYTES : FwdLds<NQ, NK, ND>::BYTES;
+  constexpr int W = waves_per_group(BYTES);
+  static_assert(BYTES % 16 == 0 && BYTES * W <= 160 * 1024, "LDS slice");
+  auto kern = BWD ? attn_bwd_mfma<NQ, NK, ND, W> : attn_fwd_mfma<NQ, NK, ND, W>;
+  static bool raised = false;           // first call is eager (outside any stream capture)
+  if (BYTES * W > 64 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES * W);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  const int total = a.B * a.heads;
+  hipLaunchKernelGGL(kern, dim3((total + W - 1) / W), dim3(64 * W), BYTES * W, s, a);
   return hipGetLastError();
 }
 template <bool BWD, int NQ, int NK>
