@@ -124,6 +124,11 @@ class StepEngine(object):
             arr = (C.c_void_p * len(evs))(*[ev.cuda_event for ev in evs])
             step["_seg_events_keepalive"] = arr
             c.seg_ready_events = C.cast(arr, C.c_void_p)
+        done = step.get("seg_done_events")
+        if done is not None:
+            arr = (C.c_void_p * len(done))(*[ev.cuda_event for ev in done])
+            step["_seg_done_keepalive"] = arr
+            c.seg_done_events = C.cast(arr, C.c_void_p)
         return c
 
     def _enter(self, graph):

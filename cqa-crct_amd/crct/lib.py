@@ -47,7 +47,8 @@ class Batch(C.Structure):
 
 class StepCfg(C.Structure):
     _fields_ = [("training", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32), ("tol_margin", c_f32), ("nsp_coeff", c_f32),
-                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("seg_ready_events", vp), ("use_graph", c_i32)]
+                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("seg_ready_events", vp), ("seg_done_events", vp),
+                ("use_graph", c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/crct_hip.h declares

@@ -214,6 +214,10 @@ class CrctModel(nn.Module):
         self._ensure_grad_views()
         eng = self._engine
         if self._ddp is None:
+            if os.environ.get("CRCT_FORCE_SEGMENTED"):     # developer switch: the DDP call pattern without the collectives
+                for i in range(eng.n_segments):
+                    eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, i)
+                return
             eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, -1)
         else:
             self._ddp.backward(self, eng, tensors, step)

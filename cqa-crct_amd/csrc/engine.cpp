@@ -961,6 +961,16 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
         e->cur_t ^= 1; e->cur_v ^= 1;
       }
     }
+    if (seg < 0 && cfg->seg_done_events && !Rt.rc && !Rv.rc) {
+      // segment sgi is completely enqueued: mark that point on every internal stream for the data-parallel caller
+      Rt.flush_wgrads();
+      Rv.flush_wgrads();
+      hipStream_t ss[4] = {Rt.s, Rt.sw, Rv.s, Rv.sw};
+      for (int k = 0; k < 4; ++k) {
+        hipEvent_t ev = (hipEvent_t)cfg->seg_done_events[4 * sgi + k];
+        if (ev && hipEventRecord(ev, ss[k]) != hipSuccess) { crct_set_error("engine_backward: cannot record a segment event"); Rt.rc = 1; }
+      }
+    }
   }
   // join: everything this call enqueued anywhere is ordered before later work on the caller's stream
   Rt.main_after_wgrad();

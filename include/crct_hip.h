@@ -288,6 +288,11 @@ typedef struct CrctStepCfg {
   const void* const* seg_ready_events;   /* optional HOST array [crct_engine_num_segments] of hipEvent_t (or NULL entries):
                                 forward makes the stream(s) of the layers of segment s wait for event s before they run --
                                 lets a per-segment optimizer update of step n overlap the forward of step n+1 */
+  const void* const* seg_done_events;    /* optional HOST array [4 * crct_engine_num_segments] of hipEvent_t, used by
+                                crct_engine_backward(seg < 0): after segment s has been enqueued, events 4s .. 4s+3 are recorded
+                                on the four internal streams (text, text weight-gradient, visual, visual weight-gradient); once
+                                all four have fired, the gradient range of segments 0 .. s is final -- a data-parallel caller
+                                starts that range's all-reduce behind them while the rest of backward keeps running */
   int32_t use_graph;         /* != 0: capture the call into a hipGraph on its 2nd occurrence and replay it afterwards;
                                 every pointer argument (and a memory-resident seed) must then be stable across calls */
 } CrctStepCfg;
