@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=80)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
     ap.add_argument("--graph", action="store_true", help="experimental: replay forward / backward from captured hipGraphs "
                     "(measured: no gain -- the step is GPU-bound -- and not yet supported with the wgrad side streams)")
@@ -143,6 +144,8 @@ def main():
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1
+    if a.opt_early and opt.overlap:
+        opt.set_early(True)                          # ... or start per segment as soon as backward has finished it
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
     ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb) if world > 1 else None
     pool = [stage(S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i), dev) for i in range(8)]

@@ -81,6 +81,9 @@ class CrctModel(nn.Module):
         self.use_graph = False                       # replay the step's ~900 launches from captured hipGraphs
         self._ddp = None
         self._param_events = None                    # set by FusedAdamW in overlap mode
+        self._seg_done = None
+        self._grad_waits = None
+        self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
         self.init_weights(int(params.get("seed", 0)))
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate_shadow())
@@ -208,11 +211,32 @@ class CrctModel(nn.Module):
             self._engine = StepEngine(self.config, self.params, mb, mt, mv, self._flat_p.device, self.cls_dropout)
         return self._engine
 
+    def segment_done_events(self):
+        """4 events per backward segment, recorded by the engine on its internal streams when the segment is enqueued."""
+        if self._seg_done is None:
+            self._seg_done = [torch.cuda.Event() for _ in range(4 * self._engine.n_segments)]
+            for ev in self._seg_done:                 # torch creates the hipEvent lazily, at the first record
+                ev.record()
+        return self._seg_done
+
+    def take_segment_done_events(self):
+        """For the optimizer's early mode: per segment, the callables ``w(stream)`` that order ``stream`` after the
+        segment's final gradients of the LAST backward pass (None if that pass did not record them)."""
+        waits, self._grad_waits = self._grad_waits, None
+        return waits
+
     def _run_backward(self, tensors, step):
         if self._opt_stream is not None:             # overlapped optimizer update / gradient memset of the previous step
             torch.cuda.current_stream().wait_stream(self._opt_stream)
         self._ensure_grad_views()
         eng = self._engine
+        self._grad_waits = None
+        if self._ddp is None and self.record_segment_events and not step.get("use_graph"):
+            evs = self.segment_done_events()
+            step = dict(step, seg_done_events=evs)
+            eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, -1)
+            self._grad_waits = [[(lambda st, ev=ev: st.wait_event(ev)) for ev in evs[4 * i:4 * i + 4]] for i in range(eng.n_segments)]
+            return
         if self._ddp is None:
             if os.environ.get("CRCT_FORCE_SEGMENTED"):     # developer switch: the DDP call pattern without the collectives
                 for i in range(eng.n_segments):

@@ -9,6 +9,7 @@ kernel over the flat parameter / gradient / moment buffers (crct_adamw_step), wh
 the bf16 weight shadow; tensors that never receive a gradient are skipped, as torch.optim.AdamW
 skips ``grad is None`` parameters.
 """
+import contextlib
 import json
 import os
 
@@ -81,6 +82,11 @@ class FusedAdamW(torch.optim.Optimizer):
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
         self.overlap = False
+        # early mode (with overlap): the update of a segment starts as soon as the backward pass has finished that
+        # segment's gradients (the engine marks it with events), i.e. it overlaps the REST OF BACKWARD instead of the
+        # next forward; identical arithmetic, only the start time on the GPU moves
+        self.early = False
+        self._upload_done = None
         self._opt_stream = None
         self._seg_blocks = None
         self._events = None
@@ -91,15 +97,26 @@ class FusedAdamW(torch.optim.Optimizer):
                                  exp_avg_sq=self._v[e.offset:e.offset + e.numel].view(e.shape))
         self._byname = byname
 
-    def _upload_hyper(self):
+    def set_early(self, on=True):
+        """Overlap the update with the rest of backward (needs ``overlap``); see ``early`` above."""
+        self.early = bool(on)
+        self.core.record_segment_events = bool(on)
+
+    def _upload_hyper(self, stream=None):
         lrs = [self.param_groups[self._group_of[e.name]]["lr"] for e in self._segs]
         wds = [self.param_groups[self._group_of[e.name]]["weight_decay"] for e in self._segs]
         key = (tuple(lrs), tuple(wds))
         if key != self._last:
+            if self._upload_done is not None:
+                self._upload_done.synchronize()              # the pinned staging buffers are free again (long done in practice)
             self._lr_host.copy_(torch.tensor(lrs, dtype=torch.float32))
             self._wd_host.copy_(torch.tensor(wds, dtype=torch.float32))
-            self._lr_dev.copy_(self._lr_host, non_blocking=True)
-            self._wd_dev.copy_(self._wd_host, non_blocking=True)
+            with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                self._lr_dev.copy_(self._lr_host, non_blocking=True)
+                self._wd_dev.copy_(self._wd_host, non_blocking=True)
+                if self._upload_done is None:
+                    self._upload_done = torch.cuda.Event()
+                self._upload_done.record()
             self._last = key
 
     def _launch(self, b0, b1, inv_scale, stream):
@@ -138,20 +155,32 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None, inv_scale=None):
         loss = closure() if closure is not None else None
         core = self.core
-        self._upload_hyper()
         self._step += 1
         if self.overlap and (self._seg_blocks is not None or self._plan_overlap()):
             cur = torch.cuda.current_stream()
-            self._opt_stream.wait_stream(cur)                 # gradients (and the hyper-parameter upload) are final
+            done = core.take_segment_done_events() if (self.early and inv_scale is None) else None
             n = len(self._seg_blocks)
-            for sgi in range(n - 1, -1, -1):                  # first-use order: embeddings ... heads
+            if done is None:
+                self._upload_hyper()
+                self._opt_stream.wait_stream(cur)             # gradients (and the hyper-parameter upload) are final
+                order = range(n - 1, -1, -1)                  # first-use order: embeddings ... heads
+            else:
+                self._upload_hyper(self._opt_stream)          # not behind the backward pass that `cur` still runs
+                order = range(n)                              # the order backward finishes them: heads ... embeddings
+            for sgi in order:
                 b0, b1 = self._seg_blocks[sgi]
+                if done is not None:
+                    for w in done[sgi]:
+                        w(self._opt_stream)
                 if b1 > b0:
                     self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream)
                 self._events[sgi].record(self._opt_stream)
+            if done is not None:
+                self._opt_stream.wait_stream(cur)             # the gradient memset that follows must not pass backward's tail
             core._param_events = self._events                # the next forward waits segment by segment
             core._opt_stream = self._opt_stream               # ... and the next backward for the whole stream
         else:
+            self._upload_hyper()
             self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
         core.note_params_updated_natively()
         return loss

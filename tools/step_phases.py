@@ -1,0 +1,97 @@
+"""Developer probe: GPU-side duration of the phases of a training step WITHOUT a profiler attached
+(torch events on the caller's stream), next to the host time spent enqueuing each phase."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cqa-crct_amd"))
+import torch
+
+from crct import config as CFG, synthetic as S
+from crct.model import VisualDialogEncoder
+from crct.optim import get_optimizer, WarmupLinearScheduleNonZero
+from crct.step_adapter import forward as step_forward
+
+dev = torch.device("cuda", 0)
+B = 80
+cfg = CFG.vilbert_config(v_feature_size=2048)
+params = CFG.default_params(device=dev, rank=0, world_size=1, ddp=False, batch_size=B, seed=0)
+model = VisualDialogEncoder(params, config=cfg)
+core = model.bert_pretrained
+core.sync_stats = False
+model.train()
+opt = get_optimizer(params, model)
+opt.overlap = True
+sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
+pool = [{k: v.to(dev) for k, v in S.make_batch(B, 20, 36, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
+
+marks = []
+
+
+def mark(name):
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    marks.append((name, ev, time.perf_counter()))
+
+
+orig_bwd = core._run_backward
+
+
+def run_backward(tensors, step):
+    mark("bwd_enter")
+    orig_bwd(tensors, step)
+    mark("bwd_enqueued")
+
+
+core._run_backward = run_backward
+orig_fwd = core._engine.forward if core._engine else None
+
+N, W = 30, 10
+rows = []
+for it in range(N):
+    marks.clear()
+    mark("step_begin")
+    out = step_forward(model, pool[it % 8], params)
+    mark("fwd_loss_enqueued")
+    out[0].backward()
+    mark("autograd_done")
+    opt.step()
+    opt.zero_grad()
+    sched.step()
+    mark("opt_enqueued")
+    if it >= W:
+        torch.cuda.synchronize()
+        base_ev, base_t = marks[0][1], marks[0][2]
+        rows.append([(n, base_ev.elapsed_time(ev), (t - base_t) * 1e3) for n, ev, t in marks])
+torch.cuda.synchronize()
+print("synchronised every step (host starts each step with an empty queue): GPU ms since step_begin | host ms")
+for i, (n, _, _) in enumerate(rows[0]):
+    g = sum(r[i][1] for r in rows) / len(rows)
+    h = sum(r[i][2] for r in rows) / len(rows)
+    print("  %-20s gpu %7.3f   host %7.3f" % (n, g, h))
+
+# free-running: events only, no per-step sync
+allm = []
+for it in range(N):
+    marks.clear()
+    mark("step_begin")
+    out = step_forward(model, pool[it % 8], params)
+    mark("fwd_loss_enqueued")
+    out[0].backward()
+    mark("autograd_done")
+    opt.step()
+    opt.zero_grad()
+    sched.step()
+    mark("opt_enqueued")
+    allm.append(list(marks))
+torch.cuda.synchronize()
+print("free running: GPU ms since that step's step_begin | host ms since that step's begin; step period = gpu(next step_begin)")
+keep = allm[W:-1]
+for i, (n, _, _) in enumerate(keep[0]):
+    g = sum(m[0][1].elapsed_time(m[i][1]) for m in keep) / len(keep)
+    h = sum((m[i][2] - m[0][2]) * 1e3 for m in keep) / len(keep)
+    print("  %-20s gpu %7.3f   host %7.3f" % (n, g, h))
+per = sum(allm[k][0][1].elapsed_time(allm[k + 1][0][1]) for k in range(W, N - 1)) / (N - 1 - W)
+hper = sum((allm[k + 1][0][2] - allm[k][0][2]) * 1e3 for k in range(W, N - 1)) / (N - 1 - W)
+print("  step period: gpu %.3f ms, host %.3f ms" % (per, hper))
