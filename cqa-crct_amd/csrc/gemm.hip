@@ -497,8 +497,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
 constexpr int GROUP_MAX = 8;
 struct GroupArgs {
   int n;
-  int tile_begin[GROUP_MAX + 1];
-  int tiles_n[GROUP_MAX];
+  int tile_begin[GROUP_MAX + 1];       // first block of every problem (multiples of 8: a problem starts on XCD 0)
+  TileMap map[GROUP_MAX];              // per-problem XCD-aware block -> tile map, as for single launches
   struct P { const void* A; const void* B; void* C; long lda, ldb, ldc; int M, N, K, c_is_f32, accumulate; } p[GROUP_MAX];
 };
 
@@ -509,13 +509,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
 #pragma unroll
   for (int i = 1; i < GROUP_MAX; ++i)
     if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
-  const int t = bid - ga.tile_begin[pi];
+  int tm, tn;
+  if (!map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) return;
   CrctGemmArgs g = {};
   g.A = ga.p[pi].A; g.B = ga.p[pi].B; g.C = ga.p[pi].C;
   g.lda = ga.p[pi].lda; g.ldb = ga.p[pi].ldb; g.ldc = ga.p[pi].ldc;
   g.M = ga.p[pi].M; g.N = ga.p[pi].N; g.K = ga.p[pi].K; g.ta = TA; g.tb = TB;
   g.c_is_f32 = ga.p[pi].c_is_f32; g.accumulate = ga.p[pi].accumulate; g.alpha = 1.0f;
-  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, t / ga.tiles_n[pi], t % ga.tiles_n[pi], 0);
+  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
 }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -527,8 +528,10 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     const CrctGemmArgs& g = gs[i];
     ga.tile_begin[i] = total;
-    ga.tiles_n[i] = (g.N + BN - 1) / BN;
-    total += ((g.M + BM - 1) / BM) * ga.tiles_n[i];
+    int grid = 0;
+    ga.map[i] = make_tile_map(g.M, g.N, BM, BN, &grid);
+    ga.map[i].dbg = 0;
+    total += grid;
     ga.p[i] = {g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.M, g.N, g.K, g.c_is_f32, g.accumulate};
   }
   ga.tile_begin[n] = total;
