@@ -92,6 +92,25 @@ def gemm_profile(model, run_step, n_steps):
     return rows
 
 
+def pmc_traffic(kernel_label):
+    """Fabric-side bytes per launch of a GEMM variant from the committed PMC passes of this same command
+    (profiles/r*_pmc_traffic.json, made by tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md); None when no such measurement is on disk."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except (OSError, ValueError):
+            continue
+        cand = [v for v in table.values() if v.get("bench_label") == kernel_label]
+        if cand:
+            tot = sum(v["launches"] for v in cand)
+            best = sum(v["bytes_per_launch"] * v["launches"] for v in cand) / max(tot, 1)
+    return best
+
+
 def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
     """Oracle forward+backward on the host cores, bounded to ~budget_s of CPU work: one warm-up and one
     probe at B=4 size the timed sample (B <= the benchmark batch) so that it fits the budget.
@@ -108,13 +127,16 @@ def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
     probe = time.time() - t0
     Bs = int(max(4, min(B, 4 * budget_s / max(probe, 1e-3))))
     batch = S.make_batch(Bs, T, V, Fv, seed=1234)
-    t0 = time.time()
-    O.oracle_step(sd, cfg, cpu_params, batch)[0].backward()
-    dt = time.time() - t0
-    return dict(value=Bs / dt, unit="QA-pairs/s", cores=threads, kind="port",
-                sample="1 forward+backward of the fp32 CPU oracle (oracle/crct_oracle.py) at B=%d (sized from a B=4 probe of %.2f s "
-                       "to ~%.0f s), V=%d, T=%d, F_v=%d, dropout on; %.1f s on %d threads (of %d cores)"
-                       % (Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1))
+    reps, dt = 0, 0.0
+    while reps < 8 and (reps == 0 or dt < 0.5 * budget_s):          # fast hosts: repeat the sample up to ~budget_s / 2
+        t0 = time.time()
+        O.oracle_step(sd, cfg, cpu_params, batch)[0].backward()
+        dt += time.time() - t0
+        reps += 1
+    return dict(value=Bs * reps / dt, unit="QA-pairs/s", cores=threads, kind="port",
+                sample="%d x forward+backward of the fp32 CPU oracle (oracle/crct_oracle.py) at B=%d (sized from a B=4 probe of %.2f s "
+                       "for a ~%.0f s budget), V=%d, T=%d, F_v=%d, dropout on; %.1f s in total on %d threads (of %d cores)"
+                       % (reps, Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1))
 
 
 def main():
@@ -197,8 +219,9 @@ def main():
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
         if rows:
             dom = max(rows, key=lambda r: r["ms_per_step"])
+            traffic = pmc_traffic(dom["kernel"]) if (a.batch, a.vis, a.tokens, a.feat) == (80, 36, 20, 2048) else None
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "gflop_per_launch": dom["gflop_per_launch"], "us_per_launch": dom["us_per_launch"]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(core, cfg, params, a.cpu_batch, a.tokens, a.vis, a.feat)

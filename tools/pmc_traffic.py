@@ -34,6 +34,11 @@ def main():
         rd = 2.0 * vf * 1024.0 / max(nf, 1)          # gfx950 correction: x2
         wr = vw * 1024.0 / max(nw, 1)
         out[k] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr}
+        m = re.match(r"void gemm_(pipe|group)_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)>", k)
+        if m:      # the label bench.py prints for this GEMM variant
+            tm, tn, wm, wn, ns = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(8))
+            var = "wgrad" if m.group(6) == "true" else ("dgrad" if m.group(7) == "true" else "fwd")
+            out[k]["bench_label"] = "gemm<dma%dx%dw%ds%d,%s>" % (32 * tm, 32 * tn, wm * wn, ns, var)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in list(out.items())[:25]:
         print("%-90s n=%5d  rd %8.2f MB  wr %8.2f MB" % (k[:90], v["launches"], v["read_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
