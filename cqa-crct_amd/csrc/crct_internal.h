@@ -22,3 +22,7 @@ void crct_set_error(const char* fmt, ...);
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s);
 hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s);
+
+// upper bound of the workgroup count of the LayerNorm-backward style kernels (4 rows per workgroup and pass):
+// sizes the column-partials scratch [partials][blocks][H]
+#define CRCT_LN_BWD_MAX_BLOCKS 256

@@ -185,8 +185,8 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
   s.dres_a = ar.take(M * H * 2); s.dlin_a = ar.take(M * H * 2); s.dres_b = ar.take(M * H * 2); s.dlin_b = ar.take(M * H * 2);
   s.gc = ar.take(M * H * 2); s.du = ar.take(M * (size_t)I * 2); s.dctx = ar.take(M * (size_t)Hm * 2);
   s.dqkv = ar.take(M * (size_t)3 * Hm * 2);
-  s.part_a = ar.take((size_t)3 * 256 * H * 4);      // LayerNorm-backward column partials of the layer's two norms
-  s.part_b = ar.take((size_t)3 * 256 * H * 4);
+  s.part_a = ar.take((size_t)3 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);      // LayerNorm-backward column partials of the layer's two norms
+  s.part_b = ar.take((size_t)3 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);
   return s;
 }
 
@@ -773,7 +773,7 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->sv2 = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
   {
     size_t wmax = D.H > D.Hv ? D.H : D.Hv;
-    for (int k = 0; k < 2; ++k) e->partials[k] = ar.take((size_t)8 * 256 * wmax * 4);
+    for (int k = 0; k < 2; ++k) e->partials[k] = ar.take((size_t)8 * CRCT_LN_BWD_MAX_BLOCKS * wmax * 4);
     size_t nmax = 3 * (size_t)D.Hb;
     if ((size_t)D.I > nmax) nmax = D.I;
     if ((size_t)D.Iv > nmax) nmax = D.Iv;

@@ -587,7 +587,7 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
   return 0;
 }
 
-int crct_layernorm_bwd_blocks(int M) { return row_grid(M, 256); }
+int crct_layernorm_bwd_blocks(int M) { return row_grid(M, CRCT_LN_BWD_MAX_BLOCKS); }
 
 // rows pass only: dx / dx_lin and the per-workgroup column partials [3][nblk][H]
 int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
