@@ -51,7 +51,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def __init__(self, param_groups, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
-                        foreach=None, capturable=False, differentiable=False, fused=None)
+                        foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True)
         super().__init__(param_groups, defaults)
         self.core = _crct_core(model)
         core = self.core

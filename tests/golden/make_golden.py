@@ -182,6 +182,69 @@ def optimizer_case(vilbert, ed):
     print("  wrote", path)
 
 
+def checkpoint_schema_case(vilbert, ed):
+    """Structure of the checkpoint the reference's train.py:284-291 writes (keys, shapes, dtypes, optimizer and
+    scheduler state layout), taken from a real torch.save / torch.load round trip of the reference objects after
+    two optimizer steps on the tiny model.  Only the structure is committed (values are covered by tiny_adamw3)."""
+    import importlib
+    import tempfile
+    utils = importlib.import_module("utils")
+    cfg = C.tiny_config()
+    params = C.default_params(categories=9, L1=True, device=torch.device("cpu"))
+    model = build_reference_model(vilbert, ed, cfg, params)
+    S.seeded_fill_(model.state_dict(), base_seed=7)
+    batch = S.make_batch(3, 7, 5, cfg.v_feature_size, categories=9, vocab_size=cfg.vocab_size, seed=11)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        opt = utils.get_optimizer(params, model)
+    finally:
+        os.chdir(cwd)
+    sched = utils.WarmupLinearScheduleNonZero(opt, warmup_steps=4, t_total=10, min_lr=1.3e-5)
+    for it in range(2):
+        ed.forward(model, {k: v.clone() for k, v in batch.items()}, params)[0].backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+    ckpt = {"model_state_dict": model.state_dict(), "scheduler_state_dict": sched.state_dict(),
+            "optimizer_state_dict": opt.state_dict(), "iter_id": 2}                 # train.py:287-289
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "plotqa_encoder_0_2.ckpt")                           # train.py:282
+        torch.save(ckpt, path)
+        back = torch.load(path, map_location="cpu", weights_only=False)
+
+    def jsonable(v):
+        if isinstance(v, torch.Tensor):
+            return {"tensor": list(v.shape), "dtype": str(v.dtype)}
+        if isinstance(v, (list, tuple)):
+            return [jsonable(x) for x in v]
+        if isinstance(v, dict):
+            return {str(k): jsonable(x) for k, x in v.items()}
+        if isinstance(v, (int, float, bool, str)) or v is None:
+            return v
+        return repr(v)
+
+    osd = back["optimizer_state_dict"]
+    schema = {
+        "file_name_pattern": "plotqa_encoder_%d_%d.ckpt",
+        "top_level_keys": list(back.keys()),
+        "iter_id": back["iter_id"],
+        "model_state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in back["model_state_dict"].items()],
+        "optimizer_state_keys": sorted(osd.keys()),
+        "optimizer_param_group_keys": sorted(osd["param_groups"][0].keys()),
+        "optimizer_param_groups": [[g["lr"], g["weight_decay"], g["params"], list(g["betas"]), g["eps"], g.get("initial_lr")]
+                                   for g in osd["param_groups"]],
+        "optimizer_state_ids": sorted(int(k) for k in osd["state"].keys()),
+        "optimizer_state_entry": jsonable(osd["state"][sorted(osd["state"].keys())[0]]),
+        "scheduler_state_dict": jsonable(back["scheduler_state_dict"]),
+    }
+    path = os.path.join(HERE, "ckpt_schema.json")
+    with open(path, "w") as f:
+        json.dump(schema, f)
+    print("  wrote %s (%.1f KB); %d model keys, %d groups, %d state entries" % (
+        path, os.path.getsize(path) / 1024, len(schema["model_state_dict"]), len(osd["param_groups"]), len(osd["state"])))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -207,6 +270,7 @@ def main():
     run_case("tiny_smoothL1", tiny, p_s, b2, vilbert, ed, save_weights=False)
     run_case("tiny_eval", tiny, p_tiny, b2, vilbert, ed, save_weights=False, evaluation=True)
     optimizer_case(vilbert, ed)
+    checkpoint_schema_case(vilbert, ed)
     # ---- full vilbert.json shapes, seeded weights: only inputs / outputs / gradient samples committed
     for nm, B, V, T, Fv in (("full_B4_V36_T20_F1024", 4, 36, 20, 1024),
                             ("full_B4_V36_T20_F2048", 4, 36, 20, 2048),
@@ -221,4 +285,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt_schema":      # regenerate only the checkpoint schema
+        sys.modules.setdefault("pandas", __import__("pandas"))
+        checkpoint_schema_case(*import_reference())
+    else:
+        main()

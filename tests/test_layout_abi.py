@@ -121,3 +121,28 @@ def test_synthetic_batch_schema():
     assert (b["segments"][:, 0] == 0).all() and (b["tokens"][:, 0] == 101).all()
     b2 = S.make_batch(5, 20, 36, 64, seed=1)
     assert all(torch.equal(b[k], b2[k]) for k in b)
+
+
+def test_checkpoint_schema_fixture_matches_the_parameter_table():
+    """tests/golden/ckpt_schema.json (structure of a checkpoint written by the reference's train.py path) lists exactly
+    the tensors of the flat layout, in state_dict order, plus the tied LM decoder key; AdamW state exists only for the
+    tensors that receive gradients (train.py:284-291, utils.py:228-249)."""
+    import json
+    schema = json.load(open(os.path.join(GOLDEN, "ckpt_schema.json")))
+    cfg = CFG.tiny_config()
+    params = CFG.default_params(categories=9)
+    table, _ = LY.parameter_table(cfg, params)
+    by_name = {"bert_pretrained." + e.name: e for e in table}
+    keys = [k for k, _, _ in schema["model_state_dict"]]
+    tied = "bert_pretrained.cls.predictions.decoder.weight"
+    assert tied in keys and set(keys) - {tied} == set(by_name)
+    for k, shape, dtype in schema["model_state_dict"]:
+        if k != tied:
+            assert tuple(shape) == tuple(by_name[k].shape) and dtype == "torch.float32"
+    # one optimizer group per named parameter (the tied key is the same Parameter), state only where gradients flow
+    named = [k for k in keys if k != tied]
+    assert len(schema["optimizer_param_groups"]) == len(named)
+    assert [g[2] for g in schema["optimizer_param_groups"]] == [[i] for i in range(len(named))]
+    # named_parameters() order == state_dict order without the tied key
+    used_ids = [i for i, k in enumerate(named) if by_name[k].used]
+    assert schema["optimizer_state_ids"] == used_ids
