@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=80)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--input", choices=("resident", "prefetch", "sync"), default="resident",
+                    help="resident: batches already in HBM (the headline metric); prefetch: pageable host batches through "
+                         "crct.input_pipeline.DevicePrefetcher; sync: pageable host batches moved by the step adapter's "
+                         "synchronous .to(device), as the reference does (PCIe-inclusive rates for DESIGN.md)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
     ap.add_argument("--graph", action="store_true", help="experimental: replay forward / backward from captured hipGraphs "
@@ -170,11 +174,21 @@ def main():
         opt.set_early(True)                          # ... or start per segment as soon as backward has finished it
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
     ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb) if world > 1 else None
-    pool = [stage(S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i), dev) for i in range(8)]
+    host_pool = [S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i) for i in range(8)]
+    pool = [stage(b, dev) for b in host_pool] if a.input == "resident" else host_pool
     it = [0]
+    feed = None
+    if a.input == "prefetch":
+        from crct.input_pipeline import DevicePrefetcher
+
+        def forever():
+            while True:
+                for b in host_pool:
+                    yield b
+        feed = iter(DevicePrefetcher(forever(), dev, depth=2))
 
     def run_step():
-        batch = pool[it[0] % len(pool)]
+        batch = next(feed) if feed is not None else pool[it[0] % len(pool)]
         it[0] += 1
         loss = step_forward(model, batch, params)[0]
         loss.backward()
@@ -213,7 +227,7 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss" % (a.feat, a.batch, a.vis, a.feat, a.tokens),
-                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input,
                           "gemm_variants": rows}}
         if flop_qa:
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
