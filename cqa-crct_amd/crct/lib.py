@@ -80,6 +80,7 @@ PROTOTYPES = {
     "crct_embed_image_fwd": (C.c_int, [vp] * 12 + [C.c_int] * 2 + [c_f32] + _u8 + [vp]),
     "crct_embed_image_bwd": (C.c_int, [vp] * 15 + [C.c_int] * 2 + _u8 + [vp]),
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
+    "crct_eval_select": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, vp, vp, vp, vp, vp, vp]),
     "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
     "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp]),
     "crct_engine_create": (vp, [C.POINTER(ModelDims), C.c_char_p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -170,7 +170,67 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const CrctHeadArgs a, 
   }
 }
 
+// ------------------------------------------------------------------ evaluation: per-question answer selection
+// One wave per question.  Question q owns the candidate rows [off_q, off_q + num_ans[q]) with off_q = sum of the
+// earlier counts (recomputed by every wave: Q is a few hundred at most).  p0 = softmax(logits)[0] in fp32; the
+// answer is the FIRST row with the largest p0 (torch.argmax), or forced[q] when given; the regressed value and its
+// two error measures are gathered from the chosen row.
+__global__ __launch_bounds__(64) void eval_select_kernel(const float* __restrict__ logits, const float* __restrict__ reg_out,
+                                                         const float* __restrict__ reg_err, const float* __restrict__ reg_terr,
+                                                         const int64_t* __restrict__ num_ans, const int64_t* __restrict__ forced,
+                                                         int Q, long N, float* __restrict__ prob0, int64_t* __restrict__ answers,
+                                                         float* __restrict__ sel_out, float* __restrict__ sel_err,
+                                                         float* __restrict__ sel_terr) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  long off = 0;
+  for (int i = lane; i < q; i += 64) off += num_ans[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o, 64);
+  const long n = num_ans[q];
+  float best = -INFINITY;
+  long best_i = 0x7fffffffffffffffL;
+  for (long j = lane; j < n; j += 64) {
+    const long r = off + j;
+    float p = 0.f;
+    if (r < N) {
+      const float l0 = logits[2 * r], l1 = logits[2 * r + 1], m = fmaxf(l0, l1);
+      const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+      p = e0 / (e0 + e1);
+      if (prob0) prob0[r] = p;
+    }
+    if (p > best) { best = p; best_i = j; }       // strictly greater: the earliest row of this lane wins ties
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const long oi = __shfl_xor(best_i, o, 64);
+    if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+  }
+  if (lane == 0) {
+    long a = forced ? forced[q] : (n > 0 ? best_i : 0);
+    answers[q] = a;
+    const long r = off + a;
+    const bool ok = a >= 0 && a < n && r < N;
+    sel_out[q] = ok ? reg_out[r] : 0.f;
+    sel_err[q] = ok ? reg_err[r] : INFINITY;
+    sel_terr[q] = ok ? reg_terr[r] : INFINITY;
+  }
+}
+
 }  // namespace
+
+extern "C" int crct_eval_select(const float* logits, const float* reg_out, const float* reg_err, const float* reg_terr,
+                                const int64_t* num_ans, const int64_t* forced_answers, int Q, int64_t N, float* prob0,
+                                int64_t* answers, float* sel_out, float* sel_err, float* sel_terr, crct_stream_t stream) {
+  CRCT_REQUIRE(logits && reg_out && reg_err && reg_terr && num_ans && answers && sel_out && sel_err && sel_terr,
+               "eval_select: null argument");
+  CRCT_REQUIRE(Q >= 0 && N >= 0, "eval_select: bad sizes");
+  if (Q == 0) return 0;
+  hipLaunchKernelGGL(eval_select_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, logits, reg_out, reg_err, reg_terr, num_ans,
+                     forced_answers, Q, (long)N, prob0, answers, sel_out, sel_err, sel_terr);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int crct_head_loss(const CrctHeadArgs* args, crct_stream_t stream) {
   CRCT_REQUIRE(args && args->B > 0 && args->Hb > 0, "head_loss: bad sizes");

@@ -229,6 +229,16 @@ typedef struct CrctHeadArgs {
 } CrctHeadArgs;
 int crct_head_loss(const CrctHeadArgs* args, crct_stream_t stream);
 
+/* Evaluation scoring, answer selection per question (replaces the per-question Python loop with .item() syncs of
+ * evaluation.py:281-292): question q owns num_ans[q] consecutive candidate rows of the N scored rows;
+ * prob0 = softmax(logits [N][2])[:, 0] (:249), answers[q] = argmax of prob0 over its rows (first maximum), or
+ * forced_answers[q] when given ('_REGS' question files, :283-284); sel_out / sel_err / sel_terr [Q] gather the regressed
+ * value, its relative error and its tick error (regression[0] / [4] / [2], :255-257) from the chosen row.
+ * prob0 [N] is optional.  Integer results are exact; an out-of-range forced answer selects +inf errors. */
+int crct_eval_select(const float* logits, const float* reg_out, const float* reg_err, const float* reg_terr,
+                     const int64_t* num_ans, const int64_t* forced_answers, int Q, int64_t N, float* prob0,
+                     int64_t* answers, float* sel_out, float* sel_err, float* sel_terr, crct_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW (torch.optim.AdamW semantics as constructed by utils.py:228-249) over
  * the flat fp32 parameter / gradient / moment buffers, refreshing the bf16 weight shadow.

@@ -185,7 +185,7 @@ def heads_and_losses(sd, cfg, params, seq_t, seq_v, R, kind, nsp_label, training
     needs = R[:, 1] == 1                                             # :1588
     nf = needs.to(R.dtype)
     r = regressor(sd, seq_v[:, 0], seq_t[:, 0])                      # raw CLS / IMG states :1599-1600
-    target = R[:, 0] / R[:, 3]                                       # :1617
+    target = R[:, 0] / torch.where(needs, R[:, 3], torch.ones_like(R[:, 3]))   # :1617 (only the needs rows exist there)
     if params["L1"]:
         reg_loss = (r - target).abs()                                # :1526
     else:
@@ -199,8 +199,11 @@ def heads_and_losses(sd, cfg, params, seq_t, seq_v, R, kind, nsp_label, training
     okt = (reg_l1 <= params["tol_margin"]) & needs                   # :1637
     if kind != "L1":
         reg_loss = torch.where(target.abs() > 1, torch.zeros_like(reg_loss), reg_loss)   # :1639-1641
-    reg = [torch.where(needs, r * R[:, 3], torch.zeros_like(r)).detach(),   # :1644 (scatter into zeros)
-           reg_loss * nf, (reg_l1 * nf).detach(),
+    zero = torch.zeros_like(r)
+    # rows that need no regression carry R = [0, False, 0, 0] in real batches (fig_dataloader.py:631): target = 0 / 0;
+    # the reference never computes them (gather / scatter into zeros), so they are selected away, not multiplied away
+    reg = [torch.where(needs, r * R[:, 3], zero).detach(),           # :1644 (scatter into zeros)
+           torch.where(needs, reg_loss, zero), torch.where(needs, reg_l1, zero).detach(),
            (int(ok5.sum()), int(okt.sum())), torch.where(needs, d5, torch.zeros_like(d5)).detach()]
     nsp = None
     if nsp_label is not None:

@@ -245,6 +245,151 @@ def checkpoint_schema_case(vilbert, ed):
         path, os.path.getsize(path) / 1024, len(schema["model_state_dict"]), len(osd["param_groups"]), len(osd["state"])))
 
 
+def make_eval_batches(cfg, n_batches=3, seed=5):
+    """Synthetic evaluation batches in the schema AFTER fig_dataloader.cut_batch_padding (:697-702): per-candidate rows
+    concatenated over the questions, per-question tensors [Q, 1], string lists qid / qa_type."""
+    g = np.random.RandomState(seed)
+    qids = ["S3", "S17", "D6", "D14", "D2", "A2", "M1", "CD7", "D15", "D16", "C5", "S0"]
+    types = ["line", "vbar", "hbar", "dot"]
+    batches, ans_type = [], {}
+    qa = 1000
+    for bi in range(n_batches):
+        Q = 4 + bi
+        num_ans = g.randint(1, 7, size=Q)
+        N = int(num_ans.sum())
+        rows = S.make_batch(N, 7, 5, cfg.v_feature_size, categories=9, vocab_size=cfg.vocab_size, seed=300 + bi)
+        needs = g.rand(Q) < 0.5
+        tol = np.where(needs, g.choice([0.01, 0.05, 0.2], size=Q), 0.0).astype(np.float32)
+        scale = np.where(needs, g.uniform(0.5, 2.0, size=Q), 0.0).astype(np.float32)
+        gt = np.where(needs, g.uniform(-1.5, 1.5, size=Q) * scale, 0.0).astype(np.float32)
+        R = np.zeros((N, 4), dtype=np.float32)
+        off = 0
+        for q in range(Q):
+            R[off:off + num_ans[q]] = [gt[q], 1.0 if needs[q] else 0.0, tol[q], scale[q]]
+            off += num_ans[q]
+        rows["R"] = torch.from_numpy(R)
+        b = dict(rows)
+        b["num_ans"] = torch.from_numpy(num_ans.astype(np.int64)).view(Q, 1)
+        b["id"] = torch.arange(qa, qa + Q, dtype=torch.int64).view(Q, 1)
+        b["gt_id"] = torch.from_numpy(np.array([g.randint(0, n) for n in num_ans], dtype=np.int64)).view(Q, 1)
+        b["needs_reg"] = torch.from_numpy(needs).view(Q, 1)
+        b["tolerance_margin"] = torch.from_numpy(tol).view(Q, 1)
+        b["gt"] = torch.from_numpy(gt).view(Q, 1)
+        b["reg_target"] = torch.from_numpy(np.where(needs, gt / np.where(scale == 0, 1, scale), 0).astype(np.float32)).view(Q, 1)
+        b["qid"] = [qids[g.randint(len(qids))] for _ in range(Q)]
+        b["qa_type"] = [types[g.randint(4)] for _ in range(Q)]
+        for q in range(Q):
+            ans_type[qa + q] = 2 if needs[q] else int(g.randint(0, 3))     # regression questions are answer kind 2 (:483)
+        qa += Q
+        batches.append(b)
+    return batches, ans_type
+
+
+def eval_scoring_case(vilbert, ed):
+    """The reference's own evaluation loop (evaluation.py:199-386) on synthetic candidate batches, single-process gloo
+    group, tensors kept on the CPU (``.cuda()`` is the identity here).  Commits inputs, the per-row forward outputs and
+    the accuracy tables it returned."""
+    import torch.distributed as dist
+    pt = types.ModuleType("pytorch_transformers")
+    tb = types.ModuleType("pytorch_transformers.tokenization_bert")
+    tb.BertTokenizer = type("BertTokenizer", (), {})
+    pt.tokenization_bert = tb
+    sys.modules["pytorch_transformers"] = pt
+    sys.modules["pytorch_transformers.tokenization_bert"] = tb
+    sys.modules.setdefault("pandas", __import__("pandas"))
+    import importlib
+    evaluation = importlib.import_module("evaluation")
+    cfg = C.tiny_config()
+    params = C.default_params(categories=9, L1=True, device=torch.device("cpu"), ddp=True, world_size=1, rank=0,
+                              save_path="/tmp", eval_set="val", start_checkpoint="none/tiny.ckpt", dataset="plotqa")
+    model = build_reference_model(vilbert, ed, cfg, params)
+    S.seeded_fill_(model.state_dict(), base_seed=7)
+    batches, ans_type = make_eval_batches(cfg)
+    # labels designed from the model's own predictions so that every branch of the scoring is hit: classification right /
+    # wrong, regression within 5 % and within the tick tolerance, within one of the two only, wrong candidate chosen
+    model.eval()
+    case = 0
+    for b in batches:
+        Q = b["num_ans"].shape[0]
+        probe = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+        probe["R"] = torch.tensor([[1.0, 1.0, 0.0, 1.0]]).repeat(b["tokens"].shape[0], 1)     # needs=1, scale=1: reg[0] = raw r
+        with torch.no_grad():
+            out = ed.forward(model, probe, params, output_nsp_scores=True, evaluation=True)
+        p0 = torch.softmax(out[4], dim=1)[:, 0]
+        r_raw = out[5][0]
+        off = 0
+        for q in range(Q):
+            n = int(b["num_ans"][q])
+            a = int(torch.argmax(p0[off:off + n]))
+            r = float(r_raw[off + a])
+            kind = case % 6
+            case += 1
+            needs, gt_id, tol, scale, target = False, a, 0.0, 0.0, 0.0
+            if kind == 1:
+                gt_id = (a + 1) % n if n > 1 else a
+            elif kind == 2:
+                needs, scale, target, tol = True, 2.0, r * 1.02, 0.5                 # both measures right
+            elif kind == 3:
+                needs, scale, target, tol = True, 0.5, r * 1.03, abs(r) * 0.001      # 5 % right, tick tolerance wrong
+            elif kind == 4:
+                needs, scale, target, tol = True, 1.5, r * 1.5, abs(r) + 1.0         # 5 % wrong, tick tolerance right
+            elif kind == 5:
+                needs, scale, target, tol = True, 1.0, r * 1.01, 0.5
+                gt_id = (a + 1) % n if n > 1 else a                                  # regression fine, wrong candidate
+            b["R"][off:off + n] = torch.tensor([target * scale, 1.0 if needs else 0.0, tol, scale])
+            b["gt_id"][q, 0] = gt_id
+            b["needs_reg"][q, 0] = needs
+            b["tolerance_margin"][q, 0] = tol
+            b["gt"][q, 0] = target * scale
+            b["reg_target"][q, 0] = target
+            ans_type[int(b["id"][q])] = 2 if needs else (int(b["id"][q]) % 2)
+            off += n
+    model.train()
+
+    class Dataset(object):                      # the two dataset hooks the loop calls (fig_dataloader.py:697-715)
+        def cut_batch_padding(self, item):
+            pass                                # the synthetic batches are already cut
+
+        def get_ans_type(self, qa_ind):
+            return ans_type[int(qa_ind)]
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    old_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        total, breakdown = evaluation.plotqa_evaluate_DDP([{k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in b.items()} for b in batches],
+                                                          Dataset(), params, 4, model, progress=False, csv=False)
+        hist = torch.zeros(13).long()
+        dist_vals = torch.tensor([0.0, 0.01, 0.05, 0.0500001, 0.1, 0.12, 0.2, 0.25, 0.3, 0.55, 0.9, 1.0, 1.00001, 7.0, 0.95])
+        evaluation.reduce_histogram(hist, dist_vals, dist.new_group([0]))
+    finally:
+        torch.Tensor.cuda = old_cuda
+        dist.destroy_process_group()
+    rec = {"total_correct": total.numpy(), "breakdown": breakdown.numpy(), "hist_in": dist_vals.numpy(), "hist_out": hist.numpy(),
+           "n_batches": np.array(len(batches)), "eval_batch_size": np.array(4)}
+    model.eval()
+    for bi, b in enumerate(batches):
+        with torch.no_grad():
+            out = ed.forward(model, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}, params,
+                             output_nsp_scores=True, evaluation=True)
+        rec["b%d.nsp_scores" % bi] = out[4].numpy()
+        for j in (0, 2, 4):
+            rec["b%d.reg%d" % (bi, j)] = out[5][j].numpy()
+        for k, v in b.items():
+            if torch.is_tensor(v):
+                rec["b%d.in.%s" % (bi, k)] = v.numpy()
+        rec["b%d.qid" % bi] = np.array(b["qid"])
+        rec["b%d.qa_type" % bi] = np.array(b["qa_type"])
+        rec["b%d.ans_type" % bi] = np.array([ans_type[int(i)] for i in b["id"].view(-1)])
+    rec["meta"] = np.array(json.dumps(dict(cfg=cfg.to_dict(), params={k: v for k, v in params.items() if k != "device"},
+                                           weight_seed=7)))
+    path = os.path.join(HERE, "tiny_evalscore.npz")
+    np.savez_compressed(path, **rec)
+    print("  wrote %s (%.1f KB); total_correct =\n%s" % (path, os.path.getsize(path) / 1024, total.numpy()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -271,6 +416,7 @@ def main():
     run_case("tiny_eval", tiny, p_tiny, b2, vilbert, ed, save_weights=False, evaluation=True)
     optimizer_case(vilbert, ed)
     checkpoint_schema_case(vilbert, ed)
+    eval_scoring_case(vilbert, ed)
     # ---- full vilbert.json shapes, seeded weights: only inputs / outputs / gradient samples committed
     for nm, B, V, T, Fv in (("full_B4_V36_T20_F1024", 4, 36, 20, 1024),
                             ("full_B4_V36_T20_F2048", 4, 36, 20, 2048),
@@ -288,5 +434,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt_schema":      # regenerate only the checkpoint schema
         sys.modules.setdefault("pandas", __import__("pandas"))
         checkpoint_schema_case(*import_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "evalscore":      # regenerate only the evaluation-scoring fixture
+        eval_scoring_case(*import_reference())
     else:
         main()
