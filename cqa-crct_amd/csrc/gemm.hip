@@ -268,10 +268,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g, const T
 // bias, saved pre-activation, activation-derivative source, residual / upstream-gradient addend, fp32
 // accumulate and the output itself -- is then 16 bytes per lane, consecutive lanes on consecutive chunks
 // of a row (full 128-byte row segments).  Same arithmetic, same Philox element indexing as gemm_epilogue.
-template <int BM, int BN, int WM, int WN, int WTM, int WTN>
+// As many wave rows per pass as the ring holds (RING bytes): usually the whole tile in ONE pass (2 workgroup barriers
+// in all and every thread busy) instead of one pass per wave row.
+template <int BM, int BN, int WM, int RING>
+constexpr int epilogue_passes() {
+  for (int p = 1; p <= WM; p *= 2)
+    if (WM % p == 0 && (BM / p) * (BN + 4) * 4 <= RING) return p;
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING>
 __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
                                                      int wm, int wn, int lane, int tid) {
-  constexpr int R = BM / WM;                 // rows staged per pass (one wave-row of the wave grid)
+  constexpr int P = epilogue_passes<BM, BN, WM, RING>();
+  static_assert(P >= 1, "staging tile must fit into the operand ring");
+  constexpr int R = BM / P;                  // rows staged per pass (WM / P wave rows of the wave grid)
+  constexpr int WR = BM / WM;                // rows of one wave row
   constexpr int LDC = BN + 4;                // floats; 16-byte aligned rows, +4 breaks the power-of-two stride
   constexpr int CPR = BN / 8;                // 8-column chunks per row
   constexpr int NT = WM * WN * 64;
@@ -281,13 +293,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
   const float dscale = g.drop_scale;
   __syncthreads();                           // every wave is done reading the operand ring
 #pragma unroll 1
-  for (int pass = 0; pass < WM; ++pass) {
-    if (wm == pass) {
+  for (int pass = 0; pass < P; ++pass) {
+    if (wm / (WM / P) == pass) {
 #pragma unroll
       for (int b = 0; b < WTM; ++b)
 #pragma unroll
         for (int a = 0; a < WTN; ++a) {
-          const int r = b * 16 + (lane & 15), c = wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
+          const int r = (wm % (WM / P)) * WR + b * 16 + (lane & 15), c = wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
           *reinterpret_cast<f4_t*>(ct + r * LDC + c) = acc[a][b];
         }
     }
@@ -356,7 +368,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
         *dst = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
       }
     }
-    if (pass + 1 < WM) __syncthreads();      // the staging tile is rewritten by the next wave row
+    if (pass + 1 < P) __syncthreads();       // the staging tile is rewritten by the next group of wave rows
   }
 }
 
@@ -481,8 +493,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
       for (int b = 0; b < WTM; ++b) asm volatile("" ::"v"(acc[a][b]));
     return;
   }
-  static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "staging tile must fit into the operand ring");
-  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN>(g, acc, smem, m0, n0, wm, wn, lane, tid);
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
