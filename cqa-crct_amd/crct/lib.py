@@ -76,9 +76,9 @@ PROTOTYPES = {
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
     "crct_attention_force_valu": (None, [C.c_int]),
     "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),
-    "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp]),
+    "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp, vp, C.c_int, vp]),
     "crct_embed_image_fwd": (C.c_int, [vp] * 12 + [C.c_int] * 2 + [c_f32] + _u8 + [vp]),
-    "crct_embed_image_bwd": (C.c_int, [vp] * 15 + [C.c_int] * 2 + _u8 + [vp]),
+    "crct_embed_image_bwd": (C.c_int, [vp] * 15 + [C.c_int] * 2 + _u8 + [vp, vp, C.c_int, vp]),
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
     "crct_eval_select": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, vp, vp, vp, vp, vp, vp]),
     "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),

@@ -23,15 +23,39 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 
 // ------------------------------------------------------------------ wave reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Pure-VALU reductions (DPP inside the 16-lane rows, v_readlane across the four rows); every lane gets the result.
+// They deliberately stay OFF the LDS data path: the __shfl_xor butterfly compiles to ds_bpermute_b32, and with other
+// waves saturating the LDS pipeline a late 16-lane slice of a bpermute result was observed to overwrite the
+// destination register after the compiler had already given that register to another value (tools/embed_stress.py,
+// DESIGN.md section 8).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {      // sum over each row of 16 lanes, in every lane of the row
+  v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);       // row_half_mirror
+  v += dpp_f32<0x140>(v);       // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
   return v;
+}
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 // ------------------------------------------------------------------ Philox4x32-10 (counter based RNG)

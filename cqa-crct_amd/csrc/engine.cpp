@@ -122,6 +122,7 @@ struct crct_engine {
   StreamScratch st, sv;          // backward scratch per data stream (dy ping-pong lives in these)
   StreamScratch st2, sv2;        // second set: layers alternate sets so weight-gradient GEMMs may lag one layer behind
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
+  size_t embed_rows[2], embed_idx[2];   // embedding backward: fp32 row gradients + table indices for the gather-sum pass
   size_t ws_bytes = 0;
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
@@ -485,7 +486,7 @@ struct Run {
     if (!rc) fail(crct_embed_text_bwd(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
                                       P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
                                       G(e->et.ln.g), G(e->et.ln.b), F(partials), b->B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
-                                      dt.site, c->seed, s));
+                                      dt.site, c->seed, F(e->embed_rows[0]), W<int32_t>(e->embed_idx[0]), D.n_types, s));
   }
   void embed_image_bwd(size_t gv) {
     const CrctModelDims& D = e->d;
@@ -496,7 +497,7 @@ struct Run {
     if (!rc) fail(crct_embed_image_bwd(A(gv), A(e->eva.sum), F(e->eva.mean), F(e->eva.rstd), b->image_loc, b->image_target,
                                        P(e->ev.ln.g), A(sc.gc), G(e->ev.color), G(e->ev.wloc), G(e->ev.bloc), G(e->ev.img.b),
                                        G(e->ev.ln.g), G(e->ev.ln.b), F(partials), Mv, D.Hv, dv.thr, dv.scale, dv.site,
-                                       c->seed, s));
+                                       c->seed, F(e->embed_rows[1]), W<int32_t>(e->embed_idx[1]), D.n_color, s));
     lin_wgrad(A(sc.gc), D.Hv, A(e->eva.soft), D.Fv, e->ev.img, Mv);   // no dgrad: features are inputs
   }
 
@@ -773,7 +774,11 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->sv2 = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
   {
     size_t wmax = D.H > D.Hv ? D.H : D.Hv;
-    for (int k = 0; k < 2; ++k) e->partials[k] = ar.take((size_t)8 * CRCT_LN_BWD_MAX_BLOCKS * wmax * 4);
+    for (int k = 0; k < 2; ++k) {
+      e->partials[k] = ar.take((size_t)8 * 4 * CRCT_LN_BWD_MAX_BLOCKS * wmax * 4);   // [7][4 waves x blocks][H]
+    }
+    e->embed_rows[0] = ar.take(Mt * D.H * 4);  e->embed_idx[0] = ar.take(2 * Mt * 4);
+    e->embed_rows[1] = ar.take(Mv * D.Hv * 4); e->embed_idx[1] = ar.take(Mv * 4);
     size_t nmax = 3 * (size_t)D.Hb;
     if ((size_t)D.I > nmax) nmax = D.I;
     if ((size_t)D.Iv > nmax) nmax = D.Iv;

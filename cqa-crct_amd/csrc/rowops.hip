@@ -217,6 +217,67 @@ __device__ __forceinline__ void row_atomic_add(const Row<NCH>& r, float* dst, in
   }
 }
 
+template <int NCH>
+__device__ __forceinline__ void row_store_f32(const Row<NCH>& r, float* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      *reinterpret_cast<float4*>(p + c) = make_float4(r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]);
+      *reinterpret_cast<float4*>(p + c + 4) = make_float4(r.v[i][4], r.v[i][5], r.v[i][6], r.v[i][7]);
+    }
+  }
+}
+
+// table[p][:] += sum of rows[r][:] over the rows r with idx[r] == p   (small tables: position / type / colour
+// embeddings, where thousands of rows hit a few dozen table rows and float atomics serialise).  One workgroup per
+// table row: the 256 threads scan idx in a fixed strided order, compact the matching row numbers into LDS through a
+// block prefix sum (a fixed order: the result does not depend on timing), then every thread sums its 4 columns over
+// the listed rows.  M <= GATHER_MAX_ROWS.
+constexpr int GATHER_MAX_ROWS = 16384;
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
+                                                         float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* list = reinterpret_cast<int*>(smem);              // [M]
+  __shared__ int cnt[256];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  int n = 0;
+  for (int r = tid; r < M; r += 256) n += idx[r] == p;
+  cnt[tid] = n;
+  __syncthreads();
+  // exclusive prefix over the 256 counts (Hillis-Steele in LDS)
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = tid >= o ? cnt[tid - o] : 0;
+    __syncthreads();
+    cnt[tid] += v;
+    __syncthreads();
+  }
+  const int total = cnt[255];
+  if (total == 0) return;
+  int at = cnt[tid] - n;
+  for (int r = tid; r < M; r += 256)
+    if (idx[r] == p) list[at++] = r;
+  __syncthreads();
+  for (int c = tid * 4; c < H; c += 1024) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int i = 0;
+    for (; i + 1 < total; i += 2) {
+      const float4 x = *reinterpret_cast<const float4*>(rows + (long)list[i] * H + c);
+      const float4 y = *reinterpret_cast<const float4*>(rows + (long)list[i + 1] * H + c);
+      a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w;
+      a1.x += y.x; a1.y += y.y; a1.z += y.z; a1.w += y.w;
+    }
+    if (i < total) {
+      const float4 x = *reinterpret_cast<const float4*>(rows + (long)list[i] * H + c);
+      a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(table + (long)p * H + c);
+    float4 o = *dst;
+    o.x += a0.x + a1.x; o.y += a0.y + a1.y; o.z += a0.z + a1.z; o.w += a0.w + a1.w;
+    *dst = o;
+  }
+}
+
 // Sum one per-lane column accumulator over the 4 waves of the block and store to partial[blk][H].
 // `red` is LDS [4][H] floats.
 template <int NCH>
@@ -451,7 +512,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     const float* __restrict__ rstd_p, const int64_t* __restrict__ ids, const int64_t* __restrict__ segs,
     const float* __restrict__ loc, const float* __restrict__ gamma, float* __restrict__ d_word,
     float* __restrict__ d_pos, float* __restrict__ d_type, float* __restrict__ partials, int B, int T, int H, int n_pos,
-    uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+    uint32_t thr, float scale, uint32_t site, uint64_t seed, float* __restrict__ rows_scratch, int* __restrict__ idx_scratch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -467,28 +528,38 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     row_load_bf16(x, sum_p + row * H, H, lane);
     row_apply_dropmask(dy, H, lane, row, thr, scale, site, seed);
     row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
-    row_atomic_add(dy, d_word + ids[row] * (long)H, H, lane);
+    row_atomic_add(dy, d_word + ids[row] * (long)H, H, lane);          // 30k-row table: collisions are rare
+    int pid = -1;
     if (qa) {
       const int fq = first_qa_index(segs + (long)b * T, T, lane);
-      int pid = t - fq;
+      pid = t - fq;
       pid = pid < 0 ? 0 : (pid >= n_pos ? n_pos - 1 : pid);
-      row_atomic_add(dy, d_pos + (long)pid * H, H, lane);
     }
-    if (seg != 0) row_atomic_add(dy, d_type + (seg == -1 ? 0 : seg) * (long)H, H, lane);
+    const int tyid = seg != 0 ? (int)(seg == -1 ? 0 : seg) : -1;
+    if (rows_scratch) {                                                 // position / type sums: gather_sum_kernel afterwards
+      row_store_f32(dy, rows_scratch + row * H, H, lane);
+      if (lane == 0) { idx_scratch[row] = pid; idx_scratch[M + row] = tyid; }
+    } else {
+      if (pid >= 0) row_atomic_add(dy, d_pos + (long)pid * H, H, lane);
+      if (tyid >= 0) row_atomic_add(dy, d_type + (long)tyid * H, H, lane);
+    }
     const float4 lv = *reinterpret_cast<const float4*>(loc + row * 4);
     if (fabsf(lv.x) + fabsf(lv.y) + fabsf(lv.z) + fabsf(lv.w) != 0.f) {
       row_acc(abl, dy);
       row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
     }
   }
-  const long nb = gridDim.x;
-  block_reduce_store(adg, red, partials + (0 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(adb, red, partials + (1 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(abl, red, partials + (2 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw0, red, partials + (3 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw1, red, partials + (4 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw2, red, partials + (5 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw3, red, partials + (6 * nb + blockIdx.x) * H, H, lane, wave);
+  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS in this kernel.
+  // The LDS tree used before lost 16-lane slices of its writes when ds_read_b64_tr_b16 kernels (dgrad / wgrad GEMMs)
+  // shared the CU -- reproduced with tools/embed_stress.py, see DESIGN.md section 8.
+  const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+  row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
+  row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
+  row_store_f32(abl, partials + (2 * nr + pr) * H, H, lane);
+  row_store_f32(aw0, partials + (3 * nr + pr) * H, H, lane);
+  row_store_f32(aw1, partials + (4 * nr + pr) * H, H, lane);
+  row_store_f32(aw2, partials + (5 * nr + pr) * H, H, lane);
+  row_store_f32(aw3, partials + (6 * nr + pr) * H, H, lane);
 }
 
 // ------------------------------------------------------------------------------ image embedding
@@ -522,7 +593,8 @@ __global__ __launch_bounds__(256) void embed_image_bwd_kernel(
     const bf16_t* __restrict__ dy_p, const bf16_t* __restrict__ sum_p, const float* __restrict__ mean_p,
     const float* __restrict__ rstd_p, const float* __restrict__ loc, const int64_t* __restrict__ target,
     const float* __restrict__ gamma, bf16_t* __restrict__ dsum_p, float* __restrict__ d_color,
-    float* __restrict__ partials, int M, int H, uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+    float* __restrict__ partials, int M, int H, uint32_t thr, float scale, uint32_t site, uint64_t seed,
+    float* __restrict__ rows_scratch, int* __restrict__ idx_scratch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -535,19 +607,27 @@ __global__ __launch_bounds__(256) void embed_image_bwd_kernel(
     row_apply_dropmask(dy, H, lane, row, thr, scale, site, seed);
     row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
     row_store_bf16(dy, dsum_p + row * H, H, lane);
-    row_atomic_add(dy, d_color + target[row] * (long)H, H, lane);
+    if (rows_scratch) {                                                 // colour sums: gather_sum_kernel afterwards
+      row_store_f32(dy, rows_scratch + row * H, H, lane);
+      if (lane == 0) idx_scratch[row] = (int)target[row];
+    } else {
+      row_atomic_add(dy, d_color + target[row] * (long)H, H, lane);
+    }
     const float4 lv = *reinterpret_cast<const float4*>(loc + row * 4);
     row_acc(abl, dy);       // = d b_loc = d b_img (both are plain column sums of d_sum)
     row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
   }
-  const long nb = gridDim.x;
-  block_reduce_store(adg, red, partials + (0 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(adb, red, partials + (1 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(abl, red, partials + (2 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw0, red, partials + (3 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw1, red, partials + (4 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw2, red, partials + (5 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(aw3, red, partials + (6 * nb + blockIdx.x) * H, H, lane, wave);
+  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS in this kernel.
+  // The LDS tree used before lost 16-lane slices of its writes when ds_read_b64_tr_b16 kernels (dgrad / wgrad GEMMs)
+  // shared the CU -- reproduced with tools/embed_stress.py, see DESIGN.md section 8.
+  const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+  row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
+  row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
+  row_store_f32(abl, partials + (2 * nr + pr) * H, H, lane);
+  row_store_f32(aw0, partials + (3 * nr + pr) * H, H, lane);
+  row_store_f32(aw1, partials + (4 * nr + pr) * H, H, lane);
+  row_store_f32(aw2, partials + (5 * nr + pr) * H, H, lane);
+  row_store_f32(aw3, partials + (6 * nr + pr) * H, H, lane);
 }
 
 inline int nch_for(int H) { return (H / 8 + 63) / 64; }
@@ -681,22 +761,30 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
                                         float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
                                         float* d_gamma, float* d_beta, float* partials, int B, int T, int H, int n_pos,
                                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
-                                        crct_stream_t stream) {
+                                        float* rows_scratch, int32_t* idx_scratch, int n_types, crct_stream_t stream) {
   CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_text_bwd: H=%d must be a positive multiple of 8", H);
   const long M = (long)B * T;
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (!idx_scratch || M > GATHER_MAX_ROWS || n_types <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = crct_layernorm_bwd_blocks((int)M);
   const size_t lds = (size_t)4 * H * sizeof(float);
   DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
-                                     partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed));
+                                     partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch,
+                                     rows_scratch ? idx_scratch : nullptr));
   CRCT_CHECK_HIP(hipGetLastError());
+  if (rows_scratch) {
+    const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, (int)M, H, d_pos);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(n_types), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch + M, (int)M, H, d_type);
+    CRCT_CHECK_HIP(hipGetLastError());
+  }
   FinalizeArgs fa = {};
   fa.out[0] = d_gamma; fa.out[1] = d_beta; fa.out[2] = d_bloc;
   fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
   for (int k = 0; k < 4; ++k) { fa.out[3 + k] = d_wloc ? d_wloc + k : nullptr; fa.stride[3 + k] = 4; }
-  fa.Q = 7; fa.nblk = nb; fa.H = H; fa.accumulate = 1; fa.partials = partials;
+  fa.Q = 7; fa.nblk = nb * ROWS_PER_BLOCK; fa.H = H; fa.accumulate = 1; fa.partials = partials;
   return launch_finalize(fa, s);
 }
 
@@ -719,27 +807,34 @@ extern "C" int crct_embed_image_bwd(const void* dy, const void* sum_saved, const
                                     const float* loc, const int64_t* target, const float* gamma, void* d_sum,
                                     float* d_color, float* d_wloc, float* d_bloc, float* d_bimg, float* d_gamma,
                                     float* d_beta, float* partials, int M, int H, uint32_t drop_thr, float drop_scale,
-                                    uint32_t drop_site, uint64_t seed, crct_stream_t stream) {
+                                    uint32_t drop_site, uint64_t seed, float* rows_scratch, int32_t* idx_scratch, int n_color,
+                                    crct_stream_t stream) {
   CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_image_bwd: H=%d must be a positive multiple of 8", H);
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (!idx_scratch || M > GATHER_MAX_ROWS || n_color <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = crct_layernorm_bwd_blocks(M);
   const size_t lds = (size_t)4 * H * sizeof(float);
   DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, loc, target, gamma, (bf16_t*)d_sum, d_color,
-                                     partials, M, H, drop_thr, drop_scale, drop_site, seed));
+                                     partials, M, H, drop_thr, drop_scale, drop_site, seed, rows_scratch,
+                                     rows_scratch ? idx_scratch : nullptr));
   CRCT_CHECK_HIP(hipGetLastError());
+  if (rows_scratch) {
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(n_color), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, M, H, d_color);
+    CRCT_CHECK_HIP(hipGetLastError());
+  }
   // two finalize passes share the column-sum partial (index 2): b_loc and b_img
   FinalizeArgs fa = {};
   fa.out[0] = d_gamma; fa.out[1] = d_beta; fa.out[2] = d_bloc;
   fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
   for (int k = 0; k < 4; ++k) { fa.out[3 + k] = d_wloc ? d_wloc + k : nullptr; fa.stride[3 + k] = 4; }
-  fa.Q = 7; fa.nblk = nb; fa.H = H; fa.accumulate = 1; fa.partials = partials;
+  fa.Q = 7; fa.nblk = nb * ROWS_PER_BLOCK; fa.H = H; fa.accumulate = 1; fa.partials = partials;
   if (launch_finalize(fa, s)) return 1;
   if (d_bimg) {
     FinalizeArgs fb = {};
-    fb.out[0] = d_bimg; fb.stride[0] = 1; fb.Q = 1; fb.nblk = nb; fb.H = H; fb.accumulate = 1;
-    fb.partials = partials + (size_t)2 * nb * H;
+    fb.out[0] = d_bimg; fb.stride[0] = 1; fb.Q = 1; fb.nblk = nb * ROWS_PER_BLOCK; fb.H = H; fb.accumulate = 1;
+    fb.partials = partials + (size_t)2 * nb * ROWS_PER_BLOCK * H;
     return launch_finalize(fb, s);
   }
   return 0;

@@ -164,15 +164,18 @@ int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* lo
                         int B, int T, int H, int n_pos, float eps,
                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                         crct_stream_t stream);
-/* Backward: scatter-adds (fp32 atomics) into the word / position / type tables, reduces the
- * loc-Linear and LayerNorm parameter gradients.  partials: fp32 [7][nblk][H], nblk = crct_layernorm_bwd_blocks(B*T).
- * All parameter-gradient outputs are ACCUMULATED into (caller zeroes the gradient buffer per step). */
+/* Backward: scatter-add (fp32 atomics) into the word table; position / type tables (a few dozen rows hit by
+ * thousands of tokens) through rows_scratch (fp32 [B*T][H]) + idx_scratch (int32 [2][B*T]) and a deterministic
+ * gather-sum pass (one workgroup per table row); with rows_scratch == NULL they use atomics as well.  Reduces the
+ * loc-Linear and LayerNorm parameter gradients.  partials: fp32 [7][4 * nblk][H], nblk = crct_layernorm_bwd_blocks(B*T).
+ * n_types = rows of the type table.  All parameter-gradient outputs are ACCUMULATED (caller zeroes per step). */
 int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
                         const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
                         float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
                         float* d_gamma, float* d_beta, float* partials,
                         int B, int T, int H, int n_pos,
                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                        float* rows_scratch, int32_t* idx_scratch, int n_types,
                         crct_stream_t stream);
 
 /* Image embeddings: BertImageEmbeddings.forward (dataset 'plotqa'), vilbert.py:1474-1496.
@@ -185,14 +188,17 @@ int crct_embed_image_fwd(const void* img_lin, const float* loc, const int64_t* t
                          int M, int H, float eps,
                          uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                          crct_stream_t stream);
-/* Backward: d_sum (bf16 [M][H], feeds the wgrad GEMM of new_image_embeddings), color scatter-add,
- * loc-Linear / LayerNorm / image-Linear-bias gradients (accumulated).  partials: fp32 [8][nblk][H]. */
+/* Backward: d_sum (bf16 [M][H], feeds the wgrad GEMM of new_image_embeddings), colour-table sums (gather-sum pass
+ * through rows_scratch fp32 [M][H] + idx_scratch int32 [M] over the n_color table rows, or fp32 atomics when
+ * rows_scratch == NULL), loc-Linear / LayerNorm / image-Linear-bias gradients (accumulated).
+ * partials: fp32 [7][4 * nblk][H]. */
 int crct_embed_image_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
                          const float* loc, const int64_t* target, const float* gamma,
                          void* d_sum, float* d_color, float* d_wloc, float* d_bloc, float* d_bimg,
                          float* d_gamma, float* d_beta, float* partials,
                          int M, int H,
                          uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                         float* rows_scratch, int32_t* idx_scratch, int n_color,
                          crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
