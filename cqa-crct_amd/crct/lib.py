@@ -18,7 +18,7 @@ class GemmArgs(C.Structure):
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ld_aux", c_i64), ("ld_add", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ta", c_i32), ("tb", c_i32), ("act", c_i32), ("dact", c_i32),
                 ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
-                ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64)]
+                ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp)]
 
 
 class HeadArgs(C.Structure):

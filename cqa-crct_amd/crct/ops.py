@@ -32,7 +32,7 @@ def _drop(p, site):
 
 def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
          preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
-         accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0):
+         accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None):
     lib = L.load()
     _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
     if out is None:
@@ -49,15 +49,18 @@ def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=No
     g.act, g.dact, g.c_is_f32, g.accumulate, g.tile, g.alpha = ACT[act], ACT[dact], int(out.dtype == torch.float32), int(accumulate), tile, alpha
     g.drop_thr, g.drop_scale, g.drop_site = _drop(p_drop, site)
     g.seed = seed
+    g.rowsum_out = L.ptr(rowsum_out)
     L.check(lib.crct_gemm_bf16(C.byref(g), L.current_stream()), "gemm")
     return out
 
 
 def gemm_wgrad_grouped(problems):
-    """``problems`` = [(dy[R][N], x[R][K], out[N][K] fp32)]: out += dy^T x for every entry, ONE launch."""
+    """``problems`` = [(dy[R][N], x[R][K], out[N][K] fp32[, db[N] fp32])]: out += dy^T x (db += colsum dy), ONE launch."""
     lib = L.load()
     arr = (L.GemmArgs * len(problems))()
-    for g, (dy, x, out) in zip(arr, problems):
+    for g, prob in zip(arr, problems):
+        dy, x, out = prob[:3]
+        g.rowsum_out = L.ptr(prob[3]) if len(prob) > 3 else None      # optional bias gradient [N] += column sums of dy
         _chk(dy, torch.bfloat16), _chk(x, torch.bfloat16), _chk(out, torch.float32)
         R, N = dy.shape
         K = x.shape[1]

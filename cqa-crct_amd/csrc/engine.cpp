@@ -241,6 +241,7 @@ struct Run {
     parity ^= 1;
   }
   std::vector<CrctGemmArgs> pending;   // weight-gradient GEMMs of the current layer, launched as ONE grouped grid
+  bool defer_wgrad = true;             // false: launch every weight gradient immediately on s (buffers are recycled)
   int tick = 0, ordered_tick = -1;     // launches enqueued on s / the tick sw was last ordered after (skip redundant events)
   void wgrad_after_main() {            // sw sees what s produced
     if (rc || sw == s) return;
@@ -290,13 +291,21 @@ struct Run {
     gemm(x, ldx, false, PB(l.w), l.in, false, y, ldy, M, l.out, l.in, o);
   }
   // dW[out][in] += dy^T x
-  void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M) {
+  // with_bias: also db[out] += column sums of dy.  When the contraction length qualifies for the LDS-DMA kernel the
+  // sums come out of the weight-gradient kernel itself (CrctGemmArgs.rowsum_out); otherwise a column-sum launch.
+  void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M, bool with_bias = false) {
+    if (rc) return;
+    const bool fold = with_bias && M % 64 == 0 && l.in % 8 == 0 && l.out % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0;
+    if (with_bias && !fold) bias_grad(dy, lddy, l, M);
     if (rc) return;
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = x; g.C = G(l.w); g.lda = lddy; g.ldb = ldx; g.ldc = l.in; g.M = l.out; g.N = l.in; g.K = M;
     g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f;
-    if (sw == s) { ++tick; fail(crct_gemm_bf16(&g, s)); return; }     // no side stream: in order, one by one
+    if (fold) g.rowsum_out = G(l.b);
+    if (!defer_wgrad) { ++tick; fail(crct_gemm_bf16(&g, s)); return; }     // head chain: in order, right now
+    // queued also without a side stream (sw == s): the same groups, hence the same kernels and summation orders,
+    // in every stream mode -- results stay bit-identical across modes
     pending.push_back(g);
     if (pending.size() == 8) flush_wgrads();
   }
@@ -307,6 +316,7 @@ struct Run {
   // launch the queued weight-gradient GEMMs on the side stream, ordered after everything enqueued on s so far
   void flush_wgrads() {
     if (rc || pending.empty()) return;
+    if (sw == s) ++tick;
     wgrad_after_main();
     if (!rc) fail(crct_gemm_bf16_grouped(pending.data(), (int)pending.size(), sw));
     pending.clear();
@@ -377,8 +387,7 @@ struct Run {
     lin_wgrad(A(dl), H, A(a.h), I, p.down, M);
     Opt o; o.dact_src = A(a.u); o.dact = ACT_GELU; o.ld_aux = I;
     lin_dgrad(A(dl), H, p.down, M, A(sc.du), I, o);
-    bias_grad(A(sc.du), I, p.up, M);
-    lin_wgrad(A(sc.du), I, A(x), H, p.up, M);
+    lin_wgrad(A(sc.du), I, A(x), H, p.up, M, true);
     Opt o2; o2.addend = A(sc.dres_a); o2.ld_add = H;
     lin_dgrad(A(sc.du), I, p.up, M, A(gx), H, o2);
   }
@@ -398,8 +407,7 @@ struct Run {
     proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1));
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
              A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
-    bias_grad(A(sc.dqkv), 3 * H, p.qkv, M);
-    lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M);
+    lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M, true);
     Opt o; o.addend = A(sc.dres_b); o.ld_add = H;
     lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
     layer_end();
@@ -448,12 +456,10 @@ struct Run {
     // each stream's dqkv buffer has been written by BOTH attention backward kernels
     if (!rc) fail(order_streams(e, V.s, s));
     if (!V.rc) V.fail(order_streams(e, s, V.s));
-    V.bias_grad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv);
-    V.lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv);
+    V.lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv, true);
     Opt ov; ov.addend = A(sv.dres_b); ov.ld_add = D.Hv;
     V.lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
-    bias_grad(A(st.dqkv), 3 * Hb, p.qkv2, Mt);
-    lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt);
+    lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt, true);
     Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
     lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
     V.layer_end();
@@ -571,8 +577,10 @@ struct Run {
     // be called alone for evaluation
     // the head's small GEMM chain recycles two scratch buffers every other call: keep its weight-gradient
     // GEMMs on this stream (in order) instead of the side stream
-    struct SwGuard { Run* r; hipStream_t keep; ~SwGuard() { r->sw = keep; } } guard{this, sw};
+    struct SwGuard { Run* r; hipStream_t keep; ~SwGuard() { r->sw = keep; r->defer_wgrad = true; } } guard{this, sw};
+    flush_wgrads();
     sw = s;
+    defer_wgrad = false;
     heads_fwd_grad_only(logits, reg, stats);
     if (rc) return;
     if (hipMemsetAsync(A(gt), 0, (size_t)B * b->T * D.H * 2, s) != hipSuccess ||

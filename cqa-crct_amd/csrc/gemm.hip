@@ -445,6 +445,16 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
 #pragma unroll
     for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
 
+  // optional row sums of A' (bias gradient of a weight-gradient GEMM): only the workgroups of the first tile column
+  // compute them; the WN waves of a wave row share the K sub-steps round-robin, so the extra MFMAs are 1/WN of a wave's
+  const bool do_rs = g.rowsum_out != nullptr && tile_n == 0;
+  f4_t accb[WTM];
+#pragma unroll
+  for (int b = 0; b < WTM; ++b) accb[b] = f4_t{0.f, 0.f, 0.f, 0.f};
+  bf8_t ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
   const int nk = g.K / BK;
   auto issue = [&](int kt, int st) {
     char* base = smem + st * STAGE + wave * 1024;
@@ -482,6 +492,10 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
 #pragma unroll
         for (int b = 0; b < WTM; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[a], fm[b], acc[a][b], 0, 0, 0);
+      if (do_rs && (((kt << 1) + (ks >> 5)) & (WN - 1)) == wn) {
+#pragma unroll
+        for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[b], accb[b], 0, 0, 0);
+      }
     }
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
@@ -492,6 +506,25 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
 #pragma unroll
       for (int b = 0; b < WTM; ++b) asm volatile("" ::"v"(acc[a][b]));
     return;
+  }
+  if (do_rs) {
+    // every row of the 16x16 result holds the same sums: row 0 lives in lanes 0..15, register 0
+    static_assert((WN & (WN - 1)) == 0 && WN * BM * 4 <= NS * STAGE, "row-sum staging");
+    float* rs = reinterpret_cast<float*>(smem);            // [WN][BM]
+    __syncthreads();                                       // every wave is done reading the operand ring
+    if (lane < 16) {
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) rs[wn * BM + wm * (BM / WM) + b * 16 + lane] = accb[b][0];
+    }
+    __syncthreads();
+    for (int i = tid; i < BM; i += NW * 64) {
+      if (m0 + i < g.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) v += rs[w * BM + i];  // fixed order: reproducible
+        g.rowsum_out[m0 + i] += v;
+      }
+    }
   }
   gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
@@ -510,7 +543,7 @@ struct GroupArgs {
   int n;
   int tile_begin[GROUP_MAX + 1];       // first block of every problem (multiples of 8: a problem starts on XCD 0)
   TileMap map[GROUP_MAX];              // per-problem XCD-aware block -> tile map, as for single launches
-  struct P { const void* A; const void* B; void* C; long lda, ldb, ldc; int M, N, K, c_is_f32, accumulate; } p[GROUP_MAX];
+  struct P { const void* A; const void* B; void* C; float* rowsum; long lda, ldb, ldc; int M, N, K, c_is_f32, accumulate; } p[GROUP_MAX];
 };
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
@@ -526,7 +559,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
   g.A = ga.p[pi].A; g.B = ga.p[pi].B; g.C = ga.p[pi].C;
   g.lda = ga.p[pi].lda; g.ldb = ga.p[pi].ldb; g.ldc = ga.p[pi].ldc;
   g.M = ga.p[pi].M; g.N = ga.p[pi].N; g.K = ga.p[pi].K; g.ta = TA; g.tb = TB;
-  g.c_is_f32 = ga.p[pi].c_is_f32; g.accumulate = ga.p[pi].accumulate; g.alpha = 1.0f;
+  g.c_is_f32 = ga.p[pi].c_is_f32; g.accumulate = ga.p[pi].accumulate; g.alpha = 1.0f; g.rowsum_out = ga.p[pi].rowsum;
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
 }
 
@@ -543,7 +576,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
     ga.map[i] = make_tile_map(g.M, g.N, BM, BN, &grid);
     ga.map[i].dbg = 0;
     total += grid;
-    ga.p[i] = {g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.M, g.N, g.K, g.c_is_f32, g.accumulate};
+    ga.p[i] = {g.A, g.B, g.C, g.rowsum_out, g.lda, g.ldb, g.ldc, g.M, g.N, g.K, g.c_is_f32, g.accumulate};
   }
   ga.tile_begin[n] = total;
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
@@ -695,6 +728,7 @@ extern "C" int crct_prof_read(int variant, long* count, double* flops, double* m
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
   const bool pipe = pipe_ok(g) && !g_force_generic;
+  if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
   if (t > 12) t = 12;
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);

@@ -54,6 +54,10 @@ typedef struct CrctGemmArgs {
   float drop_scale;         /* 1/(1-p) */
   uint32_t drop_site;
   uint64_t seed;
+  float* rowsum_out;        /* fp32 [M] or NULL: rowsum_out[m] += sum_k A'[m][k] (A' = A as the GEMM reads it).  For a
+                               weight gradient dW = dy^T x (ta = tb = 1) this is the BIAS gradient, computed by the
+                               same kernel from the dy tiles it already holds (one extra MFMA against a fragment of
+                               ones).  LDS-DMA kernel only (K % 64 == 0); other shapes are rejected. */
 } CrctGemmArgs;
 
 int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);

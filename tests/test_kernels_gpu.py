@@ -109,6 +109,28 @@ def test_gemm_wgrad_grouped(R):
             assert rel_err(out, solo) < 2e-5
 
 
+@pytest.mark.parametrize("R", [1600, 2880])
+def test_gemm_wgrad_with_bias_gradient(R, gemm_path):
+    # rowsum_out: the bias gradient (column sums of dy) out of the weight-gradient kernel itself, single and grouped
+    if gemm_path == "generic":
+        pytest.skip("row sums exist in the LDS-DMA kernel only")
+    shapes = [(768, 3072), (2304, 768), (1024, 1024)]
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy, x = bf(rand(R, N, seed=60 + i)), bf(rand(R, K, seed=70 + i))
+        out, db = torch.zeros(N, K, device=DEV), torch.full((N,), 2.0, device=DEV)
+        probs.append((dy, x, out, db))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0) + 2.0))
+    ops.gemm_wgrad_grouped(probs)
+    for (_, _, out, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(out, rw) < 2e-3 and rel_err(db, rb) < 2e-3
+    for tile in (-1, 9, 12, 3):
+        dy, x, _, _ = probs[0]
+        out, db = torch.zeros(768, 3072, device=DEV), torch.zeros(768, device=DEV)
+        ops.gemm(dy, x, 768, 3072, R, ta=True, tb=True, lda=768, ldb=3072, out=out, accumulate=True, tile=tile, rowsum_out=db)
+        assert rel_err(out, refs[0][0]) < 2e-3 and rel_err(db, refs[0][1] - 2.0) < 2e-3, tile
+
+
 def test_gemm_strided_rows():
     # CLS-row gather: A rows are hidden_states[:, 0] with row stride T*H
     B, T, H, N = 80, 20, 768, 1024
