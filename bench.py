@@ -40,8 +40,8 @@ FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9}
 VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
               5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x256w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
-              10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "reg128x128", 14: "reg128x64",
-              15: "reg64x128", 16: "reg64x64"}
+              10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 16: "reg128x128", 17: "reg128x64",
+              18: "reg64x128", 19: "reg64x64"}
 
 
 def parse():
@@ -85,7 +85,7 @@ def gemm_profile(model, run_step, n_steps):
     core.use_graph = graph_mode
     lib.crct_prof_enable(0)
     rows = []
-    for v in range(48):
+    for v in range(72):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue

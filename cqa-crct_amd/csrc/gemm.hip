@@ -408,7 +408,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   CRCT_VMCNT_CASE(0) CRCT_VMCNT_CASE(1) CRCT_VMCNT_CASE(2) CRCT_VMCNT_CASE(3) CRCT_VMCNT_CASE(4) CRCT_VMCNT_CASE(5)
   CRCT_VMCNT_CASE(6) CRCT_VMCNT_CASE(7) CRCT_VMCNT_CASE(8) CRCT_VMCNT_CASE(9) CRCT_VMCNT_CASE(10) CRCT_VMCNT_CASE(11)
   CRCT_VMCNT_CASE(12) CRCT_VMCNT_CASE(13) CRCT_VMCNT_CASE(14) CRCT_VMCNT_CASE(15) CRCT_VMCNT_CASE(16) CRCT_VMCNT_CASE(18)
-  CRCT_VMCNT_CASE(20) CRCT_VMCNT_CASE(24)
+  CRCT_VMCNT_CASE(20) CRCT_VMCNT_CASE(21) CRCT_VMCNT_CASE(24) CRCT_VMCNT_CASE(27) CRCT_VMCNT_CASE(28) CRCT_VMCNT_CASE(30)
+  CRCT_VMCNT_CASE(32) CRCT_VMCNT_CASE(36) CRCT_VMCNT_CASE(40) CRCT_VMCNT_CASE(48)
   else static_assert(N == 0, "add the vmcnt literal");
 #undef CRCT_VMCNT_CASE
 }
@@ -472,7 +473,9 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
   int st = 0, st_next = NS - 1;      // stage holding tile kt; stage the next prefetch goes to
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = (nk - 1 < kt + NS - 2 ? nk - 1 : kt + NS - 2) - kt;     // younger tiles that may stay in flight
-    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    if (NS >= 6 && ahead >= 4) wait_vmcnt<4 * L>();
+    else if (NS >= 5 && ahead >= 3) wait_vmcnt<3 * L>();
+    else if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -692,7 +695,8 @@ struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
-  double flops[48] = {0}; long count[48] = {0};
+  static constexpr int NV = 72;        // (16 LDS-DMA configurations + 4 register-staged + spare) x {fwd, dgrad, wgrad}
+  double flops[NV] = {0}; long count[NV] = {0};
 } g_prof;
 }  // namespace
 
@@ -706,13 +710,13 @@ extern "C" int crct_prof_enable(int on) {
 }
 extern "C" int crct_prof_reset(void) {
   g_prof.used = 0;
-  for (int i = 0; i < 48; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
+  for (int i = 0; i < Prof::NV; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
   return 0;
 }
-// variant = config * 3 + {0: fwd (NT), 1: dgrad (tb), 2: wgrad (ta, tb)}; config 0..12 = LDS-DMA kernel
+// variant = config * 3 + {0: fwd (NT), 1: dgrad (tb), 2: wgrad (ta, tb)}; config 0..15 = LDS-DMA kernel, 16..19 = register-staged
 // configurations, 13..16 = register-staged kernel tiles 0..3.  Synchronises the events.
 extern "C" int crct_prof_read(int variant, long* count, double* flops, double* ms) {
-  if (variant < 0 || variant >= 48) return 1;
+  if (variant < 0 || variant >= Prof::NV) return 1;
   double t = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     if (g_prof.slots[i].variant != variant) continue;
@@ -730,7 +734,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   const bool pipe = pipe_ok(g) && !g_force_generic;
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 12) t = 12;
+  if (t > 14) t = 12;
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
   ProfSlot* slot = nullptr;
@@ -741,7 +745,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       g_prof.slots.push_back(ns);
     }
     slot = &g_prof.slots[g_prof.used++];
-    slot->variant = (pipe ? t : 13 + (t & 3)) * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
+    slot->variant = (pipe ? t : 16 + (t & 3)) * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
     g_prof.count[slot->variant] += 1;
     g_prof.flops[slot->variant] += 2.0 * g.M * g.N * g.K;
     hipEventRecord(slot->a, s);
@@ -761,6 +765,8 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       case 9: e = launch_pipe<4, 4, 2, 4, 2>(g, s); break;     // 128x128, 8 waves, 2 stages (2 blocks / CU)
       case 10: e = launch_pipe<4, 2, 2, 4, 3>(g, s); break;    // 128x64, 8 waves
       case 11: e = launch_pipe<2, 4, 2, 4, 3>(g, s); break;    // 64x128, 8 waves
+      case 13: e = launch_pipe<4, 2, 4, 2, 4>(g, s); break;    // 128x64, 8 waves (4x2), 4 stages: long K, one block per CU
+      case 14: e = launch_pipe<4, 2, 4, 2, 6>(g, s); break;    // 128x64, 8 waves (4x2), 6 stages
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
   } else {

@@ -1,11 +1,16 @@
+# usage (on the GPU box): bash tools/pmc_gemm.sh <name> <shape index> <tile> ; prints per-kernel counter sums
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-run() { # name shape tile generic
-  for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
-    rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/pmc_$1 -- ./tools/gemm_lab.bin 3 $2 $3 $4 > /dev/null 2>&1
-  done
-}
-run ffnup_t3_gen 1 3 1
-run ffnup_t1_gen 1 1 1
-run ffnup_t0_pipe 1 0 0
-run big_t1_gen 13 1 1
-ls gpurun_out/pmc_ffnup_t3_gen/*/ | head
+name=$1; shape=$2; tile=$3
+for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
+  rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/pmc_$name -- ./tools/gemm_lab.bin 3 $shape $tile 0 > /dev/null 2>&1
+done
+python3 - gpurun_out/pmc_$name <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(float); n = collections.defaultdict(int)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "gemm" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+print(sys.argv[1], {k: round(v / max(n[k], 1)) for k, v in sorted(acc.items())})
+PY
+rm -rf gpurun_out/pmc_$name
