@@ -82,6 +82,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
         self.overlap = False
+        self.overlap_workgroups = 256        # throttle of the overlapped launches (one workgroup per CU), 0 = full width
         # early mode (with overlap): the update of a segment starts as soon as the backward pass has finished that
         # segment's gradients (the engine marks it with events), i.e. it overlaps the REST OF BACKWARD instead of the
         # next forward; identical arithmetic, only the start time on the GPU moves
@@ -119,13 +120,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._upload_done.record()
             self._last = key
 
-    def _launch(self, b0, b1, inv_scale, stream):
+    def _launch(self, b0, b1, inv_scale, stream, max_workgroups=0):
         core, g0 = self.core, self.param_groups[0]
         L.check(L.load().crct_adamw_step(core.flat_params.data_ptr(), core.flat_grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                          core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
                                          self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr() + 4 * b0,
                                          self._blk_off.data_ptr() + 8 * b0, b1 - b0, g0["betas"][0], g0["betas"][1], g0["eps"],
-                                         self._step, L.ptr(inv_scale), stream), "adamw_step")
+                                         self._step, L.ptr(inv_scale), int(max_workgroups), stream), "adamw_step")
 
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
@@ -173,7 +174,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     for w in done[sgi]:
                         w(self._opt_stream)
                 if b1 > b0:
-                    self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream)
+                    self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, self.overlap_workgroups)
                 self._events[sgi].record(self._opt_stream)
             if done is not None:
                 self._opt_stream.wait_stream(cur)             # the gradient memset that follows must not pass backward's tail
