@@ -61,6 +61,7 @@ def parse():
                     help="resident: batches already in HBM (the headline metric); prefetch: pageable host batches through "
                          "crct.input_pipeline.DevicePrefetcher; sync: pageable host batches moved by the step adapter's "
                          "synchronous .to(device), as the reference does (PCIe-inclusive rates for DESIGN.md)")
+    ap.add_argument("--fuse-zero-grad", action="store_true", help="AdamW zeroes the gradients it consumes (measured: no gain)")
     ap.add_argument("--adamw-wgs", type=int, default=-1, help="workgroups per overlapped AdamW launch (0 = full width; default: the optimizer's)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
@@ -171,6 +172,7 @@ def main():
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1
+    opt.fuse_zero_grad = bool(a.fuse_zero_grad)
     if a.adamw_wgs >= 0:
         opt.overlap_workgroups = a.adamw_wgs
     if a.opt_early and opt.overlap:

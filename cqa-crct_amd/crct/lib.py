@@ -82,7 +82,7 @@ PROTOTYPES = {
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
     "crct_eval_select": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, vp, vp, vp, vp, vp, vp]),
     "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
-    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, C.c_int, vp]),
+    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, C.c_int, C.c_int, vp]),
     "crct_engine_create": (vp, [C.POINTER(ModelDims), C.c_char_p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crct_engine_destroy": (None, [vp]),
     "crct_engine_workspace_bytes": (C.c_size_t, [vp]),

@@ -82,6 +82,7 @@ class CrctModel(nn.Module):
         self._ddp = None
         self._param_events = None                    # set by FusedAdamW in overlap mode
         self._seg_done = None
+        self._grads_dirty = True
         self._grad_waits = None
         self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
@@ -229,6 +230,7 @@ class CrctModel(nn.Module):
         if self._opt_stream is not None:             # overlapped optimizer update / gradient memset of the previous step
             torch.cuda.current_stream().wait_stream(self._opt_stream)
         self._ensure_grad_views()
+        self._grads_dirty = True                     # gradients are being accumulated again (optimizer bookkeeping)
         eng = self._engine
         self._grad_waits = None
         if self._ddp is None and self.record_segment_events and not step.get("use_graph"):

@@ -83,6 +83,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
         self.overlap = False
         self.overlap_workgroups = 256        # throttle of the overlapped launches (one workgroup per CU), 0 = full width
+        # the update zeroes every gradient element it has consumed; the zero_grad() that follows is then free.  Off by
+        # default: torch optimizers leave .grad untouched in step() (a caller may still want to read it there)
+        self.fuse_zero_grad = False
         # early mode (with overlap): the update of a segment starts as soon as the backward pass has finished that
         # segment's gradients (the engine marks it with events), i.e. it overlaps the REST OF BACKWARD instead of the
         # next forward; identical arithmetic, only the start time on the GPU moves
@@ -126,7 +129,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                          core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
                                          self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr() + 4 * b0,
                                          self._blk_off.data_ptr() + 8 * b0, b1 - b0, g0["betas"][0], g0["betas"][1], g0["eps"],
-                                         self._step, L.ptr(inv_scale), int(max_workgroups), stream), "adamw_step")
+                                         self._step, L.ptr(inv_scale), int(max_workgroups), int(self.fuse_zero_grad), stream), "adamw_step")
 
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
@@ -184,6 +187,9 @@ class FusedAdamW(torch.optim.Optimizer):
             self._upload_hyper()
             self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
         core.note_params_updated_natively()
+        self._grads_cleared = bool(self.fuse_zero_grad)
+        if self._grads_cleared:
+            core._grads_dirty = False                         # until the next backward pass
         return loss
 
     def synchronize(self):
@@ -193,6 +199,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         # one memset; .grad views stay attached (set_to_none would only force a re-attach next step)
+        if getattr(self, "_grads_cleared", False) and not self.core._grads_dirty:
+            return                                            # step() has already zeroed them (fuse_zero_grad)
         if self.overlap and self._opt_stream is not None:
             with torch.cuda.stream(self._opt_stream):        # after the update that is still reading the gradients
                 self.core.zero_flat_grads()

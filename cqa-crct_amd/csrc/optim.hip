@@ -13,13 +13,13 @@
 namespace {
 constexpr int ADAMW_CHUNK = 4096;
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb,
                                                     const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_len,
                                                     const float* __restrict__ seg_lr, const float* __restrict__ seg_wd,
                                                     const int32_t* __restrict__ blk_seg, const int64_t* __restrict__ blk_off,
                                                     float beta1, float beta2, float eps, float inv_bc1, float inv_sqrt_bc2,
-                                                    const float* __restrict__ inv_scale_dev, int n_blk) {
+                                                    const float* __restrict__ inv_scale_dev, int n_blk, int zero_g) {
  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
   const int sgi = blk_seg[blk];
   const int64_t off = blk_off[blk];
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       *reinterpret_cast<float4*>(m + e) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *reinterpret_cast<float4*>(v + e) = make_float4(va[0], va[1], va[2], va[3]);
       if (pb) *reinterpret_cast<uint2*>(pb + e) = make_uint2(pack2bf(pa[0], pa[1]), pack2bf(pa[2], pa[3]));
+      if (zero_g) *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       for (int64_t k = i; k < n; ++k) {
         const int64_t q = base + k;
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         pa -= step_size * ma / (sqrtf(va) * inv_sqrt_bc2 + eps);
         p[q] = pa; m[q] = ma; v[q] = va;
         if (pb) pb[q] = f2bf(pa);
+        if (zero_g) g[q] = 0.f;
       }
     }
   }
@@ -75,10 +77,10 @@ extern "C" int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* b
   return nb;
 }
 
-extern "C" int crct_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const int64_t* seg_off,
+extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, const int64_t* seg_off,
                                const int64_t* seg_len, const float* seg_lr, const float* seg_wd, const int32_t* blk_seg,
                                const int64_t* blk_off, int64_t n_blk, float beta1, float beta2, float eps, int step,
-                               const float* inv_scale_dev, int max_workgroups, crct_stream_t stream) {
+                               const float* inv_scale_dev, int max_workgroups, int zero_grads, crct_stream_t stream) {
   CRCT_REQUIRE(step >= 1, "adamw: step must be >= 1 (got %d)", step);
   if (n_blk <= 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -88,7 +90,7 @@ extern "C" int crct_adamw_step(float* p, const float* g, float* m, float* v, voi
   const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      seg_off, seg_len, seg_lr, seg_wd, blk_seg, blk_off, beta1, beta2, eps, (float)(1.0 / bc1),
-                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, (int)n_blk);
+                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, (int)n_blk, zero_grads);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -257,13 +257,15 @@ int crct_eval_select(const float* logits, const float* reg_out, const float* reg
  * with crct_adamw_plan().  inv_scale_dev: optional device scalar dividing the gradients (GradScaler).
  * max_workgroups: 0 = one workgroup per 4096-element block; > 0 = grid-stride launch of at most that many workgroups
  * (throttle for an update that overlaps other work on another stream).
+ * zero_grads != 0: every gradient element is overwritten with 0 right after it has been read (optimizer.zero_grad()
+ * folded into the update: the separate 953 MB memset disappears).
  */
 int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap);
-int crct_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16,
+int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
                     const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
                     const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk,
                     float beta1, float beta2, float eps, int step, const float* inv_scale_dev,
-                    int max_workgroups, crct_stream_t stream);
+                    int max_workgroups, int zero_grads, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Step engine: the whole forward + loss + backward of one batch as one native call
