@@ -90,7 +90,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, want_lin=False, p_lin=0.0, lin_site=
     dx = torch.empty_like(x)
     dxl = torch.empty_like(x) if want_lin else None
     nb = lib.crct_layernorm_bwd_blocks(M)
-    part = torch.empty(3 * nb * H, device=x.device, dtype=torch.float32)
+    part = torch.empty(3 * 4 * nb * H, device=x.device, dtype=torch.float32)       # one partial row per wave
     dgamma = torch.zeros(H, device=x.device) if dgamma is None else dgamma
     dbeta = torch.zeros(H, device=x.device) if dbeta is None else dbeta
     dbias = torch.zeros(H, device=x.device) if dbias is None else dbias

@@ -186,8 +186,8 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
   s.dres_a = ar.take(M * H * 2); s.dlin_a = ar.take(M * H * 2); s.dres_b = ar.take(M * H * 2); s.dlin_b = ar.take(M * H * 2);
   s.gc = ar.take(M * H * 2); s.du = ar.take(M * (size_t)I * 2); s.dctx = ar.take(M * (size_t)Hm * 2);
   s.dqkv = ar.take(M * (size_t)3 * Hm * 2);
-  s.part_a = ar.take((size_t)3 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);      // LayerNorm-backward column partials of the layer's two norms
-  s.part_b = ar.take((size_t)3 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);
+  s.part_a = ar.take((size_t)3 * 4 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);   // [3][4 waves x blocks][H]      // LayerNorm-backward column partials of the layer's two norms
+  s.part_b = ar.take((size_t)3 * 4 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);
   return s;
 }
 

@@ -278,24 +278,6 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
   }
 }
 
-// Sum one per-lane column accumulator over the 4 waves of the block and store to partial[blk][H].
-// `red` is LDS [4][H] floats.
-template <int NCH>
-__device__ __forceinline__ void block_reduce_store(const Row<NCH>& acc, float* red, float* partial_row, int H, int lane, int wave) {
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = (lane + 64 * i) * 8;
-    if (c < H) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) red[wave * H + c + j] = acc.v[i][j];
-    }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256)
-    partial_row[c] = red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c];
-}
-
 // ------------------------------------------------------------------------------ LayerNorm fwd
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
@@ -322,8 +304,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ dxl_p, float* __restrict__ partials, int M, int H,
                                                      uint32_t post_thr, float post_scale, uint32_t post_site,
                                                      uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   Row<NCH> adg, adb, adl;
   row_zero(adg); row_zero(adb); row_zero(adl);
@@ -340,10 +320,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
     row_acc(adl, dy);
   }
-  const long nb = gridDim.x;
-  block_reduce_store(adg, red, partials + (0 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(adb, red, partials + (1 * nb + blockIdx.x) * H, H, lane, wave);
-  block_reduce_store(adl, red, partials + (2 * nb + blockIdx.x) * H, H, lane, wave);
+  // one partial row per WAVE ([3][4 * gridDim.x][H]), summed by the finalize pass on the side stream: no LDS tree and no
+  // workgroup barriers on the data stream
+  const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+  row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
+  row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
+  row_store_f32(adl, partials + (2 * nr + pr) * H, H, lane);
 }
 
 // out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
@@ -513,8 +495,6 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     const float* __restrict__ loc, const float* __restrict__ gamma, float* __restrict__ d_word,
     float* __restrict__ d_pos, float* __restrict__ d_type, float* __restrict__ partials, int B, int T, int H, int n_pos,
     uint32_t thr, float scale, uint32_t site, uint64_t seed, float* __restrict__ rows_scratch, int* __restrict__ idx_scratch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long M = (long)B * T;
   Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3;
@@ -595,8 +575,6 @@ __global__ __launch_bounds__(256) void embed_image_bwd_kernel(
     const float* __restrict__ gamma, bf16_t* __restrict__ dsum_p, float* __restrict__ d_color,
     float* __restrict__ partials, int M, int H, uint32_t thr, float scale, uint32_t site, uint64_t seed,
     float* __restrict__ rows_scratch, int* __restrict__ idx_scratch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3;
   row_zero(adg); row_zero(adb); row_zero(abl); row_zero(aw0); row_zero(aw1); row_zero(aw2); row_zero(aw3);
@@ -678,8 +656,7 @@ int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, co
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int nb = crct_layernorm_bwd_blocks(M);
-  const size_t lds = (size_t)4 * H * sizeof(float);
-  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
+  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin, partials, M, H,
                                      post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
   CRCT_CHECK_HIP(hipGetLastError());
@@ -693,7 +670,7 @@ int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbe
   FinalizeArgs fa = {};
   fa.out[0] = dgamma; fa.out[1] = dbeta; fa.out[2] = dbias_lin;
   fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
-  fa.Q = 3; fa.nblk = crct_layernorm_bwd_blocks(M); fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
+  fa.Q = 3; fa.nblk = crct_layernorm_bwd_blocks(M) * ROWS_PER_BLOCK; fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
   return launch_finalize(fa, (hipStream_t)stream);
 }
 
@@ -768,8 +745,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_types <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = crct_layernorm_bwd_blocks((int)M);
-  const size_t lds = (size_t)4 * H * sizeof(float);
-  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
+  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
                                      partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch,
                                      rows_scratch ? idx_scratch : nullptr));
@@ -814,8 +790,7 @@ extern "C" int crct_embed_image_bwd(const void* dy, const void* sum_saved, const
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_color <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = crct_layernorm_bwd_blocks(M);
-  const size_t lds = (size_t)4 * H * sizeof(float);
-  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), lds, s, (const bf16_t*)dy,
+  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, loc, target, gamma, (bf16_t*)d_sum, d_color,
                                      partials, M, H, drop_thr, drop_scale, drop_site, seed, rows_scratch,
                                      rows_scratch ? idx_scratch : nullptr));

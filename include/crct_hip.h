@@ -97,7 +97,7 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
  *   dx_lin  bf16 [M][H]   (optional) dx with the PRE-norm dropout mask of the producing Linear
  *                         re-applied (site/seed of that Linear's epilogue) = gradient of dense(x)
  *   dgamma, dbeta, dbias_lin  fp32 [H]: column sums (dbias_lin = colsum(dx_lin or dx)), written or
- *                         accumulated (`accumulate`).  `partials` is fp32 scratch [3][nblk][H],
+ *                         accumulated (`accumulate`).  `partials` is fp32 scratch [3][4 * nblk][H] (one row per wave),
  *                         nblk = crct_layernorm_bwd_blocks(M).
  */
 int crct_layernorm_bwd_blocks(int M);
