@@ -336,34 +336,49 @@ struct FinalizeArgs {
   int Q, nblk, H, accumulate;
   const float* partials;
 };
-// 32 columns x 8 row-groups per 256-thread block: each thread sums nblk/8 partial rows (independent
-// loads, unrolled), then an LDS tree over the 8 groups.
+// 32 columns (8 threads x float4) x 32 row-groups per 256-thread block: every thread sums nblk/32 partial rows with
+// four independent 16-byte loads in flight, then the 32 row-group sums of a column quad are added in a fixed order.
 __global__ __launch_bounds__(256) void finalize_partials_kernel(const FinalizeArgs a) {
-  __shared__ float red[8][33];
+  __shared__ float4 red[32][9];
   const int q = blockIdx.y;
   float* o = a.out[q];
   if (!o) return;
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  float s = 0.f;
+  const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int c = blockIdx.x * 32 + cl * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < a.H) {
     const float* p = a.partials + ((long)q * a.nblk) * a.H + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float4 s0 = s, s1 = s, s2 = s, s3 = s;
     int b = rg;
-    for (; b + 24 < a.nblk; b += 32) {
-      s0 += p[(long)b * a.H]; s1 += p[(long)(b + 8) * a.H]; s2 += p[(long)(b + 16) * a.H]; s3 += p[(long)(b + 24) * a.H];
+    for (; b + 96 < a.nblk; b += 128) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p + (long)b * a.H), x1 = *reinterpret_cast<const float4*>(p + (long)(b + 32) * a.H);
+      const float4 x2 = *reinterpret_cast<const float4*>(p + (long)(b + 64) * a.H), x3 = *reinterpret_cast<const float4*>(p + (long)(b + 96) * a.H);
+      s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+      s1.x += x1.x; s1.y += x1.y; s1.z += x1.z; s1.w += x1.w;
+      s2.x += x2.x; s2.y += x2.y; s2.z += x2.z; s2.w += x2.w;
+      s3.x += x3.x; s3.y += x3.y; s3.z += x3.z; s3.w += x3.w;
     }
-    for (; b < a.nblk; b += 8) s0 += p[(long)b * a.H];
-    s = (s0 + s1) + (s2 + s3);
+    for (; b < a.nblk; b += 32) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p + (long)b * a.H);
+      s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+    }
+    s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
+    s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
   }
   red[rg][cl] = s;
   __syncthreads();
   if (rg == 0 && c < a.H) {
-    float t = 0.f;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
-    const long oi = (long)c * a.stride[q];
-    o[oi] = a.accumulate ? o[oi] + t : t;
+    for (int k = 0; k < 32; ++k) { const float4 r = red[k][cl]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < a.H) {
+        const long oi = (long)(c + j) * a.stride[q];
+        o[oi] = a.accumulate ? o[oi] + tv[j] : tv[j];
+      }
+    }
   }
 }
 
