@@ -1,5 +1,5 @@
-// MFMA attention for the short CRCT sequences: ONE WAVE per (batch, head), sequences up to 64 queries x
-// 64 keys, head size 32 / 48 / 64.  Same math and the same dropout stream as attention.hip (which stays
+// MFMA attention for the short CRCT sequences: ONE WAVE per (batch, head), sequences up to 112 queries x
+// 112 keys (1-4 or 7 tiles of 16 per side), head size 32 / 48 / 64.  Same math and the same dropout stream as attention.hip (which stays
 // the path for longer sequences):
 //   P = softmax(q k^T / sqrt(d) + (1 - keymask) * -10000) ; ctx = dropout(P) v
 // Reference: BertSelfAttention.forward vilbert.py:392-412, BertImageSelfAttention :522-543,
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(64 * W) void attn_fwd_mfma(const AttnArgs a) {
   for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
     for (int ks = 0; ks < ND; ++ks) kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
-  f4_t o[ND][NQ];
 #pragma unroll
   for (int it = 0; it < NQ; ++it) {
     s4_t qf[ND];
@@ -211,18 +210,15 @@ __global__ __launch_bounds__(64 * W) void attn_fwd_mfma(const AttnArgs a) {
       for (int r = 0; r < 4; ++r) p[r] = ((keep >> (4 * jt + r)) & 1u) ? s[jt][r] * ds : 0.f;
       pb[jt] = pack4(p);
     }
+    // the 16 query rows of this block have been read into qf: their slot in the Q image takes the output tile
 #pragma unroll
     for (int ct = 0; ct < ND; ++ct) {
-      o[ct][it] = f4_t{0.f, 0.f, 0.f, 0.f};
+      f4_t o = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jt = 0; jt < NK; ++jt) o[ct][it] = mma16(frag_cols(Vs, STB, 16 * jt, 16 * ct, lane), pb[jt], o[ct][it]);   // ctx^T[c][i]
+      for (int jt = 0; jt < NK; ++jt) o = mma16(frag_cols(Vs, STB, 16 * jt, 16 * ct, lane), pb[jt], o);   // ctx^T[c][i]
+      put_tile_t(Qs, STB, 16 * it, 16 * ct, o, lane);
     }
   }
-  wave_sync();                          // every fragment of Q has been read: its image becomes the output staging tile
-#pragma unroll
-  for (int it = 0; it < NQ; ++it)
-#pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Qs, STB, 16 * it, 16 * ct, o[ct][it], lane);
   wave_sync();
   store_rows<ND>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq, lane);
 }
@@ -405,6 +401,7 @@ hipError_t pick_k(const AttnArgs& a, hipStream_t s) {
     case 2: return pick_d<BWD, NQ, 2>(a, s);
     case 3: return pick_d<BWD, NQ, 3>(a, s);
     case 4: return pick_d<BWD, NQ, 4>(a, s);
+    case 5: case 6: case 7: return pick_d<BWD, NQ, 7>(a, s);     // 65..112 keys: padded to 7 tiles
   }
   return hipErrorInvalidValue;
 }
@@ -415,12 +412,13 @@ hipError_t pick_q(const AttnArgs& a, hipStream_t s) {
     case 2: return pick_k<BWD, 2>(a, s);
     case 3: return pick_k<BWD, 3>(a, s);
     case 4: return pick_k<BWD, 4>(a, s);
+    case 5: case 6: case 7: return pick_k<BWD, 7>(a, s);
   }
   return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-bool crct_attention_mfma_ok(int Tq, int Tk, int d) { return Tq <= 64 && Tk <= 64 && (d == 32 || d == 48 || d == 64); }
+bool crct_attention_mfma_ok(int Tq, int Tk, int d) { return Tq <= 112 && Tk <= 112 && (d == 32 || d == 48 || d == 64); }
 hipError_t crct_attention_mfma_fwd(const AttnArgs& a, hipStream_t s) { return pick_q<false>(a, s); }
 hipError_t crct_attention_mfma_bwd(const AttnArgs& a, hipStream_t s) { return pick_q<true>(a, s); }

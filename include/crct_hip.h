@@ -142,7 +142,7 @@ int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                        uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                        crct_stream_t stream);
-/* Two implementations share these entry points: Tq, Tk <= 64 with d in {32, 48, 64} run one wave per
+/* Two implementations share these entry points: Tq, Tk <= 112 with d in {32, 48, 64} run one wave per
  * (batch, head) on MFMA (attention_mfma.hip); everything else (and everything after
  * crct_attention_force_valu(1) / CRCT_ATTN_VALU=1) the fp32 VALU kernels.  Same dropout stream in both. */
 void crct_attention_force_valu(int on);
