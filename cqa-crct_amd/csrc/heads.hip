@@ -126,25 +126,35 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const CrctHeadArgs a, fl
 // stats + parameter gradients of bi_seq_relationship and fusion.6 (sums over the batch rows)
 __global__ __launch_bounds__(256) void head_reduce_kernel(const CrctHeadArgs a, const float* scratch) {
   const int tid = threadIdx.x;
-  const int c = blockIdx.x * 256 + tid;
   const float dsc = a.drop_thr ? a.drop_scale : 1.0f;
-  if (a.d_w_cls && c < a.Hb) {
+  // parameter gradients: 32 columns x 8 row groups per workgroup (a thread walks B / 8 rows, not all of them), the 8
+  // partial sums are added in a fixed order.  Columns beyond Hb / 256 idle.
+  __shared__ float part[3][8][33];
+  const int cl = tid & 31, rg = tid >> 5;
+  const int cc = blockIdx.x * 32 + cl;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (a.d_w_cls && cc < a.Hb) {
     const bf16_t* pt = reinterpret_cast<const bf16_t*>(a.pooled_t);
     const bf16_t* pv = reinterpret_cast<const bf16_t*>(a.pooled_v);
-    float g0 = 0.f, g1 = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-      const float t = bf2f(pt[(long)b * a.Hb + c]), v = bf2f(pv[(long)b * a.Hb + c]);
+    for (int b = rg; b < a.B; b += 8) {
+      const float t = bf2f(pt[(long)b * a.Hb + cc]), v = bf2f(pv[(long)b * a.Hb + cc]);
       float f = a.fusion_sum ? t + v : t * v;
-      f = head_keep(a, b, c) ? f * dsc : 0.f;
+      f = head_keep(a, b, cc) ? f * dsc : 0.f;
       g0 += scratch[b * 8] * f; g1 += scratch[b * 8 + 1] * f;
     }
-    a.d_w_cls[c] += g0; a.d_w_cls[a.Hb + c] += g1;
   }
-  if (a.d_w_f6 && c < 256) {
+  if (a.d_w_f6 && cc < 256) {
     const bf16_t* fh = reinterpret_cast<const bf16_t*>(a.fus_h);
-    float g = 0.f;
-    for (int b = 0; b < a.B; ++b) g += scratch[b * 8 + 2] * bf2f(fh[(long)b * 256 + c]);
-    a.d_w_f6[c] += g;
+    for (int b = rg; b < a.B; b += 8) g2 += scratch[b * 8 + 2] * bf2f(fh[(long)b * 256 + cc]);
+  }
+  part[0][rg][cl] = g0; part[1][rg][cl] = g1; part[2][rg][cl] = g2;
+  __syncthreads();
+  if (rg == 0) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t0 += part[0][k][cl]; t1 += part[1][k][cl]; t2 += part[2][k][cl]; }
+    if (a.d_w_cls && cc < a.Hb) { a.d_w_cls[cc] += t0; a.d_w_cls[a.Hb + cc] += t1; }
+    if (a.d_w_f6 && cc < 256) a.d_w_f6[cc] += t2;
   }
   if (blockIdx.x == 0 && tid < 64) {
     // one wave reduces the per-row records
@@ -238,7 +248,7 @@ extern "C" int crct_head_loss(const CrctHeadArgs* args, crct_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(head_rows_kernel, dim3(args->B), dim3(256), 0, s, *args, args->scratch);
   CRCT_CHECK_HIP(hipGetLastError());
-  const int nb = ((args->Hb > 256 ? args->Hb : 256) + 255) / 256;
+  const int nb = ((args->Hb > 256 ? args->Hb : 256) + 31) / 32;
   hipLaunchKernelGGL(head_reduce_kernel, dim3(nb), dim3(256), 0, s, *args, (const float*)args->scratch);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
