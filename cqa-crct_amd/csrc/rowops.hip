@@ -235,12 +235,16 @@ __device__ __forceinline__ void row_store_f32(const Row<NCH>& r, float* p, int H
 // block prefix sum (a fixed order: the result does not depend on timing), then every thread sums its 4 columns over
 // the listed rows.  M <= GATHER_MAX_ROWS.
 constexpr int GATHER_MAX_ROWS = 16384;
+// Two tables in one launch: workgroups [0, n0) serve (idx, table), the rest (idx1, table1).
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
-                                                         float* __restrict__ table) {
+                                                         float* __restrict__ table, int n0, const int* __restrict__ idx1,
+                                                         float* __restrict__ table1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* list = reinterpret_cast<int*>(smem);              // [M]
   __shared__ int cnt[256];
-  const int p = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int p = blockIdx.x;
+  if (p >= n0) { p -= n0; idx = idx1; table = table1; }
   int n = 0;
   for (int r = tid; r < M; r += 256) n += idx[r] == p;
   cnt[tid] = n;
@@ -767,8 +771,8 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
     const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, (int)M, H, d_pos);
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(n_types), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch + M, (int)M, H, d_type);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch,
+                       (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
     CRCT_CHECK_HIP(hipGetLastError());
   }
   FinalizeArgs fa = {};
@@ -811,7 +815,8 @@ extern "C" int crct_embed_image_bwd(const void* dy, const void* sum_saved, const
                                      rows_scratch ? idx_scratch : nullptr));
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(n_color), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, M, H, d_color);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(n_color), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, M, H, d_color,
+                       n_color, (const int*)nullptr, (float*)nullptr);
     CRCT_CHECK_HIP(hipGetLastError());
   }
   // two finalize passes share the column-sum partial (index 2): b_loc and b_img
