@@ -152,11 +152,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    if os.environ.get("CRCT_BENCH_SHARE_GPU"):       # developer check of the N > 1 code path on a 1-GPU box (gloo, every rank on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("CRCT_BENCH_SHARE_GPU"):
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from crct.model import VisualDialogEncoder
     from crct.optim import get_optimizer, WarmupLinearScheduleNonZero
