@@ -242,6 +242,8 @@ struct Run {
   }
   std::vector<CrctGemmArgs> pending;   // weight-gradient GEMMs of the current layer, launched as ONE grouped grid
   bool defer_wgrad = true;             // false: launch every weight gradient immediately on s (buffers are recycled)
+  struct FinJob { const float* part; float* dg; float* db; float* dlb; int M, H; };
+  std::vector<FinJob> pending_fin;     // LayerNorm column passes of the current layer (run on sw at the layer's flush)
   int tick = 0, ordered_tick = -1;     // launches enqueued on s / the tick sw was last ordered after (skip redundant events)
   void wgrad_after_main() {            // sw sees what s produced
     if (rc || sw == s) return;
@@ -315,9 +317,13 @@ struct Run {
   }
   // launch the queued weight-gradient GEMMs on the side stream, ordered after everything enqueued on s so far
   void flush_wgrads() {
-    if (rc || pending.empty()) return;
+    if (rc || (pending.empty() && pending_fin.empty())) return;
     if (sw == s) ++tick;
     wgrad_after_main();
+    for (const FinJob& f : pending_fin)
+      if (!rc) fail(crct_layernorm_bwd_finalize(f.part, f.dg, f.db, f.dlb, f.M, f.H, 1, sw));
+    pending_fin.clear();
+    if (pending.empty()) return;
     if (!rc) fail(crct_gemm_bf16_grouped(pending.data(), (int)pending.size(), sw));
     pending.clear();
   }
@@ -340,8 +346,9 @@ struct Run {
     ++tick;
     fail(crct_layernorm_bwd_rows(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
                                  0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
-    wgrad_after_main();
-    if (!rc) fail(crct_layernorm_bwd_finalize(F(part), G(ln.g), G(ln.b), G(lin.b), M, H, 1, sw));
+    // the column pass is queued like the weight gradients: ONE ordering event per layer covers all of them
+    if (defer_wgrad) pending_fin.push_back(FinJob{F(part), G(ln.g), G(ln.b), G(lin.b), M, H});
+    else { wgrad_after_main(); if (!rc) fail(crct_layernorm_bwd_finalize(F(part), G(ln.g), G(ln.b), G(lin.b), M, H, 1, sw)); }
     return dr.thr ? dlin : dres;
   }
   void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
@@ -989,6 +996,8 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   Rt.main_after_wgrad();
   Rv.main_after_wgrad();
   Rt.fail(order_streams(e, Rv.s, Rt.s));
+  static const bool dbg_ev = getenv("CRCT_DEBUG_EVENTS") != nullptr;
+  if (dbg_ev) fprintf(stderr, "[crct] backward: %d ordering events\n", e->evnext);
   return Rt.rc ? Rt.rc : Rv.rc;
 }
 
