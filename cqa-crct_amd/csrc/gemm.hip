@@ -748,7 +748,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
     slot->variant = (pipe ? t : 16 + (t & 3)) * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
     g_prof.count[slot->variant] += 1;
     g_prof.flops[slot->variant] += 2.0 * g.M * g.N * g.K;
-    hipEventRecord(slot->a, s);
+    if (hipEventRecord(slot->a, s) != hipSuccess) return hipErrorUnknown;
   }
   hipError_t e;
   if (pipe) {
@@ -777,7 +777,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       default: e = launch_cfg<2, 2>(g, s); break;
     }
   }
-  if (slot) hipEventRecord(slot->b, s);
+  if (slot && hipEventRecord(slot->b, s) != hipSuccess) return hipErrorUnknown;
   return e;
 }
 
