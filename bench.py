@@ -226,6 +226,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     final_loss = float(loss.detach())
+    comm = None
+    if world > 1:
+        # evidence for the data-parallel exchange: the flat gradient buffer all-reduced on its own, after the
+        # timed region (the step itself overlaps it with backward in >= bucket_mb pieces)
+        used = int(max(hi for _, hi in core._engine.segments)) if core._engine is not None else core.flat_grads.numel()
+        buf = core.flat_grads[:used]
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar = (time.perf_counter() - t1) / 5
+        comm = {"allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
+                "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9}
     qa_per_s = a.batch * world * a.steps / dt
 
     out = None
@@ -237,7 +253,7 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss" % (a.feat, a.batch, a.vis, a.feat, a.tokens),
-                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input,
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input, "gradient_allreduce": comm,
                           "gemm_variants": rows}}
         if flop_qa:
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
