@@ -60,6 +60,29 @@ __device__ __forceinline__ bf8_t load_frag(const char* lds, int r0, int k0, int 
   }
 }
 
+// The same transposed fragment for the LDS-DMA kernel, as inline assembly.  The compiler treats the transposing-read
+// builtin as a possible LDS *store*, so behind every buffer_load ... lds still in flight it puts an s_waitcnt vmcnt(0)
+// in front of the first such read: the prefetch of the next K tile then lands before the current one is used and
+// nothing overlaps (measured: text FFN-up dgrad 37 us, of which 19 us exposed DMA latency; its K-contiguous twin 10 us).
+// An asm read carries no memory operand, so the counted vmcnt of the pipeline is the only wait; the price is that the
+// compiler does not count these reads in lgkmcnt either: frag_async_wait() must follow before the registers are used.
+template <int WC>
+__device__ __forceinline__ bf8_t load_frag_tr_async(const char* lds, int r0, int k0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int k = k0 + 8 * g + q;
+  const int ch = (r0 >> 3) + (p >> 1);
+  const uint32_t base = (uint32_t)(uintptr_t)lds;
+  const uint32_t a0 = base + off_tr<WC>(k, ch) + 8 * (p & 1);
+  const uint32_t a1 = base + off_tr<WC>(k + 4, ch) + 8 * (p & 1);
+  s4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8_t, v);
+}
+__device__ __forceinline__ void frag_async_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void frag_async_use(bf8_t& f) { asm volatile("" : "+v"(f)); }   // orders consumers behind the wait
+
 // ---- global -> register staging of one operand tile: R = 32*RC rows (output index) x 64 (contraction)
 template <bool T, int RC>
 struct Stage {
@@ -385,8 +408,18 @@ constexpr unsigned OOB_OFF = 0x80000000u;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 template <bool T, int RC>
-__device__ __forceinline__ unsigned dma_src_offset(int slot, int r0, int R, long ld) {
+__device__ __forceinline__ unsigned dma_src_offset(int slot, int r0, int R, long ld, int dbg = 0) {
   // slot = 16-byte slot index inside the operand image; returns the byte offset of its source chunk at k0 = 0
+#ifdef CRCT_GEMM_LAB       // timing ablations of tools/gemm_lab only (wrong results)
+  if (T && (dbg & 4)) {     // whole source rows by consecutive lanes
+    const int k = slot / (RC * 4), ch = slot % (RC * 4);
+    return (unsigned)(((long)k * ld + r0 + ch * 8) * 2);
+  }
+  if (T && (dbg & 8)) {     // the K-contiguous operand's address stream (rows of 128 B advancing along the row)
+    const int r = slot >> 3, ch = slot & 7;
+    return (unsigned)((((long)(r0 / 8 + r)) * ld + ch * 8) * 2);
+  }
+#endif
   if constexpr (!T) {
     const int r = slot >> 3, ch = (slot & 7) ^ (r & 7);
     return (r0 + r < R) ? (unsigned)((((long)(r0 + r)) * ld + ch * 8) * 2) : OOB_OFF;
@@ -434,11 +467,15 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)OOB_OFF, 0x00020000);
   unsigned offA[PA], offB[PB];
 #pragma unroll
-  for (int i = 0; i < PA; ++i) offA[i] = dma_src_offset<TA, TM>((i * NW + wave) * 64 + lane, m0, g.M, g.lda);
+  for (int i = 0; i < PA; ++i) offA[i] = dma_src_offset<TA, TM>((i * NW + wave) * 64 + lane, m0, g.M, g.lda, dbg);
 #pragma unroll
-  for (int i = 0; i < PB; ++i) offB[i] = dma_src_offset<TB, TN>((i * NW + wave) * 64 + lane, n0, g.N, g.ldb);
+  for (int i = 0; i < PB; ++i) offB[i] = dma_src_offset<TB, TN>((i * NW + wave) * 64 + lane, n0, g.N, g.ldb, dbg);
   const int stepA = TA ? (int)(64 * g.lda * 2) : 128;     // bytes per K tile
+#ifdef CRCT_GEMM_LAB
+  const int stepB = TB && !(dbg & 8) ? (int)(64 * g.ldb * 2) : 128;
+#else
   const int stepB = TB ? (int)(64 * g.ldb * 2) : 128;
+#endif
 
   f4_t acc[WTN][WTM];
 #pragma unroll
@@ -487,9 +524,32 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     for (int ks = 0; ks < BK; ks += 32) {
       bf8_t fm[WTM], fn[WTN];
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) fm[i] = load_frag<TA, TM>(ldsA, wm * (BM / WM) + i * 16, ks, lane);
+      for (int i = 0; i < WTM; ++i) {
+        if constexpr (TA) fm[i] = load_frag_tr_async<TM>(ldsA, wm * (BM / WM) + i * 16, ks, lane);
+        else fm[i] = load_frag<false, TM>(ldsA, wm * (BM / WM) + i * 16, ks, lane);
+      }
 #pragma unroll
-      for (int i = 0; i < WTN; ++i) fn[i] = load_frag<TB, TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
+      for (int i = 0; i < WTN; ++i) {
+        if constexpr (TB) fn[i] = load_frag_tr_async<TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
+        else fn[i] = load_frag<false, TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
+      }
+      if constexpr (TA || TB) {
+        frag_async_wait();
+        if constexpr (TA) {
+#pragma unroll
+          for (int i = 0; i < WTM; ++i) frag_async_use(fm[i]);
+        }
+        if constexpr (TB) {
+#pragma unroll
+          for (int i = 0; i < WTN; ++i) frag_async_use(fn[i]);
+        }
+      }
+#ifdef CRCT_GEMM_LAB
+      if (TB && (dbg & 16)) {   // plain 16-byte fragment reads in place of the transposing ones
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) fn[i] = load_frag<false, TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
+      }
+#endif
 #pragma unroll
       for (int a = 0; a < WTN; ++a)
 #pragma unroll

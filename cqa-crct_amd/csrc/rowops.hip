@@ -664,7 +664,14 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
   return 0;
 }
 
-int crct_layernorm_bwd_blocks(int M) { return row_grid(M, CRCT_LN_BWD_MAX_BLOCKS); }
+int crct_layernorm_bwd_blocks(int M) {
+  static const int cap = [] {
+    const char* e = getenv("CRCT_LN_BWD_BLOCKS");   // developer knob (<= CRCT_LN_BWD_MAX_BLOCKS: buffers are sized for the maximum)
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v < CRCT_LN_BWD_MAX_BLOCKS ? v : CRCT_LN_BWD_MAX_BLOCKS;
+  }();
+  return row_grid(M, cap);
+}
 
 // rows pass only: dx / dx_lin and the per-workgroup column partials [3][nblk][H]
 int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,

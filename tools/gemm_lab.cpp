@@ -12,7 +12,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s);
 static char err[256];
 void crct_set_error(const char* fmt, ...) { strcpy(err, fmt); }
 
-struct Shape { const char* name; int M, N, K, ta, tb; };
+struct Shape { const char* name; int M, N, K, ta, tb; int lda = 0, ldb = 0; };
 
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 50;
@@ -22,7 +22,10 @@ int main(int argc, char** argv) {
       {"t.out fwd   ", 1600, 768, 768, 0, 0},  {"v.qkv fwd   ", 2880, 3072, 1024, 0, 0}, {"v.ffn fwd   ", 2880, 1024, 1024, 0, 0},
       {"t.ffn_up dg ", 1600, 768, 3072, 0, 1}, {"t.ffn_dn dg ", 1600, 3072, 768, 0, 1}, {"v.qkv dg    ", 2880, 1024, 3072, 0, 1},
       {"t.ffn_up wg ", 3072, 768, 1600, 1, 1}, {"t.ffn_dn wg ", 768, 3072, 1600, 1, 1}, {"v.qkv wg    ", 3072, 1024, 2880, 1, 1},
-      {"v.ffn wg    ", 1024, 1024, 2880, 1, 1}, {"big 4096^3  ", 4096, 4096, 4096, 0, 0}};
+      {"v.ffn wg    ", 1024, 1024, 2880, 1, 1}, {"big 4096^3  ", 4096, 4096, 4096, 0, 0},
+      {"up dg ldb1024", 1600, 768, 3072, 0, 1, 0, 1024}, {"up dg ldb 832", 1600, 768, 3072, 0, 1, 0, 832},
+      {"up dg lda3136", 1600, 768, 3072, 0, 1, 3136, 0}, {"dn fw lda3136", 1600, 768, 3072, 0, 0, 3136, 3136},
+      {"up dg N=1536 ", 1600, 1536, 3072, 0, 1}, {"dn fw N=1536 ", 1600, 1536, 3072, 0, 0}};
   size_t maxel = (size_t)4096 * 4096;
   unsigned short *A, *B, *C;
   hipMalloc(&A, maxel * 2); hipMalloc(&B, maxel * 2); hipMalloc(&C, maxel * 4);
@@ -43,7 +46,7 @@ int main(int argc, char** argv) {
         if (only_tile >= 0 && tile != only_tile) continue;
         CrctGemmArgs g; memset(&g, 0, sizeof(g));
         g.A = A; g.B = B; g.C = C; g.M = s.M; g.N = s.N; g.K = s.K; g.ta = s.ta; g.tb = s.tb;
-        g.lda = s.ta ? s.M : s.K; g.ldb = s.tb ? s.N : s.K; g.ldc = s.N; g.ld_aux = s.N; g.ld_add = s.N;
+        g.lda = s.lda ? s.lda : (s.ta ? s.M : s.K); g.ldb = s.ldb ? s.ldb : (s.tb ? s.N : s.K); g.ldc = s.N; g.ld_aux = s.N; g.ld_add = s.N;
         g.tile = tile; g.alpha = 1.f; g.c_is_f32 = s.ta ? 1 : 0;
         for (int i = 0; i < 5; ++i) crct_gemm_launch(g, 0);
         hipEventRecord(e0, 0);
