@@ -39,8 +39,8 @@ PEAK_BF16_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense b
 FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9}   # SURVEY.md 8d, fwd+bwd
 VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
-              5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x256w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
-              10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 16: "reg128x128", 17: "reg128x64",
+              5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x128w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
+              10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 15: "dma128x64w8s3", 16: "reg128x128", 17: "reg128x64",
               18: "reg64x128", 19: "reg64x64"}
 
 

@@ -28,6 +28,9 @@
 namespace {
 
 constexpr int BK = 64;
+#ifndef CRCT_GEMM_SPLIT_HALVES
+#define CRCT_GEMM_SPLIT_HALVES 1
+#endif
 
 // byte offset of 16-byte chunk `ch` (0..7) of row r in the [R][64] bf16 image (128-B rows)
 __device__ __forceinline__ int off_rowmajor(int r, int ch) { return r * 128 + ((ch ^ (r & 7)) << 4); }
@@ -80,7 +83,26 @@ __device__ __forceinline__ bf8_t load_frag_tr_async(const char* lds, int r0, int
   s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf8_t, v);
 }
-__device__ __forceinline__ void frag_async_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// K-contiguous fragment (one 16-byte read) in the same uncounted form, so that a kernel with a transposed operand issues
+// ALL its fragment reads in a known order and can wait for the first half of them only
+__device__ __forceinline__ bf8_t load_frag_async(const char* lds, int r0, int k0, int lane) {
+  const int r = r0 + (lane & 15);
+  const int ch = (k0 >> 3) + (lane >> 4);
+  const uint32_t a = (uint32_t)(uintptr_t)lds + off_rowmajor(r, ch);
+  bf8_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void frag_async_wait() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+#define CRCT_LGKM_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");
+  if constexpr (N < 0) {}
+  CRCT_LGKM_CASE(0) CRCT_LGKM_CASE(1) CRCT_LGKM_CASE(2) CRCT_LGKM_CASE(3) CRCT_LGKM_CASE(4) CRCT_LGKM_CASE(5) CRCT_LGKM_CASE(6)
+  CRCT_LGKM_CASE(7) CRCT_LGKM_CASE(8) CRCT_LGKM_CASE(9) CRCT_LGKM_CASE(10) CRCT_LGKM_CASE(11) CRCT_LGKM_CASE(12) CRCT_LGKM_CASE(13)
+  CRCT_LGKM_CASE(14) CRCT_LGKM_CASE(15)
+#undef CRCT_LGKM_CASE
+}
 __device__ __forceinline__ void frag_async_use(bf8_t& f) { asm volatile("" : "+v"(f)); }   // orders consumers behind the wait
 
 // ---- global -> register staging of one operand tile: R = 32*RC rows (output index) x 64 (contraction)
@@ -520,45 +542,60 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     if (kt + NS - 1 < nk && !(dbg & 2)) issue(kt + NS - 1, st_next);
     const char* ldsA = smem + st * STAGE;
     const char* ldsB = ldsA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 32) {
-      bf8_t fm[WTM], fn[WTN];
+    // fragments of both 32-deep halves of the K tile are requested up front; the MFMAs of the first half run while the
+    // reads of the second are still in flight
+    static_assert(BK == 64, "two MFMA K-halves per tile");
+    constexpr bool ASYNC = TA || TB;
+    constexpr int N_HALF = WTM * (TA ? 2 : 1) + WTN * (TB ? 2 : 1);      // LDS reads per half (a transposed fragment takes two)
+    bf8_t fm[2][WTM], fn[2][WTN];
+    auto request = [&](int h) {
 #pragma unroll
       for (int i = 0; i < WTM; ++i) {
-        if constexpr (TA) fm[i] = load_frag_tr_async<TM>(ldsA, wm * (BM / WM) + i * 16, ks, lane);
-        else fm[i] = load_frag<false, TM>(ldsA, wm * (BM / WM) + i * 16, ks, lane);
+        if constexpr (TA) fm[h][i] = load_frag_tr_async<TM>(ldsA, wm * (BM / WM) + i * 16, h * 32, lane);
+        else if constexpr (ASYNC) fm[h][i] = load_frag_async(ldsA, wm * (BM / WM) + i * 16, h * 32, lane);
+        else fm[h][i] = load_frag<false, TM>(ldsA, wm * (BM / WM) + i * 16, h * 32, lane);
       }
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
-        if constexpr (TB) fn[i] = load_frag_tr_async<TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
-        else fn[i] = load_frag<false, TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
+        if constexpr (TB) fn[h][i] = load_frag_tr_async<TN>(ldsB, wn * (BN / WN) + i * 16, h * 32, lane);
+        else if constexpr (ASYNC) fn[h][i] = load_frag_async(ldsB, wn * (BN / WN) + i * 16, h * 32, lane);
+        else fn[h][i] = load_frag<false, TN>(ldsB, wn * (BN / WN) + i * 16, h * 32, lane);
       }
-      if constexpr (TA || TB) {
-        frag_async_wait();
-        if constexpr (TA) {
-#pragma unroll
-          for (int i = 0; i < WTM; ++i) frag_async_use(fm[i]);
-        }
-        if constexpr (TB) {
-#pragma unroll
-          for (int i = 0; i < WTN; ++i) frag_async_use(fn[i]);
-        }
-      }
-#ifdef CRCT_GEMM_LAB
-      if (TB && (dbg & 16)) {   // plain 16-byte fragment reads in place of the transposing ones
-#pragma unroll
-        for (int i = 0; i < WTN; ++i) fn[i] = load_frag<false, TN>(ldsB, wn * (BN / WN) + i * 16, ks, lane);
-      }
+    };
+#if CRCT_GEMM_SPLIT_HALVES
+    request(0);
+    request(1);
 #endif
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#if !CRCT_GEMM_SPLIT_HALVES
+      request(h);
+#endif
+      if constexpr (ASYNC) {
+        if (h == 0 && CRCT_GEMM_SPLIT_HALVES) frag_async_wait<(N_HALF <= 15 ? N_HALF : 0)>();
+        else frag_async_wait<0>();
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+      }
 #pragma unroll
       for (int a = 0; a < WTN; ++a)
 #pragma unroll
         for (int b = 0; b < WTM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[a], fm[b], acc[a][b], 0, 0, 0);
-      if (do_rs && (((kt << 1) + (ks >> 5)) & (WN - 1)) == wn) {
-#pragma unroll
-        for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[b], accb[b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[h][a], fm[h][b], acc[a][b], 0, 0, 0);
+      // keep the first half's MFMAs in front of the second wait (they are not ordered against it otherwise)
+      if constexpr (ASYNC) {
+        if (h == 0) asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));
       }
+    }
+    if (do_rs) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if ((((kt << 1) + h) & (WN - 1)) == wn) {
+#pragma unroll
+          for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[h][b], accb[b], 0, 0, 0);
+        }
     }
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
@@ -794,7 +831,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   const bool pipe = pipe_ok(g) && !g_force_generic;
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 14) t = 12;
+  if (t > 15) t = 12;
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
   ProfSlot* slot = nullptr;
@@ -827,6 +864,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       case 11: e = launch_pipe<2, 4, 2, 4, 3>(g, s); break;    // 64x128, 8 waves
       case 13: e = launch_pipe<4, 2, 4, 2, 4>(g, s); break;    // 128x64, 8 waves (4x2), 4 stages: long K, one block per CU
       case 14: e = launch_pipe<4, 2, 4, 2, 6>(g, s); break;    // 128x64, 8 waves (4x2), 6 stages
+      case 15: e = launch_pipe<4, 2, 4, 2, 3>(g, s); break;    // 128x64, 8 waves (4x2), 3 stages
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
   } else {
@@ -857,7 +895,7 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
     }
     return hipSuccess;
   }
-  static const int cfg = getenv("CRCT_GEMM_GROUP") ? atoi(getenv("CRCT_GEMM_GROUP")) : 9;
+  static const int cfg = getenv("CRCT_GEMM_GROUP") ? atoi(getenv("CRCT_GEMM_GROUP")) : 4;   // 128x128, 8 waves, 3 stages
   ProfSlot* slot = nullptr;
   if (g_prof.on) {                     // one timed slot for the whole group, FLOPs summed
     if (g_prof.used == g_prof.slots.size()) {
@@ -866,12 +904,13 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
       g_prof.slots.push_back(ns);
     }
     slot = &g_prof.slots[g_prof.used++];
-    slot->variant = (cfg == 12 ? 12 : 9) * 3 + (gs[0].ta ? 2 : (gs[0].tb ? 1 : 0));
+    slot->variant = (cfg == 12 || cfg == 9 ? cfg : 4) * 3 + (gs[0].ta ? 2 : (gs[0].tb ? 1 : 0));
     g_prof.count[slot->variant] += 1;
     for (int i = 0; i < n; ++i) g_prof.flops[slot->variant] += 2.0 * gs[i].M * gs[i].N * gs[i].K;
     (void)hipEventRecord(slot->a, s);
   }
-  const hipError_t e = cfg == 12 ? launch_group<4, 2, 4, 2, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 2>(gs, n, s);
+  const hipError_t e = cfg == 12 ? launch_group<4, 2, 4, 2, 2>(gs, n, s)
+                       : cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s);
   if (slot) (void)hipEventRecord(slot->b, s);
   return e;
 }
