@@ -39,17 +39,33 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ f4_t mma16(s4_t a, s4_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
-// rows [T][16*ND] bf16 (row stride ld) -> LDS image with `rows` rows (rows >= T are zero)
-template <int ND>
-__device__ __forceinline__ void load_rows(char* img, const bf16_t* src, long ld, int T, int rows, int lane) {
-  constexpr int CPR = 2 * ND, STB = 32 * ND + 16;
-  for (int c = lane; c < rows * CPR; c += 64) {
-    const int r = c / CPR, cc = (c - r * CPR) << 3;
-    uint4 u = make_uint4(0u, 0u, 0u, 0u);
-    if (r < T) u = *reinterpret_cast<const uint4*>(src + (long)r * ld + cc);
-    *reinterpret_cast<uint4*>(img + r * STB + cc * 2) = u;
+// rows [T][16*ND] bf16 (row stride ld) -> LDS image of 16*NT rows (rows >= T are zero), in two phases so that the global
+// loads of SEVERAL matrices are all in flight before the first one is waited for: fetch() issues every load of the
+// matrix unconditionally (rows past T re-read row 0 and are zeroed afterwards: no branch, no wait between loads),
+// put() stores the registers to the image.  (A plain load -> store loop costs one memory round trip per 64 chunks and
+// matrix: 6-14 serial round trips in front of 2-3 us of arithmetic.)
+template <int ND, int NT>
+struct RowTile {
+  static constexpr int CPR = 2 * ND, STB = 32 * ND + 16, CHUNKS = 16 * NT * CPR, ITER = (CHUNKS + 63) / 64;
+  uint4 reg[ITER];
+  __device__ __forceinline__ void fetch(const bf16_t* __restrict__ src, long ld, int T, int lane) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int c = lane + 64 * i, r = c / CPR, cc = (c - r * CPR) << 3;
+      const int rr = min(r, T - 1);                            // c >= CHUNKS implies r >= 16 * NT >= T
+      const uint32_t m = r < T ? 0xffffffffu : 0u;             // mask, not a select: the load must stay unconditional
+      const uint4 u = *reinterpret_cast<const uint4*>(src + (long)rr * ld + cc);
+      reg[i] = make_uint4(u.x & m, u.y & m, u.z & m, u.w & m);
+    }
   }
-}
+  __device__ __forceinline__ void put(char* img, int lane) const {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int c = lane + 64 * i, r = c / CPR, cc = (c - r * CPR) << 3;
+      if (CHUNKS % 64 == 0 || c < CHUNKS) *reinterpret_cast<uint4*>(img + r * STB + cc * 2) = reg[i];
+    }
+  }
+};
 template <int ND>
 __device__ __forceinline__ void store_rows(bf16_t* dst, long ld, const char* img, int T, int lane) {
   constexpr int CPR = 2 * ND, STB = 32 * ND + 16;
@@ -89,21 +105,22 @@ __device__ __forceinline__ float xsum2(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// bit 4*jt + r of the result: key 16*jt + 4*g + r exists and is attended (keymask != 0); `valid`: it exists
+// bit 4*jt + r of the result: key 16*jt + 4*g + r exists and is attended (keymask != 0); `valid`: it exists.
+// Lane l reads keymask[l] (and [l + 64] for more than 64 keys), two wave ballots give every lane all the keys.
 template <int NK>
 __device__ __forceinline__ void key_bits(const uint8_t* km, int Tk, int lane, uint32_t& attend, uint32_t& valid) {
   const int g = lane >> 4;
+  const uint8_t m0 = km[min(lane, Tk - 1)];
+  const uint8_t m1 = NK > 4 ? km[min(lane + 64, Tk - 1)] : (uint8_t)0;
+  const uint64_t e0 = __ballot(lane < Tk), e1 = NK > 4 ? __ballot(lane + 64 < Tk) : 0ull;
+  const uint64_t a0 = __ballot(m0 != 0) & e0, a1 = NK > 4 ? (__ballot(m1 != 0) & e1) : 0ull;
   attend = 0u; valid = 0u;
 #pragma unroll
-  for (int jt = 0; jt < NK; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = 16 * jt + 4 * g + r;
-      if (j < Tk) {
-        valid |= 1u << (4 * jt + r);
-        if (km[j]) attend |= 1u << (4 * jt + r);
-      }
-    }
+  for (int jt = 0; jt < NK; ++jt) {
+    const int sh = 16 * (jt & 3) + 4 * g;
+    attend |= (uint32_t)(((jt < 4 ? a0 : a1) >> sh) & 0xfull) << (4 * jt);
+    valid |= (uint32_t)(((jt < 4 ? e0 : e1) >> sh) & 0xfull) << (4 * jt);
+  }
 }
 
 // P^T tiles of one 16-query column block `it`: in: raw scores S^T (acc), out: probabilities (before dropout) and
@@ -154,9 +171,10 @@ __device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, uint
 // fragment X[r0 + (lane & 15)][c0 + 4 (lane >> 4) + e] straight from global memory (rows >= T read as zero)
 __device__ __forceinline__ s4_t frag_rows_global(const bf16_t* src, long ld, int T, int r0, int c0, int lane) {
   const int r = r0 + (lane & 15);
-  s4_t v = {0, 0, 0, 0};
-  if (r < T) v = *reinterpret_cast<const s4_t*>(src + (long)r * ld + c0 + 4 * (lane >> 4));
-  return v;
+  // unconditional load (last row for the padding rows) and a mask: no branch, the loads stay batched
+  const uint2 u = *reinterpret_cast<const uint2*>(src + (long)min(r, T - 1) * ld + c0 + 4 * (lane >> 4));
+  const uint32_t m = r < T ? 0xffffffffu : 0u;
+  return __builtin_bit_cast(s4_t, make_uint2(u.x & m, u.y & m));
 }
 
 template <int NQ, int NK, int ND> struct FwdLds { static constexpr int STB = 32 * ND + 16, BYTES = 16 * (NQ + 2 * NK) * STB; };
@@ -176,11 +194,18 @@ __global__ __launch_bounds__(64 * W) void attn_fwd_mfma(const AttnArgs a) {
   char* Ks = Qs + 16 * NQ * STB;
   char* Vs = Ks + 16 * NK * STB;
   const int b = (int)(bh / a.heads), h = (int)(bh % a.heads), d = 16 * ND;
-  load_rows<ND>(Qs, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, 16 * NQ, lane);
-  load_rows<ND>(Ks, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, 16 * NK, lane);
-  load_rows<ND>(Vs, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, 16 * NK, lane);
   uint32_t attend, valid;
-  key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
+  {
+    RowTile<ND, NQ> tq;
+    RowTile<ND, NK> tk, tv;
+    tq.fetch(a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, lane);
+    tk.fetch(a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, lane);
+    tv.fetch(a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, lane);
+    key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
+    tq.put(Qs, lane);
+    tk.put(Ks, lane);
+    tv.put(Vs, lane);
+  }
   wave_sync();
   s4_t kf[NK][ND];
 #pragma unroll
@@ -237,16 +262,23 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
   char* Pi = Ks + 16 * G::NX * STB;     // dropout(P) [i][j], then dS [i][j]
   const int b = (int)(bh / a.heads), h = (int)(bh % a.heads), d = 16 * ND;
   const bf16_t* vg = a.v + (long)b * a.Tk * a.ldv + h * d;
-  load_rows<ND>(Qs, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, 16 * NQ, lane);
-  load_rows<ND>(Os, a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, 16 * NQ, lane);
-  load_rows<ND>(Ks, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, 16 * NK, lane);
   s4_t vf[NK][ND];                      // V is only ever contracted along its columns: fragments straight from global
-#pragma unroll
-  for (int jt = 0; jt < NK; ++jt)
-#pragma unroll
-    for (int ks = 0; ks < ND; ++ks) vf[jt][ks] = frag_rows_global(vg, a.ldv, a.Tk, 16 * jt, 16 * ks, lane);
   uint32_t attend, valid;
-  key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
+  {
+    RowTile<ND, NQ> tq, to;
+    RowTile<ND, NK> tk;
+    tq.fetch(a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, lane);
+    to.fetch(a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, lane);
+    tk.fetch(a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, lane);
+#pragma unroll
+    for (int jt = 0; jt < NK; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < ND; ++ks) vf[jt][ks] = frag_rows_global(vg, a.ldv, a.Tk, 16 * jt, 16 * ks, lane);
+    key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
+    tq.put(Qs, lane);
+    to.put(Os, lane);
+    tk.put(Ks, lane);
+  }
   wave_sync();
   const float ds = a.thr ? a.dscale : 1.0f;
   f4_t dq[ND][NQ];

@@ -548,9 +548,9 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
       row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
     }
   }
-  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS in this kernel.
-  // The LDS tree used before lost 16-lane slices of its writes when ds_read_b64_tr_b16 kernels (dgrad / wgrad GEMMs)
-  // shared the CU -- reproduced with tools/embed_stress.py, see DESIGN.md section 8.
+  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS tree and no
+  // workgroup barrier in this kernel.  (The wrong lanes 48..63 once seen here beside the dgrad / wgrad GEMMs came from
+  // packed-fp32 instructions, not from LDS: DESIGN.md section 8, tools/embed_stress.py; the build bans them.)
   const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
   row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
   row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
@@ -614,9 +614,9 @@ __global__ __launch_bounds__(256) void embed_image_bwd_kernel(
     row_acc(abl, dy);       // = d b_loc = d b_img (both are plain column sums of d_sum)
     row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
   }
-  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS in this kernel.
-  // The LDS tree used before lost 16-lane slices of its writes when ds_read_b64_tr_b16 kernels (dgrad / wgrad GEMMs)
-  // shared the CU -- reproduced with tools/embed_stress.py, see DESIGN.md section 8.
+  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS tree and no
+  // workgroup barrier in this kernel.  (The wrong lanes 48..63 once seen here beside the dgrad / wgrad GEMMs came from
+  // packed-fp32 instructions, not from LDS: DESIGN.md section 8, tools/embed_stress.py; the build bans them.)
   const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
   row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
   row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
