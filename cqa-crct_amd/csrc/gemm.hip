@@ -765,7 +765,8 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 // Configuration of the LDS-DMA kernel per call, from tools/gemm_lab measurements on MI355X at the
 // CRCT shapes (profiles/gemm_lab_r1.txt): every GEMM here is a 1-2 wave problem whose time is set by
 // L2->LDS traffic and prefetch latency, so 8-wave workgroups with 2 resident per CU win.
-//   12: 128x64, 8 waves (4x2), 2 stages    11: 64x128, 8 waves, 3 stages    3: 64x64, 4 waves, 4 stages
+//   12: 128x64, 8 waves (4x2), 2 stages    15: the same with 3 stages (narrow output, long K)    3: 64x64, 4 waves, 4 stages
+//   grouped weight gradients: 4 = 128x128, 8 waves (2x4), 3 stages
 static int env_cfg(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
 static int pick_pipe_config(const CrctGemmArgs& g) {
   // developer overrides for A/B runs of the whole step: CRCT_GEMM_FWD / _DGRAD / _WGRAD = configuration id
@@ -777,10 +778,13 @@ static int pick_pipe_config(const CrctGemmArgs& g) {
   }
   if (g.tb) {
     if (ov_d >= 0) return ov_d;
+    static const int ov_dl = env_cfg("CRCT_GEMM_DGRAD_LONGK");
+    if (g.N <= 1024 && g.K >= 2048) return ov_dl >= 0 ? ov_dl : 15;  // narrow output, long K
     return 12;
   }
   if (ov_f >= 0) return ov_f;
-  if (g.N <= 1024 && g.K >= 2048) return 11;                        // narrow output, long K
+  static const int ov_fl = env_cfg("CRCT_GEMM_FWD_LONGK");
+  if (g.N <= 1024 && g.K >= 2048) return ov_fl >= 0 ? ov_fl : 15;   // narrow output, long K
   return 12;
 }
 
