@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     for (size_t si = 0; si < shapes.size(); ++si) {
       auto& s = shapes[si];
       if (only_shape >= 0 && (int)si != only_shape) continue;
-      for (int tile = 0; tile < (generic ? 4 : 15); ++tile) {
+      for (int tile = 0; tile < (generic ? 4 : 16); ++tile) {
         if (only_tile >= 0 && tile != only_tile) continue;
         CrctGemmArgs g; memset(&g, 0, sizeof(g));
         g.A = A; g.B = B; g.C = C; g.M = s.M; g.N = s.N; g.K = s.K; g.ta = s.ta; g.tb = s.tb;
