@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <vector>
+#include <utility>
 
 #include "common.cuh"
 #include "crct_internal.h"
@@ -28,8 +29,12 @@
 namespace {
 
 constexpr int BK = 64;
-#ifndef CRCT_GEMM_SPLIT_HALVES
-#define CRCT_GEMM_SPLIT_HALVES 1
+#ifndef CRCT_GEMM_PIPE_MODE
+// 1: register-pipelined main loop (fragments of the next K tile read under the MFMAs of the current one).  Measured, not
+// the default: stand-alone it is within +-3 % of mode 0 (0 to 20 % slower at K = 768), and in the step it costs 0.8 ms
+// (8.9 -> 9.7 ms): 110 instead of 74 VGPRs per lane means two instead of three 8-wave workgroups per CU, and the
+// co-residency with the other streams' kernels is worth more than the overlap inside one workgroup.
+#define CRCT_GEMM_PIPE_MODE 0
 #endif
 
 // byte offset of 16-byte chunk `ch` (0..7) of row r in the [R][64] bf16 image (128-B rows)
@@ -104,6 +109,69 @@ __device__ __forceinline__ void frag_async_wait() {
 #undef CRCT_LGKM_CASE
 }
 __device__ __forceinline__ void frag_async_use(bf8_t& f) { asm volatile("" : "+v"(f)); }   // orders consumers behind the wait
+
+// ---- fragment reads with precomputed per-lane base addresses and immediate offsets (no address arithmetic in the loop)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int OFF>
+__device__ __forceinline__ bf8_t lds_read_b128_imm(uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  bf8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ s4_t lds_read_tr_imm(uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  s4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+// Per-lane bases of one operand's fragments inside a stage (byte offsets from the stage start).  WT = 16-row tiles per wave,
+// r0w = the wave's first row.  K-contiguous image: base[h] for the two 32-deep halves, tile i adds 2048 bytes.  Transposed
+// image: base[2 * (i & 1) + {0: k, 1: k + 4}] at h = 0, tile pair i >> 1 adds 512 bytes and half h adds WC * 2048 (see off_tr).
+template <bool T, int WC, int WT>
+struct FragBase {
+  static constexpr int NB = T ? (WT > 1 ? 4 : 2) : 2;
+  uint32_t b[NB];
+  __device__ __forceinline__ void init(int img_off, int r0w, int lane) {
+    if constexpr (!T) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) b[h] = img_off + off_rowmajor(r0w + (lane & 15), 4 * h + (lane >> 4));
+    } else {
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+      for (int par = 0; par < NB / 2; ++par) {
+        const int ch = ((r0w + 16 * par) >> 3) + (p >> 1);
+        b[2 * par + 0] = img_off + off_tr<WC>(8 * g + q, ch) + 8 * (p & 1);
+        b[2 * par + 1] = img_off + off_tr<WC>(8 * g + q + 4, ch) + 8 * (p & 1);
+      }
+    }
+  }
+  // fragments of K half H for all WT tiles, from the stage at byte address `stage`
+  __device__ __forceinline__ void at(uint32_t stage, uint32_t (&cur)[NB]) const {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cur[j] = stage + b[j];
+  }
+  template <int H>
+  static __device__ __forceinline__ void read(const uint32_t (&cur)[NB], bf8_t (&f)[WT]) {
+    static_for<WT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (!T) {
+        f[i] = lds_read_b128_imm<i * 2048>(cur[H]);
+      } else {
+        constexpr int OFF = WC * 2048 * H + 512 * (i >> 1);
+        const s4_t lo = lds_read_tr_imm<OFF>(cur[2 * (i & 1) + 0]);
+        const s4_t hi = lds_read_tr_imm<OFF>(cur[2 * (i & 1) + 1]);
+        const s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        f[i] = __builtin_bit_cast(bf8_t, v);
+      }
+    });
+  }
+};
 
 // ---- global -> register staging of one operand tile: R = 32*RC rows (output index) x 64 (contraction)
 template <bool T, int RC>
@@ -529,66 +597,44 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
   const int npre = nk < NS - 1 ? nk : NS - 1;
   for (int t = 0; t < npre; ++t) issue(t, t);
 
-  int st = 0, st_next = NS - 1;      // stage holding tile kt; stage the next prefetch goes to
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = (nk - 1 < kt + NS - 2 ? nk - 1 : kt + NS - 2) - kt;     // younger tiles that may stay in flight
+  // All fragment reads are uncounted asm reads (see load_frag_tr_async) from per-lane base addresses computed once, with
+  // immediate offsets: the only address arithmetic per K tile is adding the stage offset to the <= 8 bases.
+  static_assert(BK == 64, "two MFMA K-halves per tile");
+  FragBase<TA, TM, WTM> fbA;
+  FragBase<TB, TN, WTN> fbB;
+  fbA.init(0, wm * (BM / WM), lane);
+  fbB.init(A_BYTES, wn * (BN / WN), lane);
+  const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+  constexpr int N_HALF = WTM * (TA ? 2 : 1) + WTN * (TB ? 2 : 1);      // LDS reads per half (a transposed fragment takes two)
+  auto wait_tile = [&](int t) {        // tile t has landed; the younger tiles issued so far may stay in flight
+    const int ahead = (nk - 1 < t + NS - 2 ? nk - 1 : t + NS - 2) - t;
     if (NS >= 6 && ahead >= 4) wait_vmcnt<4 * L>();
     else if (NS >= 5 && ahead >= 3) wait_vmcnt<3 * L>();
     else if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk && !(dbg & 2)) issue(kt + NS - 1, st_next);
-    const char* ldsA = smem + st * STAGE;
-    const char* ldsB = ldsA + A_BYTES;
-    // fragments of both 32-deep halves of the K tile are requested up front; the MFMAs of the first half run while the
-    // reads of the second are still in flight
-    static_assert(BK == 64, "two MFMA K-halves per tile");
-    constexpr bool ASYNC = TA || TB;
-    constexpr int N_HALF = WTM * (TA ? 2 : 1) + WTN * (TB ? 2 : 1);      // LDS reads per half (a transposed fragment takes two)
-    bf8_t fm[2][WTM], fn[2][WTN];
-    auto request = [&](int h) {
+  };
+  auto request = [&](int stg, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN]) {
+    uint32_t ca[FragBase<TA, TM, WTM>::NB], cb[FragBase<TB, TN, WTN>::NB];
+    fbA.at(smem_base + stg * STAGE, ca);
+    fbB.at(smem_base + stg * STAGE, cb);
+    FragBase<TA, TM, WTM>::template read<0>(ca, fm[0]);
+    FragBase<TB, TN, WTN>::template read<0>(cb, fn[0]);
+    FragBase<TA, TM, WTM>::template read<1>(ca, fm[1]);
+    FragBase<TB, TN, WTN>::template read<1>(cb, fn[1]);
+  };
+  auto multiply = [&](int h, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN]) {
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) {
-        if constexpr (TA) fm[h][i] = load_frag_tr_async<TM>(ldsA, wm * (BM / WM) + i * 16, h * 32, lane);
-        else if constexpr (ASYNC) fm[h][i] = load_frag_async(ldsA, wm * (BM / WM) + i * 16, h * 32, lane);
-        else fm[h][i] = load_frag<false, TM>(ldsA, wm * (BM / WM) + i * 16, h * 32, lane);
-      }
+    for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
 #pragma unroll
-      for (int i = 0; i < WTN; ++i) {
-        if constexpr (TB) fn[h][i] = load_frag_tr_async<TN>(ldsB, wn * (BN / WN) + i * 16, h * 32, lane);
-        else if constexpr (ASYNC) fn[h][i] = load_frag_async(ldsB, wn * (BN / WN) + i * 16, h * 32, lane);
-        else fn[h][i] = load_frag<false, TN>(ldsB, wn * (BN / WN) + i * 16, h * 32, lane);
-      }
-    };
-#if CRCT_GEMM_SPLIT_HALVES
-    request(0);
-    request(1);
-#endif
+    for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#if !CRCT_GEMM_SPLIT_HALVES
-      request(h);
-#endif
-      if constexpr (ASYNC) {
-        if (h == 0 && CRCT_GEMM_SPLIT_HALVES) frag_async_wait<(N_HALF <= 15 ? N_HALF : 0)>();
-        else frag_async_wait<0>();
+    for (int a = 0; a < WTN; ++a)
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
-#pragma unroll
-        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
-      }
-#pragma unroll
-      for (int a = 0; a < WTN; ++a)
-#pragma unroll
-        for (int b = 0; b < WTM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[h][a], fm[h][b], acc[a][b], 0, 0, 0);
-      // keep the first half's MFMAs in front of the second wait (they are not ordered against it otherwise)
-      if constexpr (ASYNC) {
-        if (h == 0) asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));
-      }
-    }
+      for (int b = 0; b < WTM; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[h][a], fm[h][b], acc[a][b], 0, 0, 0);
+  };
+  auto rowsums = [&](int kt, bf8_t (&fm)[2][WTM]) {
     if (do_rs) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -597,9 +643,61 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
           for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[h][b], accb[b], 0, 0, 0);
         }
     }
+  };
+#if CRCT_GEMM_PIPE_MODE == 1
+  // register-pipelined: while the MFMAs of tile kt run from one register set, the reads of tile kt+1 fill the other;
+  // tile t lives in stage t % NS and its stage goes back to the DMA one barrier after its reads have completed
+  {
+    bf8_t fmA[2][WTM], fnA[2][WTN], fmB[2][WTM], fnB[2][WTN];
+    auto step = [&](int kt, int stg, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN], bf8_t (&fm_n)[2][WTM], bf8_t (&fn_n)[2][WTN]) {
+      frag_async_wait<0>();                            // tile kt is in registers
+      if (kt + 1 < nk) {
+        wait_tile(kt + 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NS < nk && !(dbg & 2)) issue(kt + NS, stg);
+        request(stg + 1 == NS ? 0 : stg + 1, fm_n, fn_n);
+      }
+      multiply(0, fm, fn);
+      multiply(1, fm, fn);
+      rowsums(kt, fm);
+    };
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (NS - 1 < nk && !(dbg & 2)) issue(NS - 1, NS - 1);
+    request(0, fmA, fnA);
+    int stg = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(kt, stg, fmA, fnA, fmB, fnB);
+      stg = stg + 1 == NS ? 0 : stg + 1;
+      if (kt + 1 < nk) {
+        step(kt + 1, stg, fmB, fnB, fmA, fnA);
+        stg = stg + 1 == NS ? 0 : stg + 1;
+      }
+    }
+  }
+#else
+  int st = 0, st_next = NS - 1;      // stage holding tile kt; stage the next prefetch goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_tile(kt);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk && !(dbg & 2)) issue(kt + NS - 1, st_next);
+    // fragments of both 32-deep halves of the K tile are requested up front; the MFMAs of the first half run while the
+    // reads of the second are still in flight
+    bf8_t fm[2][WTM], fn[2][WTN];
+    request(st, fm, fn);
+    frag_async_wait<(N_HALF <= 15 ? N_HALF : 0)>();
+    multiply(0, fm, fn);
+    asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));     // keep the first half's MFMAs in front of the second wait
+    frag_async_wait<0>();
+    multiply(1, fm, fn);
+    rowsums(kt, fm);
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
   }
+#endif
   if (dbg & 1) {      // ablation: keep the accumulators alive, skip the epilogue
 #pragma unroll
     for (int a = 0; a < WTN; ++a)

@@ -5,4 +5,5 @@ for i in 1 2 3; do
   cp /tmp/main.so cqa-crct_amd/crct/libcrct_hip.so; run main
   cp tools/libcrct_alt.so cqa-crct_amd/crct/libcrct_hip.so; run alt
 done
+if [ "$1" = "test-alt" ]; then python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm or wgrad" 2>&1 | tail -2; fi
 cp /tmp/main.so cqa-crct_amd/crct/libcrct_hip.so
