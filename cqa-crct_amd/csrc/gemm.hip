@@ -68,36 +68,14 @@ __device__ __forceinline__ bf8_t load_frag(const char* lds, int r0, int k0, int 
   }
 }
 
-// The same transposed fragment for the LDS-DMA kernel, as inline assembly.  The compiler treats the transposing-read
-// builtin as a possible LDS *store*, so behind every buffer_load ... lds still in flight it puts an s_waitcnt vmcnt(0)
-// in front of the first such read: the prefetch of the next K tile then lands before the current one is used and
-// nothing overlaps (measured: text FFN-up dgrad 37 us, of which 19 us exposed DMA latency; its K-contiguous twin 10 us).
-// An asm read carries no memory operand, so the counted vmcnt of the pipeline is the only wait; the price is that the
-// compiler does not count these reads in lgkmcnt either: frag_async_wait() must follow before the registers are used.
-template <int WC>
-__device__ __forceinline__ bf8_t load_frag_tr_async(const char* lds, int r0, int k0, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int k = k0 + 8 * g + q;
-  const int ch = (r0 >> 3) + (p >> 1);
-  const uint32_t base = (uint32_t)(uintptr_t)lds;
-  const uint32_t a0 = base + off_tr<WC>(k, ch) + 8 * (p & 1);
-  const uint32_t a1 = base + off_tr<WC>(k + 4, ch) + 8 * (p & 1);
-  s4_t lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
-  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf8_t, v);
-}
-// K-contiguous fragment (one 16-byte read) in the same uncounted form, so that a kernel with a transposed operand issues
-// ALL its fragment reads in a known order and can wait for the first half of them only
-__device__ __forceinline__ bf8_t load_frag_async(const char* lds, int r0, int k0, int lane) {
-  const int r = r0 + (lane & 15);
-  const int ch = (k0 >> 3) + (lane >> 4);
-  const uint32_t a = (uint32_t)(uintptr_t)lds + off_rowmajor(r, ch);
-  bf8_t v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
-  return v;
-}
+// Fragment reads of the LDS-DMA kernel are inline assembly.  The compiler treats the transposing-read builtin as a
+// possible LDS *store*, so behind every buffer_load ... lds still in flight it puts an s_waitcnt vmcnt(0) in front of the
+// first such read: the prefetch of the next K tile then lands before the current one is used and nothing overlaps
+// (measured: text FFN-up dgrad 37 us, of which 19 us exposed DMA latency; its K-contiguous twin 10 us).  An asm read
+// carries no memory operand, so the counted vmcnt of the pipeline is the only wait; the price is that the compiler does
+// not count these reads in lgkmcnt either: frag_async_wait<N>() must follow before the registers are used, and
+// frag_async_use() pins the consumers behind that wait.  All reads of a K tile are issued in a fixed order so that the
+// first half can be waited for alone.
 template <int N>
 __device__ __forceinline__ void frag_async_wait() {
   static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
@@ -597,7 +575,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
   const int npre = nk < NS - 1 ? nk : NS - 1;
   for (int t = 0; t < npre; ++t) issue(t, t);
 
-  // All fragment reads are uncounted asm reads (see load_frag_tr_async) from per-lane base addresses computed once, with
+  // All fragment reads are uncounted asm reads (see frag_async_wait) from per-lane base addresses computed once, with
   // immediate offsets: the only address arithmetic per K tile is adding the stage offset to the <= 8 bases.
   static_assert(BK == 64, "two MFMA K-halves per tile");
   FragBase<TA, TM, WTM> fbA;
