@@ -16,21 +16,22 @@ struct Row {
   float v[NCH][8];
 };
 
+// All loads of the row are issued before the first one is unpacked, and none is conditional: a chunk past the end of
+// the row re-reads the last chunk and is masked to zero (a branch around each 16-byte load made the compiler wait for
+// every load separately: 4-6 serial memory round trips per row in the LayerNorm kernels).
 template <int NCH>
 __device__ __forceinline__ void row_load_bf16(Row<NCH>& r, const bf16_t* p, int H, int lane) {
+  uint4 u[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) u[i] = *reinterpret_cast<const uint4*>(p + min((lane + 64 * i) * 8, H - 8));
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = (lane + 64 * i) * 8;
-    if (c < H) {
-      const uint4 u = *reinterpret_cast<const uint4*>(p + c);
-      r.v[i][0] = bf2f((bf16_t)(u.x & 0xffff)); r.v[i][1] = bf2f((bf16_t)(u.x >> 16));
-      r.v[i][2] = bf2f((bf16_t)(u.y & 0xffff)); r.v[i][3] = bf2f((bf16_t)(u.y >> 16));
-      r.v[i][4] = bf2f((bf16_t)(u.z & 0xffff)); r.v[i][5] = bf2f((bf16_t)(u.z >> 16));
-      r.v[i][6] = bf2f((bf16_t)(u.w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(u.w >> 16));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
-    }
+    const uint32_t m = (lane + 64 * i) * 8 < H ? 0xffffffffu : 0u;
+    const uint32_t x = u[i].x & m, y = u[i].y & m, z = u[i].z & m, w = u[i].w & m;
+    r.v[i][0] = bf2f((bf16_t)(x & 0xffff)); r.v[i][1] = bf2f((bf16_t)(x >> 16));
+    r.v[i][2] = bf2f((bf16_t)(y & 0xffff)); r.v[i][3] = bf2f((bf16_t)(y >> 16));
+    r.v[i][4] = bf2f((bf16_t)(z & 0xffff)); r.v[i][5] = bf2f((bf16_t)(z >> 16));
+    r.v[i][6] = bf2f((bf16_t)(w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(w >> 16));
   }
 }
 template <int NCH>
@@ -48,18 +49,18 @@ __device__ __forceinline__ void row_store_bf16(const Row<NCH>& r, bf16_t* p, int
 }
 template <int NCH>
 __device__ __forceinline__ void row_load_f32(Row<NCH>& r, const float* p, int H, int lane) {
+  float4 a[NCH], b[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = (lane + 64 * i) * 8;
-    if (c < H) {
-      const float4 a = *reinterpret_cast<const float4*>(p + c);
-      const float4 b = *reinterpret_cast<const float4*>(p + c + 4);
-      r.v[i][0] = a.x; r.v[i][1] = a.y; r.v[i][2] = a.z; r.v[i][3] = a.w;
-      r.v[i][4] = b.x; r.v[i][5] = b.y; r.v[i][6] = b.z; r.v[i][7] = b.w;
-    } else {
+    const int c = min((lane + 64 * i) * 8, H - 8);
+    a[i] = *reinterpret_cast<const float4*>(p + c);
+    b[i] = *reinterpret_cast<const float4*>(p + c + 4);
+  }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
-    }
+  for (int i = 0; i < NCH; ++i) {
+    const float m = (lane + 64 * i) * 8 < H ? 1.f : 0.f;
+    r.v[i][0] = a[i].x * m; r.v[i][1] = a[i].y * m; r.v[i][2] = a[i].z * m; r.v[i][3] = a[i].w * m;
+    r.v[i][4] = b[i].x * m; r.v[i][5] = b[i].y * m; r.v[i][6] = b[i].z * m; r.v[i][7] = b[i].w * m;
   }
 }
 template <int NCH>
@@ -112,6 +113,28 @@ __device__ __forceinline__ void row_stats(const Row<NCH>& r, int H, int lane, fl
   rstd = 1.0f / sqrtf(var + eps);
 }
 
+// y = gamma * (x - mean) * rstd + beta, optional post-norm dropout keyed by (row*H + col); gamma / beta held in registers
+// (loaded once per wave, outside the row loop)
+template <int NCH>
+__device__ __forceinline__ void row_normalize(Row<NCH>& r, const Row<NCH>& gamma, const Row<NCH>& beta, int H, int lane,
+                                              float mean, float rstd, long row, uint32_t thr, float scale,
+                                              uint32_t site, uint64_t seed) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = gamma.v[i][j] * ((r.v[i][j] - mean) * rstd) + beta.v[i][j];
+      if (thr) {
+        const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)c;
+        const Philox4 p0 = philox4x32_10(seed, site, idx >> 2), p1 = philox4x32_10(seed, site, (idx >> 2) + 1);
+        const uint32_t u[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[i][j] = u[j] >= thr ? r.v[i][j] * scale : 0.f;
+      }
+    }
+  }
+}
 // y = gamma * (x - mean) * rstd + beta, optional post-norm dropout keyed by (row*H + col)
 template <int NCH>
 __device__ __forceinline__ void row_normalize(Row<NCH>& r, const float* gamma, const float* beta, int H, int lane,
@@ -158,6 +181,36 @@ __device__ __forceinline__ void row_apply_dropmask(Row<NCH>& r, int H, int lane,
 
 // LayerNorm backward of one row.  in: dy (gradient w.r.t. y), x (pre-norm row).  out: dy <- dx,
 // xhat in x.  dgamma/dbeta accumulators updated.
+template <int NCH>
+__device__ __forceinline__ void row_ln_bwd(Row<NCH>& dy, Row<NCH>& x, const Row<NCH>& gamma, int H, int lane,
+                                           float mean, float rstd, Row<NCH>& acc_dg, Row<NCH>& acc_db) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (x.v[i][j] - mean) * rstd;
+        x.v[i][j] = xh;
+        acc_dg.v[i][j] += dy.v[i][j] * xh;
+        acc_db.v[i][j] += dy.v[i][j];
+        const float g = dy.v[i][j] * gamma.v[i][j];
+        dy.v[i][j] = g;
+        s1 += g; s2 += g * xh;
+      }
+    }
+  }
+  const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dy.v[i][j] = rstd * (dy.v[i][j] - c1 - x.v[i][j] * c2);
+    }
+  }
+}
 template <int NCH>
 __device__ __forceinline__ void row_ln_bwd(Row<NCH>& dy, Row<NCH>& x, const float* gamma, int H, int lane,
                                            float mean, float rstd, Row<NCH>& acc_dg, Row<NCH>& acc_db) {
@@ -289,12 +342,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H, float eps,
                                                      uint32_t thr, float scale, uint32_t site, uint64_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Row<NCH> g, b;
+  row_load_f32(g, gamma, H, lane);
+  row_load_f32(b, beta, H, lane);
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
     Row<NCH> r;
     row_load_bf16(r, x + row * H, H, lane);
     float mean, rstd;
     row_stats(r, H, lane, eps, mean, rstd);
-    row_normalize(r, gamma, beta, H, lane, mean, rstd, row, thr, scale, site, seed);
+    row_normalize(r, g, b, H, lane, mean, rstd, row, thr, scale, site, seed);
     row_store_bf16(r, y + row * H, H, lane);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
   }
@@ -309,14 +365,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      uint32_t post_thr, float post_scale, uint32_t post_site,
                                                      uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Row<NCH> adg, adb, adl;
+  Row<NCH> adg, adb, adl, g;
   row_zero(adg); row_zero(adb); row_zero(adl);
+  row_load_f32(g, gamma, H, lane);
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
     Row<NCH> dy, x;
+    const float mean = mean_p[row], rstd = rstd_p[row];
     row_load_bf16(dy, dy_p + row * H, H, lane);
     row_load_bf16(x, x_p + row * H, H, lane);
     row_apply_dropmask(dy, H, lane, row, post_thr, post_scale, post_site, seed);
-    row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
+    row_ln_bwd(dy, x, g, H, lane, mean, rstd, adg, adb);
     row_store_bf16(dy, dx_p + row * H, H, lane);
     if (dxl_p) {
       row_apply_dropmask(dy, H, lane, row, lin_thr, lin_scale, lin_site, seed);
