@@ -399,7 +399,7 @@ struct FinalizeArgs {
   const float* partials;
 };
 // 32 columns (8 threads x float4) x 32 row-groups per 256-thread block: every thread sums nblk/32 partial rows with
-// four independent 16-byte loads in flight, then the 32 row-group sums of a column quad are added in a fixed order.
+// eight independent 16-byte loads in flight, then the 32 row-group sums of a column quad are added in a fixed order.
 __global__ __launch_bounds__(256) void finalize_partials_kernel(const FinalizeArgs a) {
   __shared__ float4 red[32][9];
   const int q = blockIdx.y;
@@ -410,22 +410,32 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const FinalizeAr
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < a.H) {
     const float* p = a.partials + ((long)q * a.nblk) * a.H + c;
-    float4 s0 = s, s1 = s, s2 = s, s3 = s;
+    float4 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = s;
     int b = rg;
+    for (; b + 224 < a.nblk; b += 256) {            // eight independent 16-byte loads in flight per thread
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (long)(b + 32 * u) * a.H);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
+    }
     for (; b + 96 < a.nblk; b += 128) {
-      const float4 x0 = *reinterpret_cast<const float4*>(p + (long)b * a.H), x1 = *reinterpret_cast<const float4*>(p + (long)(b + 32) * a.H);
-      const float4 x2 = *reinterpret_cast<const float4*>(p + (long)(b + 64) * a.H), x3 = *reinterpret_cast<const float4*>(p + (long)(b + 96) * a.H);
-      s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
-      s1.x += x1.x; s1.y += x1.y; s1.z += x1.z; s1.w += x1.w;
-      s2.x += x2.x; s2.y += x2.y; s2.z += x2.z; s2.w += x2.w;
-      s3.x += x3.x; s3.y += x3.y; s3.z += x3.z; s3.w += x3.w;
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(p + (long)(b + 32 * u) * a.H);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
     }
     for (; b < a.nblk; b += 32) {
       const float4 x0 = *reinterpret_cast<const float4*>(p + (long)b * a.H);
-      s0.x += x0.x; s0.y += x0.y; s0.z += x0.z; s0.w += x0.w;
+      acc[0].x += x0.x; acc[0].y += x0.y; acc[0].z += x0.z; acc[0].w += x0.w;
     }
-    s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
-    s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
+    s.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
+    s.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
+    s.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
+    s.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
   }
   red[rg][cl] = s;
   __syncthreads();
