@@ -790,7 +790,7 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   {
     size_t wmax = D.H > D.Hv ? D.H : D.Hv;
     for (int k = 0; k < 2; ++k) {
-      e->partials[k] = ar.take((size_t)8 * 4 * CRCT_LN_BWD_MAX_BLOCKS * wmax * 4);   // [7][4 waves x blocks][H]
+      e->partials[k] = ar.take((size_t)10 * 4 * CRCT_LN_BWD_MAX_BLOCKS * wmax * 4);   // [<= 9][4 waves x blocks][H]
     }
     e->embed_rows[0] = ar.take(Mt * D.H * 4);  e->embed_idx[0] = ar.take(2 * Mt * 4);
     e->embed_rows[1] = ar.take(Mv * D.Hv * 4); e->embed_idx[1] = ar.take(Mv * 4);

@@ -316,21 +316,27 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
     if (idx[r] == p) list[at++] = r;
   __syncthreads();
   for (int c = tid * 4; c < H; c += 1024) {
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float4 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     int i = 0;
-    for (; i + 1 < total; i += 2) {
-      const float4 x = *reinterpret_cast<const float4*>(rows + (long)list[i] * H + c);
-      const float4 y = *reinterpret_cast<const float4*>(rows + (long)list[i + 1] * H + c);
-      a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w;
-      a1.x += y.x; a1.y += y.y; a1.z += y.z; a1.w += y.w;
+    for (; i + 7 < total; i += 8) {                 // eight rows in flight per thread (a type row can list every token)
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(rows + (long)list[i + u] * H + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
     }
-    if (i < total) {
+    for (; i < total; ++i) {
       const float4 x = *reinterpret_cast<const float4*>(rows + (long)list[i] * H + c);
-      a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w;
+      acc[i & 7].x += x.x; acc[i & 7].y += x.y; acc[i & 7].z += x.z; acc[i & 7].w += x.w;
     }
     float4* dst = reinterpret_cast<float4*>(table + (long)p * H + c);
     float4 o = *dst;
-    o.x += a0.x + a1.x; o.y += a0.y + a1.y; o.z += a0.z + a1.z; o.w += a0.w + a1.w;
+    o.x += ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
+    o.y += ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
+    o.z += ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
+    o.w += ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
     *dst = o;
   }
 }
@@ -393,8 +399,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
 // dimension (ldo) > 1 column group: out index = c*stride_q
 struct FinalizeArgs {
-  float* out[8];
-  int stride[8];
+  float* out[10];
+  int stride[10];
   int Q, nblk, H, accumulate;
   const float* partials;
 };
@@ -581,11 +587,13 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     const float* __restrict__ rstd_p, const int64_t* __restrict__ ids, const int64_t* __restrict__ segs,
     const float* __restrict__ loc, const float* __restrict__ gamma, float* __restrict__ d_word,
     float* __restrict__ d_pos, float* __restrict__ d_type, float* __restrict__ partials, int B, int T, int H, int n_pos,
-    uint32_t thr, float scale, uint32_t site, uint64_t seed, float* __restrict__ rows_scratch, int* __restrict__ idx_scratch) {
+    uint32_t thr, float scale, uint32_t site, uint64_t seed, float* __restrict__ rows_scratch, int* __restrict__ idx_scratch,
+    int type_partials) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long M = (long)B * T;
-  Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3;
+  Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3, at0, at1;
   row_zero(adg); row_zero(adb); row_zero(abl); row_zero(aw0); row_zero(aw1); row_zero(aw2); row_zero(aw3);
+  row_zero(at0); row_zero(at1);
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
     const int b = (int)(row / T), t = (int)(row % T);
     const long seg = segs[row];
@@ -602,7 +610,12 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
       pid = t - fq;
       pid = pid < 0 ? 0 : (pid >= n_pos ? n_pos - 1 : pid);
     }
-    const int tyid = seg != 0 ? (int)(seg == -1 ? 0 : seg) : -1;
+    int tyid = seg != 0 ? (int)(seg == -1 ? 0 : seg) : -1;
+    if (type_partials) {               // two token types: their sums ride along as partial rows 7 and 8 (a type row lists
+      if (tyid == 0) row_acc(at0, dy);   // up to every token: one gather workgroup per type took 60 us at the tail of the step)
+      else if (tyid == 1) row_acc(at1, dy);
+      tyid = -1;
+    }
     if (rows_scratch) {                                                 // position / type sums: gather_sum_kernel afterwards
       row_store_f32(dy, rows_scratch + row * H, H, lane);
       if (lane == 0) { idx_scratch[row] = pid; idx_scratch[M + row] = tyid; }
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
       row_acc(aw0, dy, lv.x); row_acc(aw1, dy, lv.y); row_acc(aw2, dy, lv.z); row_acc(aw3, dy, lv.w);
     }
   }
-  // every WAVE stores its own partial rows ([7][4 * gridDim.x][H]; the finalize pass sums them): no LDS tree and no
+  // every WAVE stores its own partial rows ([7 or 9][4 * gridDim.x][H]; the finalize pass sums them): no LDS tree and no
   // workgroup barrier in this kernel.  (The wrong lanes 48..63 once seen here beside the dgrad / wgrad GEMMs came from
   // packed-fp32 instructions, not from LDS: DESIGN.md section 8, tools/embed_stress.py; the build bans them.)
   const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
@@ -627,6 +640,10 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
   row_store_f32(aw1, partials + (4 * nr + pr) * H, H, lane);
   row_store_f32(aw2, partials + (5 * nr + pr) * H, H, lane);
   row_store_f32(aw3, partials + (6 * nr + pr) * H, H, lane);
+  if (type_partials) {
+    row_store_f32(at0, partials + (7 * nr + pr) * H, H, lane);
+    row_store_f32(at1, partials + (8 * nr + pr) * H, H, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------ image embedding
@@ -732,6 +749,15 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
   return 0;
 }
 
+// the embedding backward kernels write 7 partial rows per wave: fewer, longer-running waves than the LayerNorm backward
+static int embed_bwd_blocks(long M) {
+  static const int cap = [] {
+    const char* e = getenv("CRCT_EMBED_BWD_BLOCKS");   // developer knob
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v < CRCT_LN_BWD_MAX_BLOCKS ? v : CRCT_LN_BWD_MAX_BLOCKS;
+  }();
+  return row_grid(M, cap);
+}
 int crct_layernorm_bwd_blocks(int M) {
   static const int cap = [] {
     const char* e = getenv("CRCT_LN_BWD_BLOCKS");   // developer knob (<= CRCT_LN_BWD_MAX_BLOCKS: buffers are sized for the maximum)
@@ -838,23 +864,29 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_types <= 0) rows_scratch = nullptr;      // atomics fall-back
-  const int nb = crct_layernorm_bwd_blocks((int)M);
+  const int nb = embed_bwd_blocks(M);
+  const int type_partials = rows_scratch && n_types == 2 && d_type;     // partials then hold 9 row sets (CRCT_EMBED_TEXT_PARTIALS)
   DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
                                      partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch,
-                                     rows_scratch ? idx_scratch : nullptr));
+                                     rows_scratch ? idx_scratch : nullptr, type_partials));
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
     const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch,
-                       (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + (type_partials ? 0 : n_types)), dim3(256), (size_t)M * sizeof(int), s,
+                       rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
     CRCT_CHECK_HIP(hipGetLastError());
   }
   FinalizeArgs fa = {};
   fa.out[0] = d_gamma; fa.out[1] = d_beta; fa.out[2] = d_bloc;
   fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
   for (int k = 0; k < 4; ++k) { fa.out[3 + k] = d_wloc ? d_wloc + k : nullptr; fa.stride[3 + k] = 4; }
-  fa.Q = 7; fa.nblk = nb * ROWS_PER_BLOCK; fa.H = H; fa.accumulate = 1; fa.partials = partials;
+  fa.Q = 7;
+  if (type_partials) {
+    fa.out[7] = d_type; fa.out[8] = d_type + H; fa.stride[7] = fa.stride[8] = 1;
+    fa.Q = 9;
+  }
+  fa.nblk = nb * ROWS_PER_BLOCK; fa.H = H; fa.accumulate = 1; fa.partials = partials;
   return launch_finalize(fa, s);
 }
 
@@ -883,7 +915,7 @@ extern "C" int crct_embed_image_bwd(const void* dy, const void* sum_saved, const
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_color <= 0) rows_scratch = nullptr;      // atomics fall-back
-  const int nb = crct_layernorm_bwd_blocks(M);
+  const int nb = embed_bwd_blocks(M);
   DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, loc, target, gamma, (bf16_t*)d_sum, d_color,
                                      partials, M, H, drop_thr, drop_scale, drop_site, seed, rows_scratch,
