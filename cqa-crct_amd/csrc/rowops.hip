@@ -611,9 +611,9 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
       pid = pid < 0 ? 0 : (pid >= n_pos ? n_pos - 1 : pid);
     }
     int tyid = seg != 0 ? (int)(seg == -1 ? 0 : seg) : -1;
-    if (type_partials) {               // two token types: their sums ride along as partial rows 7 and 8 (a type row lists
-      if (tyid == 0) row_acc(at0, dy);   // up to every token: one gather workgroup per type took 60 us at the tail of the step)
-      else if (tyid == 1) row_acc(at1, dy);
+    if (type_partials && (tyid == 0 || tyid == 1)) {   // the two question / answer token types hold most tokens: their sums
+      if (tyid == 0) row_acc(at0, dy);                 // ride along as partial rows 7 and 8 (one gather workgroup per type
+      else row_acc(at1, dy);                           // row took 60-110 us at the tail of the step); other types: gather
       tyid = -1;
     }
     if (rows_scratch) {                                                 // position / type sums: gather_sum_kernel afterwards
@@ -865,7 +865,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_types <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = embed_bwd_blocks(M);
-  const int type_partials = rows_scratch && n_types == 2 && d_type;     // partials then hold 9 row sets (CRCT_EMBED_TEXT_PARTIALS)
+  const int type_partials = rows_scratch && n_types >= 2 && d_type;     // partials then hold 9 row sets
   DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
                                      partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch,
@@ -873,7 +873,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
     const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + (type_partials ? 0 : n_types)), dim3(256), (size_t)M * sizeof(int), s,
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s,
                        rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
     CRCT_CHECK_HIP(hipGetLastError());
   }

@@ -172,7 +172,7 @@ int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* lo
  * thousands of tokens) through rows_scratch (fp32 [B*T][H]) + idx_scratch (int32 [2][B*T]) and a deterministic
  * gather-sum pass (one workgroup per table row); with rows_scratch == NULL they use atomics as well.  Reduces the
  * loc-Linear and LayerNorm parameter gradients.  partials: fp32 [9][4 * nblk][H], nblk = crct_layernorm_bwd_blocks(B*T)
- * (7 row sets + the two token-type sums when n_types == 2).
+ * (7 row sets + the sums of token types 0 and 1).
  * n_types = rows of the type table.  All parameter-gradient outputs are ACCUMULATED (caller zeroes per step). */
 int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
                         const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
