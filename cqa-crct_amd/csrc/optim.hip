@@ -10,6 +10,11 @@
 #include "common.cuh"
 #include "crct_internal.h"
 
+// non-temporal streaming of the optimizer state: measured 8.73 -> 8.60 ms per step (the next forward keeps its operands in
+// L2 / Infinity Cache while 7 GB of state stream past)
+#ifndef CRCT_ADAMW_NT
+#define CRCT_ADAMW_NT 1
+#endif
 namespace {
 constexpr int ADAMW_CHUNK = 4096;
 
@@ -32,11 +37,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   for (int64_t i = (int64_t)threadIdx.x * 4; i < n; i += 1024) {
     const int64_t e = base + i;
     if (i + 4 <= n) {
-      float4 pv = *reinterpret_cast<float4*>(p + e);
-      const float4 gv = *reinterpret_cast<const float4*>(g + e);
-      float4 mv = *reinterpret_cast<float4*>(m + e), vv = *reinterpret_cast<float4*>(v + e);
-      float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x * gsc, gv.y * gsc, gv.z * gsc, gv.w * gsc};
-      float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#if CRCT_ADAMW_NT      // streamed once per step: non-temporal, so the 7 GB do not evict the forward's operands from L2 / MALL
+      const f4_t pv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p + e));
+      const f4_t gv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g + e));
+      const f4_t mv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(m + e));
+      const f4_t vv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(v + e));
+#else
+      const f4_t pv = *reinterpret_cast<const f4_t*>(p + e), gv = *reinterpret_cast<const f4_t*>(g + e);
+      const f4_t mv = *reinterpret_cast<const f4_t*>(m + e), vv = *reinterpret_cast<const f4_t*>(v + e);
+#endif
+      float pa[4] = {pv[0], pv[1], pv[2], pv[3]}, ga[4] = {gv[0] * gsc, gv[1] * gsc, gv[2] * gsc, gv[3] * gsc};
+      float ma[4] = {mv[0], mv[1], mv[2], mv[3]}, va[4] = {vv[0], vv[1], vv[2], vv[3]};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         pa[k] *= decay;
@@ -44,11 +55,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         va[k] = beta2 * va[k] + (1.0f - beta2) * ga[k] * ga[k];
         pa[k] -= step_size * ma[k] / (sqrtf(va[k]) * inv_sqrt_bc2 + eps);
       }
+#if CRCT_ADAMW_NT
+      __builtin_nontemporal_store(f4_t{pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<f4_t*>(p + e));
+      __builtin_nontemporal_store(f4_t{ma[0], ma[1], ma[2], ma[3]}, reinterpret_cast<f4_t*>(m + e));
+      __builtin_nontemporal_store(f4_t{va[0], va[1], va[2], va[3]}, reinterpret_cast<f4_t*>(v + e));
+#else
       *reinterpret_cast<float4*>(p + e) = make_float4(pa[0], pa[1], pa[2], pa[3]);
       *reinterpret_cast<float4*>(m + e) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *reinterpret_cast<float4*>(v + e) = make_float4(va[0], va[1], va[2], va[3]);
+#endif
       if (pb) *reinterpret_cast<uint2*>(pb + e) = make_uint2(pack2bf(pa[0], pa[1]), pack2bf(pa[2], pa[3]));
-      if (zero_g) *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (zero_g) __builtin_nontemporal_store(f4_t{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4_t*>(g + e));
     } else {
       for (int64_t k = i; k < n; ++k) {
         const int64_t q = base + k;
