@@ -29,6 +29,9 @@
 namespace {
 
 constexpr int BK = 64;
+#ifndef CRCT_GEMM_NT_F32
+#define CRCT_GEMM_NT_F32 1
+#endif
 #ifndef CRCT_GEMM_PIPE_MODE
 // 1: register-pipelined main loop (fragments of the next K tile read under the MFMAs of the current one).  Measured, not
 // the default: stand-alone it is within +-3 % of mode 0 (0 to 20 % slower at K = 768), and in the step it costs 0.8 ms
@@ -441,6 +444,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
         for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16)); }
       }
       if (g.c_is_f32) {
+#if CRCT_GEMM_NT_F32   // fp32 outputs are weight gradients: written once per step, read by AdamW / the all-reduce much later
+        f4_t* dst = reinterpret_cast<f4_t*>(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n);
+        f4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        if (g.accumulate) {
+          o0 += __builtin_nontemporal_load(dst);
+          o1 += __builtin_nontemporal_load(dst + 1);
+        }
+        __builtin_nontemporal_store(o0, dst);
+        __builtin_nontemporal_store(o1, dst + 1);
+#else
         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n);
         float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
         if (g.accumulate) {
@@ -448,6 +461,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
           o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
         }
         dst[0] = o0; dst[1] = o1;
+#endif
       } else {
         uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long)m * g.ldc + n);
         if (g.accumulate) {
