@@ -363,7 +363,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------ LayerNorm bwd
-template <int NCH>
+// COMBINE: the four waves of a workgroup add their column partials through LDS and store ONE partial row set per
+// workgroup ([3][gridDim.x][H], a quarter of the per-wave traffic for the kernel and for the finalize pass); without it
+// (rows too long for 64 KB of LDS) every wave stores its own ([3][4 * gridDim.x][H]).
+template <int NCH, bool COMBINE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy_p, const bf16_t* __restrict__ x_p,
                                                      const float* __restrict__ mean_p, const float* __restrict__ rstd_p,
                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dx_p,
@@ -388,12 +391,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
     row_acc(adl, dy);
   }
-  // one partial row per WAVE ([3][4 * gridDim.x][H]), summed by the finalize pass on the side stream: no LDS tree and no
-  // workgroup barriers on the data stream
-  const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
-  row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
-  row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
-  row_store_f32(adl, partials + (2 * nr + pr) * H, H, lane);
+  if constexpr (COMBINE) {
+    extern __shared__ __attribute__((aligned(16))) float ln_lds[];      // [3][4][H]
+    row_store_f32(adg, ln_lds + (0 * ROWS_PER_BLOCK + wave) * H, H, lane);
+    row_store_f32(adb, ln_lds + (1 * ROWS_PER_BLOCK + wave) * H, H, lane);
+    row_store_f32(adl, ln_lds + (2 * ROWS_PER_BLOCK + wave) * H, H, lane);
+    __syncthreads();
+    const int H4 = H >> 2;
+    for (int i = threadIdx.x; i < 3 * H4; i += 256) {
+      const int q = i / H4, c = (i - q * H4) << 2;
+      const float* src = ln_lds + (long)q * ROWS_PER_BLOCK * H + c;
+      const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + H);
+      const float4 d = *reinterpret_cast<const float4*>(src + 2 * H), e = *reinterpret_cast<const float4*>(src + 3 * H);
+      *reinterpret_cast<float4*>(partials + ((long)q * gridDim.x + blockIdx.x) * H + c) =
+          make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+    }
+  } else {
+    const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+    row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
+    row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
+    row_store_f32(adl, partials + (2 * nr + pr) * H, H, lane);
+  }
 }
 
 // out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
@@ -768,6 +786,11 @@ int crct_layernorm_bwd_blocks(int M) {
 }
 
 // rows pass only: dx / dx_lin and the per-workgroup column partials [3][nblk][H]
+// the LayerNorm backward combines its waves' partial rows in LDS when [3][4][H] fp32 fit the default 64 KB
+static bool ln_bwd_combines(int H) {
+  static const bool off = getenv("CRCT_LN_BWD_NO_COMBINE") != nullptr;      // developer A/B switch
+  return !off && (size_t)3 * ROWS_PER_BLOCK * H * 4 <= 64 * 1024;
+}
 int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                             void* dx, void* dx_lin, float* partials, int M, int H, uint32_t post_thr, float post_scale,
                             uint32_t post_site, uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
@@ -776,9 +799,15 @@ int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, co
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int nb = crct_layernorm_bwd_blocks(M);
-  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
-                                     (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin, partials, M, H,
-                                     post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
+  if (ln_bwd_combines(H)) {
+    DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * H * 4, s,
+                                       (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin,
+                                       partials, M, H, post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
+  } else {
+    DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
+                                       (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin, partials, M, H,
+                                       post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
+  }
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -790,7 +819,8 @@ int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbe
   FinalizeArgs fa = {};
   fa.out[0] = dgamma; fa.out[1] = dbeta; fa.out[2] = dbias_lin;
   fa.stride[0] = fa.stride[1] = fa.stride[2] = 1;
-  fa.Q = 3; fa.nblk = crct_layernorm_bwd_blocks(M) * ROWS_PER_BLOCK; fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
+  fa.Q = 3; fa.nblk = crct_layernorm_bwd_blocks(M) * (ln_bwd_combines(H) ? 1 : ROWS_PER_BLOCK);
+  fa.H = H; fa.accumulate = accumulate; fa.partials = partials;
   return launch_finalize(fa, (hipStream_t)stream);
 }
 
