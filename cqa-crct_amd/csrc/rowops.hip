@@ -778,9 +778,9 @@ static int embed_bwd_blocks(long M) {
 }
 int crct_layernorm_bwd_blocks(int M) {
   static const int cap = [] {
-    const char* e = getenv("CRCT_LN_BWD_BLOCKS");   // developer knob (<= CRCT_LN_BWD_MAX_BLOCKS: buffers are sized for the maximum)
+    const char* e = getenv("CRCT_LN_BWD_BLOCKS");   // developer knob (buffers are sized for 4 x CRCT_LN_BWD_MAX_BLOCKS partial rows)
     const int v = e ? atoi(e) : 0;
-    return v > 0 && v < CRCT_LN_BWD_MAX_BLOCKS ? v : CRCT_LN_BWD_MAX_BLOCKS;
+    return v > 0 && v <= 4 * CRCT_LN_BWD_MAX_BLOCKS ? v : CRCT_LN_BWD_MAX_BLOCKS;
   }();
   return row_grid(M, cap);
 }

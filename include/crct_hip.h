@@ -97,7 +97,8 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
  *   dx_lin  bf16 [M][H]   (optional) dx with the PRE-norm dropout mask of the producing Linear
  *                         re-applied (site/seed of that Linear's epilogue) = gradient of dense(x)
  *   dgamma, dbeta, dbias_lin  fp32 [H]: column sums (dbias_lin = colsum(dx_lin or dx)), written or
- *                         accumulated (`accumulate`).  `partials` is fp32 scratch [3][4 * nblk][H] (one row per wave),
+ *                         accumulated (`accumulate`).  `partials` is fp32 scratch sized [3][4 * nblk][H] (the kernel fills one row per workgroup, or one per
+ *                         wave when [3][4][H] fp32 do not fit 64 KB of LDS),
  *                         nblk = crct_layernorm_bwd_blocks(M).
  */
 int crct_layernorm_bwd_blocks(int M);
