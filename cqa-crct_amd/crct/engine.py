@@ -103,6 +103,7 @@ class StepEngine(object):
         c.tol_margin, c.nsp_coeff, c.reg_coeff = step["tol_margin"], step["nsp_coeff"], step["reg_coeff"]
         c.grad_scale = step.get("grad_scale", 1.0)
         c.use_graph = int(bool(step.get("use_graph", False)))
+        c.wgrad_overwrite = int(bool(step.get("wgrad_overwrite", False)))
         g_nsp, g_reg = step.get("g_nsp"), step.get("g_reg")
         if c.use_graph:
             if not step.get("_seed_set"):
@@ -130,6 +131,17 @@ class StepEngine(object):
             step["_seg_done_keepalive"] = arr
             c.seg_done_events = C.cast(arr, C.c_void_p)
         return c
+
+    def wgrad_owned(self):
+        """(offsets, numels) of the weight gradients the engine may overwrite (see CrctStepCfg.wgrad_overwrite); valid after
+        at least one complete backward pass, and the set the engine honours from this call on."""
+        n = self.lib.crct_engine_wgrad_owned(self.handle, None, None, 0)
+        if n <= 0:
+            return [], []
+        off, num = (C.c_int64 * n)(), (C.c_int64 * n)()
+        n2 = self.lib.crct_engine_wgrad_owned(self.handle, off, num, n)
+        assert n2 == n
+        return list(off), list(num)
 
     def _enter(self, graph):
         """Stream the engine call is enqueued on: the caller's current stream, or (graph mode) the engine's own

@@ -48,7 +48,7 @@ class Batch(C.Structure):
 class StepCfg(C.Structure):
     _fields_ = [("training", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32), ("tol_margin", c_f32), ("nsp_coeff", c_f32),
                 ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("seg_ready_events", vp), ("seg_done_events", vp),
-                ("use_graph", c_i32)]
+                ("use_graph", c_i32), ("wgrad_overwrite", c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/crct_hip.h declares
@@ -91,6 +91,8 @@ PROTOTYPES = {
     "crct_engine_forward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp]),
     "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
     "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
+    "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
+    "crct_zero_runs": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp]),
     "crct_engine_graph_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crct_engine_tap": (c_i64, [vp, vp, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),
 }

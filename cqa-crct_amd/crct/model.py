@@ -17,6 +17,7 @@ import os
 import torch
 from torch import nn
 
+from . import lib as L
 from . import ops
 from .config import BertConfig
 from .engine import StepEngine
@@ -83,6 +84,9 @@ class CrctModel(nn.Module):
         self._param_events = None                    # set by FusedAdamW in overlap mode
         self._seg_done = None
         self._grads_dirty = True
+        self._wgrad_overwrite_next = False       # set by a lazy clear: the next backward pass writes the owned weight gradients
+        self._backward_passes = 0
+        self._lazy_plan_engine, self._lazy_plan = None, None
         self._grad_waits = None
         self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
@@ -181,8 +185,56 @@ class CrctModel(nn.Module):
         """Called by the fused optimizer, which rewrites the flat buffers and the shadow itself."""
         self._shadow_ver = self._flat_p._version
 
-    def zero_flat_grads(self):
-        self._flat_g.zero_()
+    def zero_flat_grads(self, lazy=False):
+        """Clear the gradients.  ``lazy``: only the gradients that backward ACCUMULATES into (biases, LayerNorm, embeddings,
+        heads: one launch over ~0.1 GB) -- the Linear weight gradients, which the engine produces with exactly one GEMM
+        each, are left as they are and WRITTEN by the next backward pass (CrctStepCfg.wgrad_overwrite).  Their ``.grad``
+        therefore holds stale values between ``zero_grad()`` and ``backward()``; the values after backward are bit-identical
+        to the eager path.  Falls back to the full fill until one backward pass has run."""
+        plan = self._lazy_zero_plan() if lazy else None
+        if plan is None:
+            self._flat_g.zero_()
+            self._wgrad_overwrite_next = False
+            return
+        off, num, blk_seg, blk_off, n_blk = plan
+        L.check(L.load().crct_zero_runs(self._flat_g.data_ptr(), off.data_ptr(), num.data_ptr(), blk_seg.data_ptr(),
+                                        blk_off.data_ptr(), n_blk, L.current_stream()), "zero_runs")
+        self._wgrad_overwrite_next = True
+
+    def _lazy_zero_plan(self):
+        """Device tables for crct_zero_runs over the complement of the engine's owned weight gradients (built once per
+        engine, after its first complete backward pass)."""
+        eng = self._engine
+        if eng is None or not getattr(self, "_backward_passes", 0):
+            return None
+        if getattr(self, "_lazy_plan_engine", None) is eng:
+            return self._lazy_plan
+        owned_off, owned_num = eng.wgrad_owned()
+        owned = sorted(zip(owned_off, owned_num))          # a fused QKV weight is one owned range over three tensors
+        starts = [o for o, _ in owned]
+        import bisect
+        runs = []
+        for e in sorted((e for e in self.table if e.used), key=lambda e: e.offset):
+            k = bisect.bisect_right(starts, e.offset) - 1
+            if k >= 0 and e.offset + e.numel <= owned[k][0] + owned[k][1]:
+                continue
+            if runs and runs[-1][0] + runs[-1][1] == e.offset:
+                runs[-1][1] += e.numel
+            else:
+                runs.append([e.offset, e.numel])
+        plan = None
+        if owned and runs:
+            dev = self._flat_g.device
+            num_host = torch.tensor([r[1] for r in runs], dtype=torch.int64)
+            lib = L.load()
+            n_blk = lib.crct_adamw_plan(num_host.data_ptr(), len(runs), None, None, 0)
+            blk_seg = torch.empty(n_blk, dtype=torch.int32)
+            blk_off = torch.empty(n_blk, dtype=torch.int64)
+            lib.crct_adamw_plan(num_host.data_ptr(), len(runs), blk_seg.data_ptr(), blk_off.data_ptr(), n_blk)
+            plan = (torch.tensor([r[0] for r in runs], dtype=torch.int64, device=dev), num_host.to(dev), blk_seg.to(dev),
+                    blk_off.to(dev), int(n_blk))
+        self._lazy_plan_engine, self._lazy_plan = eng, plan
+        return plan
 
     def _ensure_grad_views(self):
         """``optimizer.zero_grad()`` of stock torch sets ``.grad = None``: re-attach the views and clear."""
@@ -198,6 +250,7 @@ class CrctModel(nn.Module):
                 break
         if missing:
             self._flat_g.zero_()
+            self._wgrad_overwrite_next = False
             for e in self.table:
                 if e.used:
                     byname[e.name].grad = self._flat_g[e.offset:e.offset + e.numel].view(e.shape)
@@ -233,6 +286,10 @@ class CrctModel(nn.Module):
         self._grads_dirty = True                     # gradients are being accumulated again (optimizer bookkeeping)
         eng = self._engine
         self._grad_waits = None
+        if getattr(self, "_wgrad_overwrite_next", False) and getattr(self, "_lazy_plan_engine", None) is eng:
+            step = dict(step, wgrad_overwrite=True)  # first pass since a lazy clear: the owned weight gradients are written
+        self._wgrad_overwrite_next = False           # a further pass before the next clear accumulates
+        self._backward_passes = getattr(self, "_backward_passes", 0) + 1
         if self._ddp is None and self.record_segment_events and not step.get("use_graph"):
             evs = self.segment_done_events()
             step = dict(step, seg_done_events=evs)

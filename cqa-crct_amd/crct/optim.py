@@ -86,6 +86,10 @@ class FusedAdamW(torch.optim.Optimizer):
         # the update zeroes every gradient element it has consumed; the zero_grad() that follows is then free.  Off by
         # default: torch optimizers leave .grad untouched in step() (a caller may still want to read it there)
         self.fuse_zero_grad = False
+        # zero_grad() clears only what backward accumulates into; the Linear weight gradients are overwritten by the next
+        # backward pass (no 0.96 GB fill, no read-modify-write in the weight-gradient GEMMs: -0.3 ms per step).  Their
+        # .grad is stale (not zero) between zero_grad() and backward(); set False for the eager fill.
+        self.lazy_zero_grad = True
         # early mode (with overlap): the update of a segment starts as soon as the backward pass has finished that
         # segment's gradients (the engine marks it with events), i.e. it overlaps the REST OF BACKWARD instead of the
         # next forward; identical arithmetic, only the start time on the GPU moves
@@ -203,9 +207,9 @@ class FusedAdamW(torch.optim.Optimizer):
             return                                            # step() has already zeroed them (fuse_zero_grad)
         if self.overlap and self._opt_stream is not None:
             with torch.cuda.stream(self._opt_stream):        # after the update that is still reading the gradients
-                self.core.zero_flat_grads()
+                self.core.zero_flat_grads(lazy=self.lazy_zero_grad)
         else:
-            self.core.zero_flat_grads()
+            self.core.zero_flat_grads(lazy=self.lazy_zero_grad)
 
     def state_dict(self):
         for st in self.state.values():

@@ -135,6 +135,14 @@ struct crct_engine {
   std::vector<GraphEntry> graphs;
   bool graph_broken = false;
   std::vector<std::pair<int64_t, int64_t>> seg_range;
+  // weight-gradient ownership (CrctStepCfg.wgrad_overwrite): per flat offset of a Linear weight, how many weight-gradient
+  // GEMMs targeted it in the current backward pass / at most in any pass so far, and the set reported as "owned"
+  struct WgradSeen { int64_t numel = 0; int pass = 0, most = 0; };
+  std::unordered_map<int64_t, WgradSeen> wgrad_seen;
+  std::unordered_map<int64_t, int64_t> wgrad_owned;     // offset -> numel, frozen by crct_engine_wgrad_owned
+  void wgrad_pass_begin() {
+    for (auto& kv : wgrad_seen) { if (kv.second.pass > kv.second.most) kv.second.most = kv.second.pass; kv.second.pass = 0; }
+  }
   std::vector<Tap> taps;
   size_t final_t = 0, final_v = 0;   // offsets of the last-layer outputs
   int cur_t = 0, cur_v = 0;          // ping-pong index of the running activation gradients
@@ -304,6 +312,15 @@ struct Run {
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = x; g.C = G(l.w); g.lda = lddy; g.ldb = ldx; g.ldc = l.in; g.M = l.out; g.N = l.in; g.K = M;
     g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f;
+    {
+      crct_engine::WgradSeen& ws = e->wgrad_seen[l.w];
+      ws.numel = (int64_t)l.out * l.in;
+      ++ws.pass;
+      if (c->wgrad_overwrite && e->wgrad_owned.count(l.w)) {
+        if (ws.pass > 1) { rc = 1; crct_set_error("engine_backward: weight gradient at offset %lld is produced twice in one pass but was reported as owned", (long long)l.w); return; }
+        g.accumulate = 0;             // the only producer of this gradient: write it, whatever the buffer held
+      }
+    }
     if (fold) g.rowsum_out = G(l.b);
     if (!defer_wgrad) { ++tick; fail(crct_gemm_bf16(&g, s)); return; }     // head chain: in order, right now
     // queued also without a side stream (sw == s): the same groups, hence the same kernels and summation orders,
@@ -945,6 +962,7 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   const int nseg = (int)e->seg_range.size();
   const int s0 = seg < 0 ? 0 : seg, s1 = seg < 0 ? nseg : seg + 1;
   CRCT_REQUIRE(s1 <= nseg, "engine_backward: bad segment %d", seg);
+  if (s0 == 0) e->wgrad_pass_begin();
   // inputs of every schedule step (outputs of the previous step of that stream)
   std::vector<size_t> in_t(e->sched.size()), in_v(e->sched.size());
   {
@@ -1078,6 +1096,26 @@ extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, c
   return run_graphed(e, key, (hipStream_t)stream, [&]() {
     return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
   });
+}
+
+extern "C" int crct_engine_wgrad_owned(crct_engine_t* e, int64_t* offsets, int64_t* numels, int cap) {
+  if (!e) return -1;
+  e->wgrad_pass_begin();
+  // gradients that other kernels add to as well (heads, embeddings) are never owned
+  const int64_t other[] = {e->et.word, e->et.pos, e->et.type, e->et.wloc, e->ev.color, e->ev.wloc, e->cls.w, e->fu[3].w};
+  e->wgrad_owned.clear();
+  for (const auto& kv : e->wgrad_seen) {
+    if (kv.second.most != 1) continue;
+    bool shared = false;
+    for (int64_t o : other) shared = shared || o == kv.first;
+    if (!shared) e->wgrad_owned[kv.first] = kv.second.numel;
+  }
+  int n = 0;
+  for (const auto& kv : e->wgrad_owned) {
+    if (offsets && numels && n < cap) { offsets[n] = kv.first; numels[n] = kv.second; }
+    ++n;
+  }
+  return n;
 }
 
 extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, int use_wgrad_streams) {

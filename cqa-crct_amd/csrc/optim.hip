@@ -82,7 +82,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
  }
 }
+// g[off[r] + blk_off .. ) = 0 over the chunk table of crct_adamw_plan (same chunking as the update itself)
+__global__ __launch_bounds__(256) void zero_runs_kernel(float* __restrict__ g, const int64_t* __restrict__ run_off,
+                                                        const int64_t* __restrict__ run_len, const int32_t* __restrict__ blk_seg,
+                                                        const int64_t* __restrict__ blk_off, int n_blk) {
+  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    const int r = blk_seg[blk];
+    const int64_t off = blk_off[blk], base = run_off[r] + off;
+    int64_t n = run_len[r] - off;
+    if (n > ADAMW_CHUNK) n = ADAMW_CHUNK;
+    const int64_t head = (4 - (base & 3)) & 3;            // elements in front of the first 16-byte boundary
+    for (int64_t i = threadIdx.x; i < (head < n ? head : n); i += 256) g[base + i] = 0.f;
+    const int64_t nv = n > head ? (n - head) / 4 : 0;
+    for (int64_t i = threadIdx.x; i < nv; i += 256)
+      __builtin_nontemporal_store(f4_t{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4_t*>(g + base + head) + i);
+    for (int64_t i = head + nv * 4 + threadIdx.x; i < n; i += 256) g[base + i] = 0.f;
+  }
+}
 }  // namespace
+
+extern "C" int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const int32_t* blk_seg,
+                              const int64_t* blk_off, int64_t n_blk, crct_stream_t stream) {
+  CRCT_REQUIRE(base && off && len && blk_seg && blk_off, "zero_runs: null argument");
+  if (n_blk <= 0) return 0;
+  const long grid = n_blk > 1024 ? 1024 : n_blk;
+  hipLaunchKernelGGL(zero_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, base, off, len, blk_seg, blk_off,
+                     (int)n_blk);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap) {
   int64_t nb = 0;

@@ -321,6 +321,11 @@ typedef struct CrctStepCfg {
                                 starts that range's all-reduce behind them while the rest of backward keeps running */
   int32_t use_graph;         /* != 0: capture the call into a hipGraph on its 2nd occurrence and replay it afterwards;
                                 every pointer argument (and a memory-resident seed) must then be stable across calls */
+  int32_t wgrad_overwrite;   /* backward only.  != 0: the caller guarantees that nothing has been accumulated into the weight
+                                gradients listed by crct_engine_wgrad_owned since they were last consumed; those gradients are
+                                then WRITTEN instead of added to (bit-identical to adding into zeros) and need not be zeroed --
+                                no 0.96 GB zero fill and no read-modify-write of the weight gradients per step.  All other
+                                gradients (biases, LayerNorm, embeddings, heads) are still accumulated and must be zero. */
 } CrctStepCfg;
 
 int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,
@@ -337,6 +342,15 @@ int crct_engine_backward(crct_engine_t*, const float* params_f32, const void* pa
 /* Internal concurrency (default: both on): the visual stream's layers run on a second HIP stream and all
  * weight-gradient GEMMs / bias column sums on two more, forked from and joined to `stream` inside every call.
  * Results do not depend on the setting (tests compare them bit for bit). */
+/* The weight gradients (flat offsets / element counts into grads_f32) that exactly one weight-gradient GEMM per backward
+ * pass produces and nothing else adds to, as observed over the backward passes run so far (call after at least one
+ * complete pass; returns the count, fills up to `cap` entries).  Only gradients reported here are overwritten under
+ * CrctStepCfg.wgrad_overwrite; the call freezes that set until it is called again. */
+int crct_engine_wgrad_owned(crct_engine_t*, int64_t* offsets, int64_t* numels, int cap);
+/* fp32 zero fill of `n_runs` ranges base[off[i] .. off[i] + len[i]) (device arrays off / len; blk_* from crct_adamw_plan
+ * over len): the gradients that stay accumulate-only under wgrad_overwrite.  Non-temporal stores. */
+int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
+                   int64_t n_blk, crct_stream_t stream);
 int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
 /* hipGraph cache counters (experimental graph mode, CrctStepCfg.use_graph). */
 int crct_engine_graph_stats(const crct_engine_t*, int* n_keys, int* n_instantiated, int* broken);
