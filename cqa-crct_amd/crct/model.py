@@ -210,6 +210,8 @@ class CrctModel(nn.Module):
         if getattr(self, "_lazy_plan_engine", None) is eng:
             return self._lazy_plan
         owned_off, owned_num = eng.wgrad_owned()
+        if not owned_off:                                  # a fresh engine (larger batch) has not run a backward pass yet
+            return None
         owned = sorted(zip(owned_off, owned_num))          # a fused QKV weight is one owned range over three tensors
         starts = [o for o, _ in owned]
         import bisect
