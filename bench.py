@@ -62,6 +62,8 @@ def parse():
                          "crct.input_pipeline.DevicePrefetcher; sync: pageable host batches moved by the step adapter's "
                          "synchronous .to(device), as the reference does (PCIe-inclusive rates for DESIGN.md)")
     ap.add_argument("--fuse-zero-grad", action="store_true", help="AdamW zeroes the gradients it consumes (measured: no gain)")
+    ap.add_argument("--eager-zero-grad", action="store_true", help="zero_grad() fills the whole gradient buffer and backward "
+                    "accumulates into it (default: lazy clear + overwritten weight gradients, same results, -0.3 ms per step)")
     ap.add_argument("--adamw-wgs", type=int, default=-1, help="workgroups per overlapped AdamW launch (0 = full width; default: the optimizer's)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
@@ -178,6 +180,7 @@ def main():
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1
     opt.fuse_zero_grad = bool(a.fuse_zero_grad)
+    opt.lazy_zero_grad = not a.eager_zero_grad
     if a.adamw_wgs >= 0:
         opt.overlap_workgroups = a.adamw_wgs
     if a.opt_early and opt.overlap:
