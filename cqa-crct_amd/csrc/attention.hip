@@ -9,7 +9,7 @@
 // regenerates the dropout mask from (seed, site, element index).
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "crct_internal.h"
 #include "attention_args.h"
 
@@ -289,11 +289,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   load_tile(K, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, d, tid);
   load_tile(V, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, d, tid);
   __syncthreads();
-  if (!(a.dbg & 1)) mm_nt<AQ, AK>(S, ldS, Q, K, a.Tq, a.Tk, d, tid);
+#ifdef CRCT_ATTN_LAB   // timing ablations of tools/attn_lab only (wrong results); never in the shipped library
+  if (!(a.dbg & 1))
+#endif
+  mm_nt<AQ, AK>(S, ldS, Q, K, a.Tq, a.Tk, d, tid);
   __syncthreads();
-  if (!(a.dbg & 2)) softmax_rows(S, ldS, a.keymask + (long)b * a.Tk, a.Tq, a.Tk, a.scale, (long)b * a.heads + h, a.thr, a.dscale, a.site, a.seed, tid, 0);
+#ifdef CRCT_ATTN_LAB
+  if (!(a.dbg & 2))
+#endif
+  softmax_rows(S, ldS, a.keymask + (long)b * a.Tk, a.Tq, a.Tk, a.scale, (long)b * a.heads + h, a.thr, a.dscale, a.site, a.seed, tid, 0);
   __syncthreads();
-  if (!(a.dbg & 4)) mm_nn<AQ>(Q, S, ldS, V, a.Tq, a.Tk, d, tid);     // ctx tile overwrites Q (no longer needed)
+#ifdef CRCT_ATTN_LAB
+  if (!(a.dbg & 4))
+#endif
+  mm_nn<AQ>(Q, S, ldS, V, a.Tq, a.Tk, d, tid);     // ctx tile overwrites Q (no longer needed)
   __syncthreads();
   store_tile(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Q, a.Tq, d, tid, 1.0f);
 }
@@ -408,8 +417,10 @@ extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, c
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
+#ifdef CRCT_ATTN_LAB
   static const int dbg = getenv("CRCT_ATTN_DBG") ? atoi(getenv("CRCT_ATTN_DBG")) : 0;
   a.dbg = dbg;
+#endif
   if (use_mfma(Tq, Tk, d)) {
     CRCT_CHECK_HIP(crct_attention_mfma_fwd(a, (hipStream_t)stream));
     return 0;

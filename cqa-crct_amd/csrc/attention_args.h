@@ -1,10 +1,10 @@
 // Arguments shared by the two attention implementations (attention.hip: fp32 VALU, any length up to 112;
-// attention_mfma.hip: one wave per (batch, head) on MFMA, lengths up to 64).
+// attention_mfma.hip: one wave per (batch, head) on MFMA, lengths up to 112, head sizes 32 / 48 / 64).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 
 struct AttnArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const uint8_t* keymask;
@@ -14,7 +14,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   uint32_t thr; float dscale; uint32_t site; uint64_t seed;
   float scale;
-  int dbg;      // developer ablation bits (tools/attn_lab), 0 in production
+  int dbg;      // ablation bits, read only by -DCRCT_ATTN_LAB builds (tools/attn_lab); always 0 in the shipped library
 };
 
 bool crct_attention_mfma_ok(int Tq, int Tk, int d);

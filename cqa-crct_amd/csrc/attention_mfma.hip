@@ -19,7 +19,7 @@
 // image written from the accumulator layout (8 bytes per lane and tile) and read back transposed.
 // Rows of all LDS images are padded by 16 bytes: strides of 80 / 112 / 144 bytes put the 16 rows of a
 // fragment read on distinct banks.
-#include "common.cuh"
+#include "common.hip.h"
 #include "crct_internal.h"
 #include "attention_args.h"
 

@@ -9,21 +9,24 @@
 //   dgrad    dx = dy W      : A = dy (TA=0), B = W  (TB=1, contraction over W's rows)
 //   wgrad    dW = dy^T x    : A = dy (TA=1), B = x  (TB=1, contraction over the token rows)
 //
-// Structure: 256-thread workgroup = 4 waves (2 x 2), tile (32*TM) x (32*TN) x 64, operands staged
-// global -> registers -> LDS (register prefetch of the next K tile overlaps the MFMAs),
-// v_mfma_f32_16x16x32_bf16 with the operands swapped (rows of D = n) so that every lane owns 4
-// consecutive output columns -> 8-byte bf16 / 16-byte fp32 stores and vector bias loads.
-// K-contiguous operands are read with ds_read_b128 from an XOR-swizzled [row][64] image;
-// operands whose contraction index is the slow axis (TA/TB = 1) are kept as they lie in memory,
-// [k][row], and read with ds_read_b64_tr_b16 (gfx950 transposed LDS read) from the 8x32-subtile
-// image of cdna_hip_programming.md T10(a) -- no transposed copies of weights or activations
-// exist anywhere in HBM.
+// Two kernels share the LDS images and the epilogue:
+//   * gemm_pipe_kernel / gemm_group_kernel (K % 64 == 0, every GEMM of the full-size step): operand tiles go
+//     HBM / L2 -> LDS by buffer_load_dwordx4 ... lds (no VGPR staging), a 2-4 stage ring, ONE raw s_barrier per
+//     64-deep K step with a counted vmcnt; fragments are read by inline-asm ds_read_b128 / ds_read_b64_tr_b16 with
+//     counted lgkmcnt waits; 4 or 8 waves per workgroup.
+//   * gemm_kernel (any K % 8 == 0: tiny configurations, B-row head GEMMs): 4 waves, operands staged
+//     global -> registers -> LDS with a register prefetch of the next K tile.
+// Both use v_mfma_f32_16x16x32_bf16 with the operands swapped (rows of D = n) so that every lane owns 4
+// consecutive output columns.  K-contiguous operands are read with ds_read_b128 from an XOR-swizzled [row][64]
+// image; operands whose contraction index is the slow axis (TA/TB = 1) are kept as they lie in memory, [k][row],
+// and read with ds_read_b64_tr_b16 (gfx950 transposed LDS read) from the 8x32-subtile image of
+// cdna_hip_programming.md T10(a) -- no transposed copies of weights or activations exist anywhere in HBM.
 #include <stdlib.h>
 
 #include <vector>
 #include <utility>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "crct_internal.h"
 
 namespace {
@@ -194,7 +197,12 @@ struct Stage {
 // private 4 MiB L2).  The tile grid is cut into gm x gn = 8 rectangles, one per XCD, chosen so that
 // the A' and B' panels one XCD touches (rm*BM + rn*BN rows of K) are as few as possible and stay
 // L2-resident; block j of XCD x takes the j-th tile of rectangle x.  Placement only affects speed.
-struct TileMap { int tiles_m, tiles_n, gn, rm, rn, dbg; };   // dbg: developer ablation bits (tools/gemm_lab), 0 in production
+struct TileMap { int tiles_m, tiles_n, gn, rm, rn, dbg; };   // dbg: ablation bits of the -DCRCT_GEMM_LAB build (tools/gemm_lab); the shipped library ignores them
+#ifdef CRCT_GEMM_LAB
+__device__ __forceinline__ int lab_bits(int dbg) { return dbg; }
+#else
+__device__ __forceinline__ constexpr int lab_bits(int) { return 0; }      // no environment variable can make a production kernel skip work
+#endif
 
 __device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int& tn) {
   const int x = bid & 7, j = bid >> 3;
@@ -221,8 +229,12 @@ inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid) {
   t.gn = 8 / bgm;
   t.rm = (t.tiles_m + bgm - 1) / bgm; t.rn = (t.tiles_n + t.gn - 1) / t.gn;
   *grid = 8 * t.rm * t.rn;
+#ifdef CRCT_GEMM_LAB   // timing ablations exist in the -DCRCT_GEMM_LAB build of tools/gemm_lab only
   static const int dbg = getenv("CRCT_GEMM_DBG") ? atoi(getenv("CRCT_GEMM_DBG")) : 0;
   t.dbg = dbg;
+#else
+  t.dbg = 0;
+#endif
   return t;
 }
 
@@ -647,7 +659,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
         wait_tile(kt + 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + NS < nk && !(dbg & 2)) issue(kt + NS, stg);
+        if (kt + NS < nk && !(lab_bits(dbg) & 2)) issue(kt + NS, stg);
         request(stg + 1 == NS ? 0 : stg + 1, fm_n, fn_n);
       }
       multiply(0, fm, fn);
@@ -657,7 +669,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     wait_tile(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (NS - 1 < nk && !(dbg & 2)) issue(NS - 1, NS - 1);
+    if (NS - 1 < nk && !(lab_bits(dbg) & 2)) issue(NS - 1, NS - 1);
     request(0, fmA, fnA);
     int stg = 0;
     for (int kt = 0; kt < nk; kt += 2) {
@@ -675,7 +687,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     wait_tile(kt);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk && !(dbg & 2)) issue(kt + NS - 1, st_next);
+    if (kt + NS - 1 < nk && !(lab_bits(dbg) & 2)) issue(kt + NS - 1, st_next);
     // fragments of both 32-deep halves of the K tile are requested up front; the MFMAs of the first half run while the
     // reads of the second are still in flight
     bf8_t fm[2][WTM], fn[2][WTN];
@@ -690,7 +702,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     st = st + 1 == NS ? 0 : st + 1;
   }
 #endif
-  if (dbg & 1) {      // ablation: keep the accumulators alive, skip the epilogue
+  if (lab_bits(dbg) & 1) {      // ablation (lab build only): keep the accumulators alive, skip the epilogue
 #pragma unroll
     for (int a = 0; a < WTN; ++a)
 #pragma unroll

@@ -4,7 +4,7 @@
 // regression bookkeeping + CrossEntropyLoss(ignore_index=-1) vilbert.py:1583-1657; loss
 // combination encoder_decorator.py:144-153.  All B rows are regressed and masked by R[:,1]
 // (the reference gathers those rows: same values, same gradients, static shapes).
-#include "common.cuh"
+#include "common.hip.h"
 #include "crct_internal.h"
 
 namespace {

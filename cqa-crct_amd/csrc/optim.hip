@@ -7,7 +7,7 @@
 // lr / wd), float4 accesses.
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "crct_internal.h"
 
 // non-temporal streaming of the optimizer state: measured 8.73 -> 8.60 ms per step (the next forward keeps its operands in

@@ -4,7 +4,7 @@
 // registers, so a row is read once and written once.  Statistics are fp32.
 // Reference arithmetic: BertLayerNorm vilbert.py:281-294; BertEmbeddingLocation :320-358;
 // BertImageEmbeddings :1474-1496.
-#include "common.cuh"
+#include "common.hip.h"
 #include "crct_internal.h"
 
 namespace {

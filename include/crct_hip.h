@@ -72,8 +72,8 @@ int crct_gemm_pick_tile(int M, int N);
 int crct_gemm_force_generic(int on);
 
 /* Live measurement for bench.py: when enabled, every GEMM launch is bracketed by HIP events on its
- * launch stream.  variant = config*3 + {0 forward, 1 dgrad (tb), 2 wgrad (ta,tb)}, config 0..12 = LDS-DMA
- * kernel configurations (tile / waves / stages, see gemm.hip), 13..16 = register-staged kernel tiles.  crct_prof_read
+ * launch stream.  variant = config*3 + {0 forward, 1 dgrad (tb), 2 wgrad (ta,tb)}, config 0..15 = LDS-DMA
+ * kernel configurations (tile / waves / stages, see gemm.hip), 16..19 = register-staged kernel tiles 0..3.  crct_prof_read
  * synchronises on the recorded events and returns launches, summed algorithmic FLOPs (2MNK) and
  * summed elapsed milliseconds of that variant since the last reset. */
 int crct_prof_enable(int on);
@@ -136,7 +136,7 @@ int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream)
  * in LDS: P = softmax(q k^T / sqrt(d) + (1-keymask)*-10000), dropout(P), ctx = P v.
  * Replaces vilbert.py:392-412 (text self), :522-543 (visual self), :684-701 / :704-723 (co-attn).
  * q [B][Tq][ldq], k/v [B][Tk][ldk] bf16 with head h at column h*d; keymask fp32/int-free: uint8 [B][Tk]
- * (1 = attend); ctx bf16 [B][Tq][ldo].  Tq, Tk <= 128, d <= 64, d % 8 == 0.
+ * (1 = attend); ctx bf16 [B][Tq][ldo].  Tq, Tk <= 112, d <= 64, d % 8 == 0.
  */
 int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx,
                        int B, int heads, int Tq, int Tk, int d,
