@@ -67,8 +67,6 @@ def parse():
     ap.add_argument("--adamw-wgs", type=int, default=-1, help="workgroups per overlapped AdamW launch (0 = full width; default: the optimizer's)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
-    ap.add_argument("--graph", action="store_true", help="experimental: replay forward / backward from captured hipGraphs "
-                    "(measured: no gain -- the step is GPU-bound -- and not yet supported with the wgrad side streams)")
     return ap.parse_args()
 
 
@@ -81,15 +79,12 @@ def gemm_profile(model, run_step, n_steps):
     lib = L.load()
     lib.crct_prof_reset()
     lib.crct_prof_enable(1)
-    core = model.bert_pretrained
-    graph_mode, core.use_graph = core.use_graph, False      # timing events cannot be recorded inside a captured graph
     for _ in range(n_steps):
         run_step()
     torch.cuda.synchronize()
-    core.use_graph = graph_mode
     lib.crct_prof_enable(0)
     rows = []
-    for v in range(72):
+    for v in range(192):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue
@@ -175,7 +170,6 @@ def main():
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
-    core.use_graph = bool(a.graph)
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1

@@ -107,9 +107,7 @@ class FlatGradDDP(object):
     def backward(self, core, eng, tensors, step):
         step = dict(step)
         if self.world > 1:      # also on accumulation-only micro-steps: the final SUM then yields the average
-            inv = 1.0 / self.world
-            step["g_nsp"] = step["g_nsp"] * inv
-            step["g_reg"] = step["g_reg"] * inv
+            step["grad_scale"] = step.get("grad_scale", 1.0) / self.world      # folded into the head kernel's gradient seeds
         if not self.require_sync or (self.world == 1 and not self.force_exchange):
             eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
             return

@@ -56,17 +56,13 @@ class StepEngine(object):
             L.check(self.lib.crct_engine_segment_range(self.handle, s, C.byref(lo), C.byref(hi)), "segment_range")
             self.segments.append((lo.value, hi.value))
         B = self.max[0]
-        # step outputs in ONE buffer [stats 8 | reg 5*maxB | logits 2*maxB] so that a snapshot is a single copy
-        self.out = torch.zeros(8 + 7 * B, device=self.device)
-        self.stats, self.reg, self.logits = self.out[:8], self.out[8:8 + 5 * B].view(5, B), self.out[8 + 5 * B:].view(B, 2)
+        # step outputs in ONE buffer [stats 24 | reg 5*maxB | logits 2*maxB] so that a snapshot is a single copy
+        self.NS = 24                                   # 17 used: see CrctHeadArgs.stats (8 step values + the 9 floats of train.py:181)
+        self.out = torch.zeros(self.NS + 7 * B, device=self.device)
+        self.stats, self.reg = self.out[:self.NS], self.out[self.NS:self.NS + 5 * B].view(5, B)
+        self.logits = self.out[self.NS + 5 * B:].view(B, 2)
         self._keep = None
-        # hipGraph mode: kernel arguments are baked at capture, so everything that changes per step lives in
-        # persistent device buffers: the dropout seed, the batch (staged copies), the upstream loss gradients
-        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.g_nsp_dev = torch.zeros(1, device=self.device)
-        self.g_reg_dev = torch.zeros(B, device=self.device)
-        self._stage = {}
-        self.gstream = torch.cuda.Stream(device=self.device)     # stream capture is illegal on the default (NULL) stream
+        self._owned_key = None
 
     def __del__(self):
         try:
@@ -79,47 +75,25 @@ class StepEngine(object):
     # -- batch marshalling: tensors must already be on the device with the dtypes of the C ABI
     def _batch(self, t):
         b = L.Batch()
-        b.tokens, b.segments, b.loc, b.text_keymask = L.ptr(t["tokens"]), L.ptr(t["segments"]), L.ptr(t["loc"]), L.ptr(t["text_keymask"])
-        b.image_feat, b.image_loc = L.ptr(t["image_feat"]), L.ptr(t["image_loc"])
-        b.image_target, b.image_keymask = L.ptr(t["image_target"]), L.ptr(t["image_keymask"])
+        b.tokens, b.segments, b.loc = L.ptr(t["tokens"]), L.ptr(t["segments"]), L.ptr(t["loc"])
+        b.image_feat, b.image_loc, b.image_target = L.ptr(t["image_feat"]), L.ptr(t["image_loc"]), L.ptr(t["image_target"])
+        # key masks: ready-made uint8 masks, or what the data loader ships (the engine builds the masks itself)
+        b.text_keymask, b.image_keymask = L.ptr(t.get("text_keymask")), L.ptr(t.get("image_keymask"))
+        if t.get("sep_indices") is not None:
+            b.sep_indices, b.hist_len, b.sep_stride = L.ptr(t["sep_indices"]), L.ptr(t["hist_len"]), t["sep_indices"].shape[1]
+        b.image_mask = L.ptr(t.get("image_mask"))
         b.R, b.labels = L.ptr(t["R"]), L.ptr(t.get("labels"))
         b.B, b.T, b.V = t["tokens"].shape[0], t["tokens"].shape[1], t["image_feat"].shape[1]
         return b
-
-    def stage_batch(self, tensors):
-        """Copy a device batch into persistent buffers (stable addresses for graph replay)."""
-        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items()))
-        st = self._stage.get(key)
-        if st is None:
-            st = {k: torch.empty_like(v) for k, v in tensors.items()}
-            self._stage[key] = st
-        for k, v in tensors.items():
-            st[k].copy_(v, non_blocking=True)
-        return st
 
     def _cfg(self, step):
         c = L.StepCfg()
         c.training, c.use_l1, c.kind_l1 = int(step["training"]), int(step["use_l1"]), int(step["kind_l1"])
         c.tol_margin, c.nsp_coeff, c.reg_coeff = step["tol_margin"], step["nsp_coeff"], step["reg_coeff"]
         c.grad_scale = step.get("grad_scale", 1.0)
-        c.use_graph = int(bool(step.get("use_graph", False)))
         c.wgrad_overwrite = int(bool(step.get("wgrad_overwrite", False)))
-        g_nsp, g_reg = step.get("g_nsp"), step.get("g_reg")
-        if c.use_graph:
-            if not step.get("_seed_set"):
-                self.seed_dev.fill_(int(step["seed"]))
-                step["_seed_set"] = True
-            c.seed = (1 << 63) | self.seed_dev.data_ptr()
-            if g_nsp is not None:
-                self.g_nsp_dev.copy_(g_nsp.reshape(1))
-                g_nsp = self.g_nsp_dev
-            if g_reg is not None:
-                n = g_reg.numel()
-                self.g_reg_dev[:n].copy_(g_reg)
-                g_reg = self.g_reg_dev
-        else:
-            c.seed = int(step["seed"])
-        c.g_nsp_dev, c.g_reg_dev = L.ptr(g_nsp), L.ptr(g_reg)
+        c.seed = int(step["seed"])
+        c.g_nsp_dev, c.g_reg_dev, c.g_loss_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg")), L.ptr(step.get("g_loss"))
         evs = step.get("seg_events")
         if evs is not None:
             arr = (C.c_void_p * len(evs))(*[ev.cuda_event for ev in evs])
@@ -133,55 +107,43 @@ class StepEngine(object):
         return c
 
     def wgrad_owned(self):
-        """(offsets, numels) of the weight gradients the engine may overwrite (see CrctStepCfg.wgrad_overwrite); valid after
-        at least one complete backward pass, and the set the engine honours from this call on."""
-        n = self.lib.crct_engine_wgrad_owned(self.handle, None, None, 0)
-        if n <= 0:
-            return [], []
-        off, num = (C.c_int64 * n)(), (C.c_int64 * n)()
-        n2 = self.lib.crct_engine_wgrad_owned(self.handle, off, num, n)
-        assert n2 == n
-        return list(off), list(num)
+        """(offsets, numels) of the weight gradients the engine overwrites under CrctStepCfg.wgrad_overwrite: fixed by the
+        layout at engine creation (every Linear weight produced by exactly one weight-gradient GEMM per pass)."""
+        return [list(x) for x in self.wgrad_owned_key()]
 
-    def _enter(self, graph):
-        """Stream the engine call is enqueued on: the caller's current stream, or (graph mode) the engine's own
-        capturable stream, ordered after the current stream."""
-        if not graph:
-            return L.current_stream()
-        self.gstream.wait_stream(torch.cuda.current_stream())
-        return self.gstream.cuda_stream
-
-    def _leave(self, graph):
-        if graph:
-            torch.cuda.current_stream().wait_stream(self.gstream)
+    def wgrad_owned_key(self):
+        if self._owned_key is None:
+            n = self.lib.crct_engine_wgrad_owned(self.handle, None, None, 0)
+            off, num = (C.c_int64 * max(n, 1))(), (C.c_int64 * max(n, 1))()
+            if n > 0:
+                assert self.lib.crct_engine_wgrad_owned(self.handle, off, num, n) == n
+            self._owned_key = (tuple(off[:n]), tuple(num[:n]))
+        return self._owned_key
 
     def forward(self, p32, p16, tensors, step):
         B = tensors["tokens"].shape[0]
         b, c = self._batch(tensors), self._cfg(step)
         self._keep = (tensors, step)
-        stream = self._enter(c.use_graph)
         L.check(self.lib.crct_engine_forward(self.handle, p32.data_ptr(), p16.data_ptr(), C.byref(b), C.byref(c),
                                              self.workspace.data_ptr(), self.logits.data_ptr(), self.reg.data_ptr(),
-                                             self.stats.data_ptr(), stream), "engine_forward")
-        self._leave(c.use_graph)
+                                             self.stats.data_ptr(), L.current_stream()), "engine_forward")
         return self.outputs_of(self.out, B)
 
     def outputs_of(self, out, B):
-        """(logits [B,2], reg [5,B], stats [8]) views of an output buffer (``self.out`` or a snapshot of it)."""
-        o = 8 + 5 * self.max[0]
-        return out[o:o + 2 * B].view(B, 2), out[8:8 + 5 * B].view(5, B), out[:8]
+        """(logits [B,2], reg [5,B], stats [24]) views of an output buffer (``self.out`` or a snapshot of it)."""
+        o = self.NS + 5 * self.max[0]
+        return out[o:o + 2 * B].view(B, 2), out[self.NS:self.NS + 5 * B].view(5, B), out[:self.NS]
 
     def snapshot(self, B):
+        """The step outputs as tensors of their own (ONE copy kernel): the engine rewrites its buffer on the next call."""
         return self.outputs_of(self.out.clone(), B)
 
     def backward(self, p32, p16, g32, tensors, step, seg=-1):
         b, c = self._batch(tensors), self._cfg(step)
-        stream = self._enter(c.use_graph)
         L.check(self.lib.crct_engine_backward(self.handle, p32.data_ptr(), p16.data_ptr(), C.byref(b), C.byref(c),
                                               self.workspace.data_ptr(), g32.data_ptr(), self.logits.data_ptr(),
-                                              self.reg.data_ptr(), self.stats.data_ptr(), int(seg), stream),
+                                              self.reg.data_ptr(), self.stats.data_ptr(), int(seg), L.current_stream()),
                 "engine_backward")
-        self._leave(c.use_graph)
 
     def tap(self, name, B, T, V):
         n_max = B * max(T * self.cfg.hidden_size, V * self.cfg.v_hidden_size)

@@ -26,7 +26,7 @@ class HeadArgs(C.Structure):
                 ("R", vp), ("labels", vp), ("logits", vp), ("reg", vp), ("stats", vp), ("scratch", vp),
                 ("d_pooled_t", vp), ("d_pooled_v", vp), ("d_fus_h", vp),
                 ("d_w_cls", vp), ("d_b_cls", vp), ("d_w_f6", vp), ("d_b_f6", vp), ("g_nsp_dev", vp), ("g_reg_dev", vp),
-                ("B", c_i32), ("Hb", c_i32), ("fusion_sum", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32),
+                ("g_loss_dev", vp), ("B", c_i32), ("Hb", c_i32), ("fusion_sum", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32),
                 ("tol_margin", c_f32), ("nsp_coeff", c_f32), ("reg_coeff", c_f32), ("grad_scale", c_f32),
                 ("drop_thr", c_u32), ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64)]
 
@@ -42,13 +42,18 @@ class ModelDims(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("tokens", vp), ("segments", vp), ("loc", vp), ("text_keymask", vp), ("image_feat", vp), ("image_loc", vp),
                 ("image_target", vp), ("image_keymask", vp), ("R", vp), ("labels", vp),
-                ("B", c_i32), ("T", c_i32), ("V", c_i32)]
+                ("B", c_i32), ("T", c_i32), ("V", c_i32),
+                ("sep_indices", vp), ("hist_len", vp), ("image_mask", vp), ("sep_stride", c_i32)]
+
+
+class AmpState(C.Structure):
+    _fields_ = [("grad_scale", vp), ("found_inf", vp), ("step", vp)]
 
 
 class StepCfg(C.Structure):
     _fields_ = [("training", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32), ("tol_margin", c_f32), ("nsp_coeff", c_f32),
-                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("seg_ready_events", vp), ("seg_done_events", vp),
-                ("use_graph", c_i32), ("wgrad_overwrite", c_i32)]
+                ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("g_loss_dev", vp),
+                ("seg_ready_events", vp), ("seg_done_events", vp), ("wgrad_overwrite", c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/crct_hip.h declares
@@ -70,6 +75,7 @@ PROTOTYPES = {
     "crct_layernorm_bwd_finalize": (C.c_int, [vp] * 4 + [C.c_int, C.c_int, C.c_int, vp]),
     "crct_colsum_blocks": (C.c_int, [C.c_int]),
     "crct_colsum_bf16": (C.c_int, [vp, c_i64, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "crct_build_keymasks": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
@@ -82,7 +88,8 @@ PROTOTYPES = {
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
     "crct_eval_select": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, vp, vp, vp, vp, vp, vp]),
     "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
-    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "crct_adamw_advance": (C.c_int, [vp, vp, vp]),
     "crct_engine_create": (vp, [C.POINTER(ModelDims), C.c_char_p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crct_engine_destroy": (None, [vp]),
     "crct_engine_workspace_bytes": (C.c_size_t, [vp]),
@@ -93,7 +100,6 @@ PROTOTYPES = {
     "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_zero_runs": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp]),
-    "crct_engine_graph_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crct_engine_tap": (c_i64, [vp, vp, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),
 }
 

@@ -32,28 +32,53 @@ class _Node(nn.Module):
 
 
 class _StepFn(torch.autograd.Function):
-    """Autograd bridge: differentiable outputs are nsp_loss [1] and the per-row regression loss [B];
-    backward hands their upstream gradients (device tensors, no sync) to the engine, which
-    accumulates every parameter gradient into the flat buffer (``param.grad`` are views of it)."""
+    """Autograd bridge.  Differentiable outputs: the COMBINED loss (0-dim, = nsp_coeff * nsp + reg_coeff * mean_B reg_loss,
+    computed by the head kernel, encoder_decorator.py:144-153), nsp_loss [1] and the per-row regression loss [B]; backward
+    hands their upstream gradients (device tensors, no sync) to the engine, which accumulates every parameter gradient
+    into the flat buffer (``param.grad`` are views of it).  The usual case -- only ``loss`` is differentiated -- costs no
+    torch kernel besides autograd's own seed: the head kernel scales its built-in seeds by the upstream scalar."""
 
     @staticmethod
     def forward(ctx, anchor, model, tensors, step):
         model._engine.forward(model._flat_p, model._flat_b16, tensors, step)
         ctx.model, ctx.tensors, ctx.step = model, tensors, step
+        ctx.set_materialize_grads(False)
         logits, reg_all, stats = model._engine.snapshot(tensors["tokens"].shape[0])    # one copy; the engine reuses its buffer
         ctx.mark_non_differentiable(logits, reg_all, stats)
-        return stats[1:2].clone(), reg_all[1].clone(), logits, reg_all, stats
+        return stats[0], stats[1:2], reg_all[1], logits, reg_all, stats       # views of the snapshot: no further copies
 
     @staticmethod
-    def backward(ctx, g_nsp, g_reg, _gl, _gr, _gs):
+    def backward(ctx, g_loss, g_nsp, g_reg, _gl, _gr, _gs):
         model = ctx.model
         step = dict(ctx.step)
-        B = ctx.tensors["tokens"].shape[0]
-        dev = model._flat_p.device
-        step["g_nsp"] = (g_nsp if g_nsp is not None else torch.zeros(1, device=dev)).contiguous().float()
-        step["g_reg"] = (g_reg if g_reg is not None else torch.zeros(B, device=dev)).contiguous().float()
+        if g_nsp is None and g_reg is None:
+            if g_loss is None:
+                return None, None, None, None
+            step["g_loss"] = g_loss.reshape(1).float()                 # views / no-ops for the fp32 scalar autograd hands over
+        else:                                                          # a caller combining nsp_loss / reg_loss itself
+            B = ctx.tensors["tokens"].shape[0]
+            dev = model._flat_p.device
+            gl = g_loss.reshape(1).float() if g_loss is not None else torch.zeros(1, device=dev)
+            gn = g_nsp.reshape(1).float() if g_nsp is not None else torch.zeros(1, device=dev)
+            gr = g_reg.reshape(B).float() if g_reg is not None else torch.zeros(B, device=dev)
+            step["g_nsp"] = (gn + gl * step["nsp_coeff"]).contiguous()
+            step["g_reg"] = (gr + gl * (step["reg_coeff"] / B)).contiguous()
         model._run_backward(ctx.tensors, step)
         return None, None, None, None
+
+
+class SequenceMask(object):
+    """What the step adapter knows about the text key mask -- ``arange(T) < sep_indices[hist_len] + 1``
+    (encoder_decorator.py:118-120) -- handed to the model as ``attention_mask`` instead of the materialised tensor: the
+    engine builds the uint8 key mask itself (one launch).  ``materialize()`` gives the reference's tensor."""
+
+    def __init__(self, sep_indices, hist_len, max_len):
+        self.sep_indices, self.hist_len, self.max_len = sep_indices, hist_len, int(max_len)
+
+    def materialize(self):
+        lengths = torch.gather(self.sep_indices, 1, self.hist_len.view(-1, 1)).squeeze(1) + 1
+        rng = torch.arange(0, self.max_len, device=lengths.device).long()
+        return rng.unsqueeze(0) < lengths.unsqueeze(1)
 
 
 class CrctModel(nn.Module):
@@ -72,6 +97,8 @@ class CrctModel(nn.Module):
         self._flat_g = torch.zeros(self.total, device=device)
         self._flat_b16 = torch.zeros(self.total, device=device, dtype=torch.bfloat16)
         self._shadow_ver = -1
+        self._rebound = None
+        self._const_zeros = None
         self._entries = {e.name: e for e in self.table}
         self._build_tree()
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -79,14 +106,13 @@ class CrctModel(nn.Module):
         self._seed, self._calls = int(params.get("seed", 0)) * 1000003 + 12345, 0
         self.cls_dropout = 0.1                       # vilbert.py:1045
         self.sync_stats = True                       # reg[3] as python ints (host sync) like the reference
-        self.use_graph = False                       # replay the step's ~900 launches from captured hipGraphs
         self._ddp = None
         self._param_events = None                    # set by FusedAdamW in overlap mode
         self._seg_done = None
         self._grads_dirty = True
         self._wgrad_overwrite_next = False       # set by a lazy clear: the next backward pass writes the owned weight gradients
         self._backward_passes = 0
-        self._lazy_plan_engine, self._lazy_plan = None, None
+        self._lazy_plan_key, self._lazy_plan = None, None
         self._grad_waits = None
         self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
@@ -141,10 +167,17 @@ class CrctModel(nn.Module):
     def _invalidate_shadow(self):
         self._shadow_ver = -1
 
+    def _param_version(self):
+        v = self._flat_p._version
+        if self._rebound is not None:                # see _rebind: in-place updates through re-pointed Parameters
+            v = (v, sum(p._version for p in self._rebound))
+        return v
+
     def _refresh_shadow(self):
-        if self._shadow_ver != self._flat_p._version:
+        v = self._param_version()
+        if self._shadow_ver != v:
             ops.cast_bf16(self._flat_p, out=self._flat_b16)
-            self._shadow_ver = self._flat_p._version
+            self._shadow_ver = v
 
     def _apply(self, fn, recurse=True):
         probe = fn(torch.zeros(1, device=self._flat_p.device))
@@ -160,12 +193,16 @@ class CrctModel(nn.Module):
         return self
 
     def _rebind(self):
+        """After a move to another device.  The Parameters keep their identity (optimizers may already hold them), so their
+        ``.data`` is re-pointed at views of the new flat buffer; such views carry their OWN version counters, so from here
+        on the bf16 shadow refresh also watches the parameters' counters (``_refresh_shadow``)."""
         byname = self._params_by_name()
         for e in self.table:
             p = byname[e.name]
             p.data = self._flat_p[e.offset:e.offset + e.numel].view(e.shape)
             if e.used:
                 p.grad = self._flat_g[e.offset:e.offset + e.numel].view(e.shape)
+        self._rebound = list(byname.values())
         self._invalidate_shadow()
 
     # ------------------------------------------------------------------ flat views for the optimizer / DDP
@@ -183,7 +220,7 @@ class CrctModel(nn.Module):
 
     def note_params_updated_natively(self):
         """Called by the fused optimizer, which rewrites the flat buffers and the shadow itself."""
-        self._shadow_ver = self._flat_p._version
+        self._shadow_ver = self._param_version()
 
     def zero_flat_grads(self, lazy=False):
         """Clear the gradients.  ``lazy``: only the gradients that backward ACCUMULATES into (biases, LayerNorm, embeddings,
@@ -202,23 +239,22 @@ class CrctModel(nn.Module):
         self._wgrad_overwrite_next = True
 
     def _lazy_zero_plan(self):
-        """Device tables for crct_zero_runs over the complement of the engine's owned weight gradients (built once per
-        engine, after its first complete backward pass)."""
+        """Device tables for crct_zero_runs over the complement of the engine's owned weight gradients.  The owned set is
+        fixed by the layout (crct_engine_wgrad_owned), so one plan serves every engine this model creates; it is keyed on
+        the set itself and ``_run_backward`` re-checks the key against the engine that actually runs the pass."""
         eng = self._engine
-        if eng is None or not getattr(self, "_backward_passes", 0):
+        if eng is None:
             return None
-        if getattr(self, "_lazy_plan_engine", None) is eng:
+        key = eng.wgrad_owned_key()
+        if self._lazy_plan_key == key:
             return self._lazy_plan
-        owned_off, owned_num = eng.wgrad_owned()
-        if not owned_off:                                  # a fresh engine (larger batch) has not run a backward pass yet
-            return None
-        owned = sorted(zip(owned_off, owned_num))          # a fused QKV weight is one owned range over three tensors
+        owned = list(zip(*key)) if key[0] else []
         starts = [o for o, _ in owned]
         import bisect
         runs = []
         for e in sorted((e for e in self.table if e.used), key=lambda e: e.offset):
             k = bisect.bisect_right(starts, e.offset) - 1
-            if k >= 0 and e.offset + e.numel <= owned[k][0] + owned[k][1]:
+            if k >= 0 and e.offset + e.numel <= owned[k][0] + owned[k][1]:      # a fused QKV weight is one owned range over three tensors
                 continue
             if runs and runs[-1][0] + runs[-1][1] == e.offset:
                 runs[-1][1] += e.numel
@@ -235,7 +271,7 @@ class CrctModel(nn.Module):
             lib.crct_adamw_plan(num_host.data_ptr(), len(runs), blk_seg.data_ptr(), blk_off.data_ptr(), n_blk)
             plan = (torch.tensor([r[0] for r in runs], dtype=torch.int64, device=dev), num_host.to(dev), blk_seg.to(dev),
                     blk_off.to(dev), int(n_blk))
-        self._lazy_plan_engine, self._lazy_plan = eng, plan
+        self._lazy_plan_key, self._lazy_plan = key, plan
         return plan
 
     def _ensure_grad_views(self):
@@ -288,11 +324,14 @@ class CrctModel(nn.Module):
         self._grads_dirty = True                     # gradients are being accumulated again (optimizer bookkeeping)
         eng = self._engine
         self._grad_waits = None
-        if getattr(self, "_wgrad_overwrite_next", False) and getattr(self, "_lazy_plan_engine", None) is eng:
-            step = dict(step, wgrad_overwrite=True)  # first pass since a lazy clear: the owned weight gradients are written
+        if self._wgrad_overwrite_next:               # first pass since a lazy clear: the owned weight gradients hold stale values
+            if self._lazy_plan_key is not None and eng.wgrad_owned_key() == self._lazy_plan_key:
+                step = dict(step, wgrad_overwrite=True)     # ... and this engine writes exactly those (an engine rebuilt for a
+            else:                                           # larger batch in between owns the same set: it follows from the layout)
+                self._flat_g.zero_()                 # an engine with another owned set: nothing else has been accumulated yet
         self._wgrad_overwrite_next = False           # a further pass before the next clear accumulates
         self._backward_passes = getattr(self, "_backward_passes", 0) + 1
-        if self._ddp is None and self.record_segment_events and not step.get("use_graph"):
+        if self._ddp is None and self.record_segment_events:
             evs = self.segment_done_events()
             step = dict(step, seg_done_events=evs)
             eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, -1)
@@ -311,20 +350,30 @@ class CrctModel(nn.Module):
                        image_attention_mask, image_target, R, labels):
         dev = self._flat_p.device
 
-        def to(t, dtype):
+        def to(t, dtype):          # no kernel when the tensor is already on the device with this dtype (resident batches)
             return t.to(device=dev, dtype=dtype, non_blocking=True).contiguous()
         B, T = input_ids.shape
         V = image_feat.shape[1]
-        if attention_mask is None:
-            attention_mask = torch.ones(B, T, dtype=torch.uint8)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
-        if image_attention_mask is None:
-            image_attention_mask = torch.ones(B, V, dtype=torch.uint8)
         t = dict(tokens=to(input_ids, torch.int64), segments=to(token_type_ids, torch.int64), loc=to(txt_loc, torch.float32),
-                 text_keymask=to(attention_mask != 0, torch.uint8), image_feat=to(image_feat, torch.float32),
-                 image_loc=to(image_loc, torch.float32), image_target=to(image_target, torch.int64),
-                 image_keymask=to(image_attention_mask != 0, torch.uint8), R=to(R, torch.float32))
+                 image_feat=to(image_feat, torch.float32), image_loc=to(image_loc, torch.float32),
+                 image_target=to(image_target, torch.int64), R=to(R, torch.float32))
+        # key masks: the engine builds them from sep_indices / hist_len (SequenceMask) and the integer image mask; any other
+        # mask tensor is reduced to uint8 here
+        if isinstance(attention_mask, SequenceMask):
+            t["sep_indices"] = to(attention_mask.sep_indices, torch.int64)
+            t["hist_len"] = to(attention_mask.hist_len.reshape(-1), torch.int64)
+        elif attention_mask is None:
+            t["text_keymask"] = torch.ones(B, T, dtype=torch.uint8, device=dev)
+        else:
+            t["text_keymask"] = to(attention_mask != 0, torch.uint8)
+        if image_attention_mask is None:
+            t["image_keymask"] = torch.ones(B, V, dtype=torch.uint8, device=dev)
+        elif image_attention_mask.dtype == torch.int64:
+            t["image_mask"] = to(image_attention_mask, torch.int64)
+        else:
+            t["image_keymask"] = to(image_attention_mask != 0, torch.uint8)
         if labels is not None:
             t["labels"] = to(labels.reshape(-1), torch.int64)
         return t
@@ -346,33 +395,38 @@ class CrctModel(nn.Module):
         B, T = tensors["tokens"].shape
         V = tensors["image_feat"].shape[1]
         eng = self._get_engine(B, T, V)
-        if self.use_graph:
-            tensors = eng.stage_batch(tensors)
         self._refresh_shadow()
         self._calls += 1
         p = self.params
         step = dict(training=self.training, use_l1=bool(p["L1"]), kind_l1=(kind == "L1"), tol_margin=float(p["tol_margin"]),
                     nsp_coeff=float(p.get("nsp_loss_coeff", 1.0)), reg_coeff=float(p.get("reg_loss_coeff", 1.0)),
                     seed=(self._seed + self._calls * 7919 + int(p.get("rank", 0)) * 104729) & 0x3FFFFFFFFFFFFFFF,
-                    use_graph=self.use_graph, seg_events=self._param_events)
+                    seg_events=self._param_events)
         self._param_events = None
         dev = self._flat_p.device
         if train_branch and torch.is_grad_enabled():
-            nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)
+            loss, nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)
         else:
-            self._engine.forward(self._flat_p, self._flat_b16, tensors, step)
-            logits, reg, stats = self._engine.snapshot(B)
-            nsp, reg_loss = stats[1:2], reg[1]
+            eng.forward(self._flat_p, self._flat_b16, tensors, step)
+            logits, reg, stats = eng.snapshot(B)
+            loss, nsp, reg_loss = stats[0], stats[1:2], reg[1]
+        # the combined training loss as the head kernel computed it (differentiable); the step adapter returns it instead
+        # of re-deriving it from nsp_loss / reg_loss with five more torch kernels and their autograd nodes
+        self.last_loss = loss if train_branch else None
+        self.loss_coeffs = (step["nsp_coeff"], step["reg_coeff"])
         self.last_stats = stats
         if self.sync_stats:
             right = (int(stats[4].item()), int(stats[5].item()))          # vilbert.py:1647 (.item() host syncs)
         else:
             right = (stats[4], stats[5])
         reg_out = [reg[0], reg_loss, reg[2], right, reg[4]]
-        legend_loss = torch.zeros(1, device=dev)
+        if self._const_zeros is None or self._const_zeros[0].device != dev:
+            # the placeholder losses of vilbert.py:1583,1652-1653 (lm, image, legend): constant tensors made once, not three
+            # fill kernels per step
+            self._const_zeros = (torch.zeros(1, 1, device=dev), torch.zeros(1, 1, device=dev), torch.zeros(1, device=dev))
+        lm_zero, img_zero, legend_loss = self._const_zeros
         if train_branch:
-            zero = torch.zeros(1, 1, device=dev)
-            return zero, zero.clone(), nsp, None, None, logits, reg_out, legend_loss       # vilbert.py:1659
+            return lm_zero, img_zero, nsp, None, None, logits, reg_out, legend_loss        # vilbert.py:1659
         return None, None, logits, None, None, reg_out, legend_loss                         # vilbert.py:1661
 
 

@@ -78,6 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._lr_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
         self._wd_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
         self._last = None
+        self._step_dev, self._amp_arg, self._amp_keep = None, None, None
         # overlap mode: the update runs as one launch per engine backward-segment on its own stream, in first-use
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
@@ -133,7 +134,35 @@ class FusedAdamW(torch.optim.Optimizer):
                                          core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
                                          self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr() + 4 * b0,
                                          self._blk_off.data_ptr() + 8 * b0, b1 - b0, g0["betas"][0], g0["betas"][1], g0["eps"],
-                                         self._step, L.ptr(inv_scale), int(max_workgroups), int(self.fuse_zero_grad), stream), "adamw_step")
+                                         max(self._step, 1), L.ptr(inv_scale), self._amp_arg, int(max_workgroups),
+                                         int(self.fuse_zero_grad), stream), "adamw_step")
+
+    # ---- torch.amp.GradScaler (train.py:157,208-212).  ``scaler.step(optimizer)`` sees ``_step_supports_amp_scaling`` and
+    # hands over ``optimizer.grad_scale`` / ``optimizer.found_inf`` (device scalars) instead of unscaling 524 gradient views
+    # itself; the update kernel divides by the scale, skips the step on inf / nan and takes its bias corrections from a
+    # device-side step counter that only advances on real steps -- no host sync anywhere.
+    _step_supports_amp_scaling = True
+
+    def _amp_begin(self):
+        import ctypes as C
+        scale, found = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        if scale is None and found is None:
+            if self._step_dev is not None:                      # scaler went away: back to the host counter
+                self._step = int(self._step_dev.item())
+                self._step_dev = None
+            self._amp_arg = None
+            return False
+        dev = self.core.flat_params.device
+        if self._step_dev is None:
+            self._step_dev = torch.tensor([self._step], dtype=torch.int32, device=dev)
+        found32 = found.to(device=dev, dtype=torch.float32).reshape(1) if found is not None else None
+        scale32 = scale.to(device=dev, dtype=torch.float32).reshape(1) if scale is not None else None
+        L.check(L.load().crct_adamw_advance(self._step_dev.data_ptr(), L.ptr(found32), L.current_stream()), "adamw_advance")
+        st = L.AmpState()
+        st.grad_scale, st.found_inf, st.step = L.ptr(scale32), L.ptr(found32), self._step_dev.data_ptr()
+        self._amp_keep = (scale32, found32, st)
+        self._amp_arg = C.byref(st)
+        return True
 
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
@@ -163,8 +192,10 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None, inv_scale=None):
         loss = closure() if closure is not None else None
         core = self.core
-        self._step += 1
-        if self.overlap and (self._seg_blocks is not None or self._plan_overlap()):
+        amp = self._amp_begin()
+        if not amp:
+            self._step += 1
+        if self.overlap and not amp and (self._seg_blocks is not None or self._plan_overlap()):
             cur = torch.cuda.current_stream()
             done = core.take_segment_done_events() if (self.early and inv_scale is None) else None
             n = len(self._seg_blocks)
@@ -212,6 +243,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self.core.zero_flat_grads(lazy=self.lazy_zero_grad)
 
     def state_dict(self):
+        if self._step_dev is not None:
+            self._step = int(self._step_dev.item())
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
         return super().state_dict()
@@ -238,6 +271,7 @@ class FusedAdamW(torch.optim.Optimizer):
             mine["exp_avg_sq"].copy_(st["exp_avg_sq"])
             step = max(step, int(float(st["step"])))
         self._step = step
+        self._step_dev = None
         self._last = None
 
 

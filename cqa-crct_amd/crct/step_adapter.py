@@ -8,6 +8,8 @@ host side of the boundary exactly as the reference does (it depends only on inte
 """
 import torch
 
+from .model import SequenceMask
+
 
 def sequence_mask(sequence_length, max_len=None):
     """True for positions < length (encoder_decorator.py:57-70)."""
@@ -39,9 +41,13 @@ def forward(dialog_encoder, batch, params, output_nsp_scores=False, output_lm_sc
         regression_target = [R, "L1"]                 # :106
     image_target = pick("image_target")
 
-    # text key mask = arange(T) < sep_indices[hist_len] + 1   (:118-120); integer work, stays on the host side
-    lengths = torch.gather(sep_indices, 1, hist_len.view(-1, 1)).squeeze(1) + 1
-    attention_mask = sequence_mask(lengths, max_len=tokens.shape[1])
+    # text key mask = arange(T) < sep_indices[hist_len] + 1   (:118-120).  The native model takes the DESCRIPTION of that
+    # mask and builds it inside its first launch; any other model gets the materialised tensor, as in the reference.
+    core = getattr(dialog_encoder, "module", dialog_encoder)
+    native = hasattr(getattr(core, "bert_pretrained", None), "flat_params")
+    attention_mask = SequenceMask(sep_indices, hist_len, tokens.shape[1])
+    if not native:
+        attention_mask = attention_mask.materialize()
     sep_len = hist_len + 1
 
     lm_loss, img_loss, nsp_loss, nsp_scores, regression, legend_loss = dialog_encoder(
@@ -50,11 +56,16 @@ def forward(dialog_encoder, batch, params, output_nsp_scores=False, output_lm_sc
         output_nsp_scores=output_nsp_scores, output_lm_scores=output_lm_scores, image_attention_mask=image_mask,
         image_label=image_label, image_target=image_target, gt_reg=regression_target, areas=None)
 
-    reg_loss = regression[1].mean()
     loss = None
     if not evaluation:
-        loss = (params["nsp_loss_coeff"] * nsp_loss) + (params["reg_loss_coeff"] * reg_loss)     # :145
-        loss = loss.sum()
+        fused = getattr(core.bert_pretrained, "last_loss", None) if native else None
+        if fused is not None and float(params["nsp_loss_coeff"]) == core.bert_pretrained.loss_coeffs[0] and \
+                float(params["reg_loss_coeff"]) == core.bert_pretrained.loss_coeffs[1]:
+            loss = fused          # = nsp_loss_coeff * nsp_loss + reg_loss_coeff * mean_B(reg_loss), from the head kernel (:144-153)
+        else:
+            reg_loss = regression[1].mean()
+            loss = (params["nsp_loss_coeff"] * nsp_loss) + (params["reg_loss_coeff"] * reg_loss)     # :145
+            loss = loss.sum()
     if evaluation:
         return loss, lm_loss, nsp_loss, img_loss, nsp_scores, regression
     return loss, lm_loss, nsp_loss, img_loss, nsp_scores, regression, legend_loss

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -39,7 +40,7 @@ void crct_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crct_last_error(void) { return g_err; }
-extern "C" int crct_abi_version(void) { return 1; }
+extern "C" int crct_abi_version(void) { return 2; }
 
 extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a != nullptr, "gemm: null args");
@@ -123,6 +124,7 @@ struct crct_engine {
   StreamScratch st2, sv2;        // second set: layers alternate sets so weight-gradient GEMMs may lag one layer behind
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
   size_t embed_rows[2], embed_idx[2];   // embedding backward: fp32 row gradients + table indices for the gather-sum pass
+  size_t km_t = 0, km_v = 0;
   size_t ws_bytes = 0;
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
@@ -130,19 +132,14 @@ struct crct_engine {
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
   std::vector<hipEvent_t> evpool;
   size_t evnext = 0;
-  // hipGraph cache: one executable graph per distinct (call kind, pointers, sizes, flags)
-  struct GraphEntry { std::vector<char> key; int seen = 0; hipGraphExec_t exec = nullptr; };
-  std::vector<GraphEntry> graphs;
-  bool graph_broken = false;
   std::vector<std::pair<int64_t, int64_t>> seg_range;
-  // weight-gradient ownership (CrctStepCfg.wgrad_overwrite): per flat offset of a Linear weight, how many weight-gradient
-  // GEMMs targeted it in the current backward pass / at most in any pass so far, and the set reported as "owned"
-  struct WgradSeen { int64_t numel = 0; int pass = 0, most = 0; };
-  std::unordered_map<int64_t, WgradSeen> wgrad_seen;
-  std::unordered_map<int64_t, int64_t> wgrad_owned;     // offset -> numel, frozen by crct_engine_wgrad_owned
-  void wgrad_pass_begin() {
-    for (auto& kv : wgrad_seen) { if (kv.second.pass > kv.second.most) kv.second.most = kv.second.pass; kv.second.pass = 0; }
-  }
+  // weight-gradient ownership (CrctStepCfg.wgrad_overwrite): the Linear weights whose gradient is produced by exactly ONE
+  // weight-gradient GEMM per backward pass and by nothing else -- every Linear of the encoder layers, the image embedding,
+  // the poolers and the regressor pipes.  Fixed by the schedule at crct_engine_create (offset -> numel); `wgrad_pass` counts
+  // the productions of the running pass so that a violation is an error, never a silent overwrite.
+  std::unordered_map<int64_t, int64_t> wgrad_owned;
+  std::unordered_map<int64_t, int> wgrad_pass;
+  void wgrad_pass_begin() { wgrad_pass.clear(); }
   std::vector<Tap> taps;
   size_t final_t = 0, final_v = 0;   // offsets of the last-layer outputs
   int cur_t = 0, cur_v = 0;          // ping-pong index of the running activation gradients
@@ -312,14 +309,9 @@ struct Run {
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = x; g.C = G(l.w); g.lda = lddy; g.ldb = ldx; g.ldc = l.in; g.M = l.out; g.N = l.in; g.K = M;
     g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f;
-    {
-      crct_engine::WgradSeen& ws = e->wgrad_seen[l.w];
-      ws.numel = (int64_t)l.out * l.in;
-      ++ws.pass;
-      if (c->wgrad_overwrite && e->wgrad_owned.count(l.w)) {
-        if (ws.pass > 1) { rc = 1; crct_set_error("engine_backward: weight gradient at offset %lld is produced twice in one pass but was reported as owned", (long long)l.w); return; }
-        g.accumulate = 0;             // the only producer of this gradient: write it, whatever the buffer held
-      }
+    if (c->wgrad_overwrite && e->wgrad_owned.count(l.w)) {
+      if (++e->wgrad_pass[l.w] > 1) { rc = 1; crct_set_error("engine_backward: weight gradient at offset %lld is produced twice in one pass but is listed as owned", (long long)l.w); return; }
+      g.accumulate = 0;               // the only producer of this gradient: write it, whatever the buffer held
     }
     if (fold) g.rowsum_out = G(l.b);
     if (!defer_wgrad) { ++tick; fail(crct_gemm_bf16(&g, s)); return; }     // head chain: in order, right now
@@ -585,7 +577,7 @@ struct Run {
       h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
       h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
     }
-    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev;
+    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev; h.g_loss_dev = c->g_loss_dev;
     h.B = B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
     h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
     const Drop dc = drop(D.p_cls, 3);
@@ -642,7 +634,7 @@ struct Run {
     h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
     h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
     h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
-    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev;
+    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev; h.g_loss_dev = c->g_loss_dev;
     h.B = b->B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
     h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
     const Drop dc = drop(D.p_cls, 3);
@@ -655,8 +647,9 @@ int check_batch(const crct_engine* e, const CrctBatch* b) {
   CRCT_REQUIRE(b && b->B >= 1 && b->T >= 1 && b->V >= 1, "engine: bad batch sizes");
   CRCT_REQUIRE(b->B <= e->maxB && b->T <= e->maxT && b->V <= e->maxV, "engine: batch (B=%d,T=%d,V=%d) exceeds the engine maximum (%d,%d,%d)",
                b->B, b->T, b->V, e->maxB, e->maxT, e->maxV);
-  CRCT_REQUIRE(b->tokens && b->segments && b->loc && b->text_keymask && b->image_feat && b->image_loc && b->image_target &&
-                   b->image_keymask && b->R, "engine: null batch pointer");
+  CRCT_REQUIRE(b->tokens && b->segments && b->loc && b->image_feat && b->image_loc && b->image_target && b->R, "engine: null batch pointer");
+  CRCT_REQUIRE(b->text_keymask || (b->sep_indices && b->hist_len && b->sep_stride > 0), "engine: text_keymask, or sep_indices + hist_len, is required");
+  CRCT_REQUIRE(b->image_keymask || b->image_mask, "engine: image_keymask or image_mask is required");
   return 0;
 }
 
@@ -762,6 +755,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     }
   }
   if (e->bad) return fail(nullptr);
+  {
+    auto own = [&](const LinearP& l) { e->wgrad_owned[l.w] = (int64_t)l.in * l.out; };
+    for (const SelfLayerP& l : e->tl) { own(l.qkv); own(l.proj.dense); own(l.ffn.up); own(l.ffn.down); }
+    for (const SelfLayerP& l : e->vl) { own(l.qkv); own(l.proj.dense); own(l.ffn.up); own(l.ffn.down); }
+    for (const ConnLayerP& l : e->cl) {
+      own(l.qkv1); own(l.qkv2); own(l.proj_v.dense); own(l.proj_t.dense);
+      own(l.ffn_v.up); own(l.ffn_v.down); own(l.ffn_t.up); own(l.ffn_t.down);
+    }
+    own(e->ev.img); own(e->t_pool); own(e->v_pool);
+    for (int j = 0; j < 4; ++j) { own(e->tp[j]); own(e->vp[j]); }
+    for (int j = 0; j < 3; ++j) own(e->fu[j]);     // fusion.6 (fu[3]) and bi_seq_relationship are produced by the head kernel: accumulate-only
+  }
 
   // ---- workspace
   Arena ar;
@@ -819,6 +824,7 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     if (nmax < 1024) nmax = 1024;
     for (int k = 0; k < 4; ++k) e->colsum_part[k] = ar.take((size_t)64 * nmax * 4);
   }
+  e->km_t = ar.take(Mt); e->km_v = ar.take(Mv);      // uint8 key masks built from sep_indices / hist_len / image_mask (CrctBatch)
   e->ws_bytes = ar.top;
 
   // ---- taps + final outputs, following the schedule
@@ -861,7 +867,6 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
 
 extern "C" void crct_engine_destroy(crct_engine_t* e) {
   if (!e) return;
-  for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (auto ev : e->evpool) (void)hipEventDestroy(ev);
   for (auto st : e->side) if (st) (void)hipStreamDestroy(st);
   delete e;
@@ -916,6 +921,16 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   if (int r = check_batch(e, batch)) return r;
   if (int r = ensure_streams(e)) return r;
   e->evnext = 0;
+  // key masks the caller did not supply are built here (one launch) and kept in the workspace for the backward pass
+  CrctBatch bl = *batch;
+  if (!bl.text_keymask || !bl.image_keymask) {
+    uint8_t* kt = bl.text_keymask ? nullptr : (uint8_t*)workspace + e->km_t;
+    uint8_t* kv = bl.image_keymask ? nullptr : (uint8_t*)workspace + e->km_v;
+    if (int r = crct_build_keymasks(bl.sep_indices, bl.hist_len, bl.sep_stride, bl.image_mask, kt, kv, bl.B, bl.T, bl.V, stream)) return r;
+    if (kt) bl.text_keymask = kt;
+    if (kv) bl.image_keymask = kv;
+  }
+  batch = &bl;
   Run Rt, Rv;
   make_runs(e, params_f32, params_bf16, nullptr, workspace, (hipStream_t)stream, batch, cfg, Rt, Rv);
   Rv.fail(order_streams(e, Rt.s, Rv.s));                 // fork: the visual stream starts after the caller's prior work
@@ -957,6 +972,10 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   if (int r = check_batch(e, batch)) return r;
   if (int r = ensure_streams(e)) return r;
   e->evnext = 0;
+  CrctBatch bl = *batch;                                 // masks built by the forward pass of this batch live in the workspace
+  if (!bl.text_keymask) bl.text_keymask = (const uint8_t*)workspace + e->km_t;
+  if (!bl.image_keymask) bl.image_keymask = (const uint8_t*)workspace + e->km_v;
+  batch = &bl;
   Run Rt, Rv;
   make_runs(e, params_f32, params_bf16, grads_f32, workspace, (hipStream_t)stream, batch, cfg, Rt, Rv);
   const int nseg = (int)e->seg_range.size();
@@ -1019,99 +1038,24 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   return Rt.rc ? Rt.rc : Rv.rc;
 }
 
-// ---- hipGraph front-end: 1st call with a given key runs eagerly (lazy one-time setup such as
-// hipFuncSetAttribute happens there), the 2nd is captured (fork / join of the internal streams
-// included) and instantiated, later ones are a single hipGraphLaunch.
-namespace {
-template <class F>
-int run_graphed(crct_engine* e, const std::vector<char>& key, hipStream_t stream, F&& body) {
-  crct_engine::GraphEntry* ent = nullptr;
-  for (auto& g : e->graphs)
-    if (g.key == key) { ent = &g; break; }
-  if (!ent) {
-    if (e->graphs.size() > 64) e->graphs.erase(e->graphs.begin());
-    e->graphs.emplace_back();
-    ent = &e->graphs.back();
-    ent->key = key;
-  }
-  if (ent->exec) {
-    if (hipGraphLaunch(ent->exec, stream) != hipSuccess) { crct_set_error("engine: hipGraphLaunch failed"); return 1; }
-    return 0;
-  }
-  if (ent->seen++ == 0 || e->graph_broken) return body();
-  static const bool dbg = getenv("CRCT_DEBUG") != nullptr;
-  if (dbg) fprintf(stderr, "[crct] begin capture on stream %p\n", (void*)stream);
-  if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->graph_broken = true; (void)hipGetLastError(); return body(); }
-  const int rc = body();
-  if (dbg) fprintf(stderr, "[crct] body rc=%d (%s)\n", rc, crct_last_error());
-  hipGraph_t graph = nullptr;
-  const hipError_t ec = hipStreamEndCapture(stream, &graph);
-  if (dbg) fprintf(stderr, "[crct] end capture: %s graph=%p\n", hipGetErrorString(ec), (void*)graph);
-  if (rc || ec != hipSuccess || !graph) {
-    e->graph_broken = true;
-    (void)hipGetLastError();
-    if (graph) (void)hipGraphDestroy(graph);
-    if (rc) return rc;
-    crct_set_error("engine: stream capture failed (%s); falling back to direct launches", hipGetErrorString(ec));
-    return body();
-  }
-  hipGraphExec_t exec = nullptr;
-  if (dbg) { size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn); fprintf(stderr, "[crct] instantiating graph with %zu nodes\n", nn); }
-  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-    (void)hipGraphDestroy(graph);
-    e->graph_broken = true;
-    return body();
-  }
-  (void)hipGraphDestroy(graph);
-  ent->exec = exec;
-  if (dbg) fprintf(stderr, "[crct] launching graph\n");
-  if (hipGraphLaunch(exec, stream) != hipSuccess) { crct_set_error("engine: hipGraphLaunch failed"); return 1; }
-  return 0;
-}
-template <class T>
-void key_put(std::vector<char>& k, const T& v) { const char* p = reinterpret_cast<const char*>(&v); k.insert(k.end(), p, p + sizeof(T)); }
-}  // namespace
-
 extern "C" int crct_engine_forward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
                                    const CrctStepCfg* cfg, void* workspace, float* logits, float* reg, float* stats,
                                    crct_stream_t stream) {
-  if (!e || !cfg || !batch || !cfg->use_graph)
-    return engine_forward_impl(e, params_f32, params_bf16, batch, cfg, workspace, logits, reg, stats, stream);
-  std::vector<char> key;
-  key_put(key, (int)1); key_put(key, params_f32); key_put(key, params_bf16); key_put(key, *batch); key_put(key, *cfg);
-  key_put(key, workspace); key_put(key, logits); key_put(key, reg); key_put(key, stats);
-  return run_graphed(e, key, (hipStream_t)stream, [&]() {
-    return engine_forward_impl(e, params_f32, params_bf16, batch, cfg, workspace, logits, reg, stats, stream);
-  });
+  return engine_forward_impl(e, params_f32, params_bf16, batch, cfg, workspace, logits, reg, stats, stream);
 }
 
 extern "C" int crct_engine_backward(crct_engine_t* e, const float* params_f32, const void* params_bf16, const CrctBatch* batch,
                                     const CrctStepCfg* cfg, void* workspace, float* grads_f32, float* logits, float* reg,
                                     float* stats, int seg, crct_stream_t stream) {
-  if (!e || !cfg || !batch || !cfg->use_graph)
-    return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
-  std::vector<char> key;
-  key_put(key, (int)2); key_put(key, params_f32); key_put(key, params_bf16); key_put(key, *batch); key_put(key, *cfg);
-  key_put(key, workspace); key_put(key, grads_f32); key_put(key, logits); key_put(key, reg); key_put(key, stats); key_put(key, seg);
-  return run_graphed(e, key, (hipStream_t)stream, [&]() {
-    return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
-  });
+  return engine_backward_impl(e, params_f32, params_bf16, batch, cfg, workspace, grads_f32, logits, reg, stats, seg, stream);
 }
 
 extern "C" int crct_engine_wgrad_owned(crct_engine_t* e, int64_t* offsets, int64_t* numels, int cap) {
   if (!e) return -1;
-  e->wgrad_pass_begin();
-  // gradients that other kernels add to as well (heads, embeddings) are never owned
-  const int64_t other[] = {e->et.word, e->et.pos, e->et.type, e->et.wloc, e->ev.color, e->ev.wloc, e->cls.w, e->fu[3].w};
-  e->wgrad_owned.clear();
-  for (const auto& kv : e->wgrad_seen) {
-    if (kv.second.most != 1) continue;
-    bool shared = false;
-    for (int64_t o : other) shared = shared || o == kv.first;
-    if (!shared) e->wgrad_owned[kv.first] = kv.second.numel;
-  }
+  std::vector<std::pair<int64_t, int64_t>> v(e->wgrad_owned.begin(), e->wgrad_owned.end());
+  std::sort(v.begin(), v.end());
   int n = 0;
-  for (const auto& kv : e->wgrad_owned) {
+  for (const auto& kv : v) {
     if (offsets && numels && n < cap) { offsets[n] = kv.first; numels[n] = kv.second; }
     ++n;
   }
@@ -1123,16 +1067,6 @@ extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, 
   e->use_vis_stream = use_visual_stream != 0;
   e->use_wgrad_stream = use_wgrad_streams != 0;
   e->streams_forced = true;
-  return 0;
-}
-
-extern "C" int crct_engine_graph_stats(const crct_engine_t* e, int* n_keys, int* n_instantiated, int* broken) {
-  if (!e) return 1;
-  int k = 0, x = 0;
-  for (auto& g : e->graphs) { ++k; if (g.exec) ++x; }
-  if (n_keys) *n_keys = k;
-  if (n_instantiated) *n_instantiated = x;
-  if (broken) *broken = e->graph_broken ? 1 : 0;
   return 0;
 }
 

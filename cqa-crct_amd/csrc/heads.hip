@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const CrctHeadArgs a, fl
   }
   // upstream gradients of the two differentiable outputs (nsp_loss scalar, reg_loss rows): either
   // device tensors handed over by autograd, or the fixed combination of encoder_decorator.py:144-153
-  const float g_nsp = a.g_nsp_dev ? a.g_nsp_dev[0] : a.nsp_coeff * a.grad_scale;
-  const float g_reg = a.g_reg_dev ? a.g_reg_dev[b] : a.reg_coeff * a.grad_scale / (float)a.B;
+  // g_loss_dev: upstream gradient of the COMBINED loss stats[0] (a device scalar: 1, 1 / batch_multiply, a GradScaler scale ...)
+  const float g_loss = (a.g_loss_dev ? a.g_loss_dev[0] : 1.0f) * a.grad_scale;
+  const float g_nsp = a.g_nsp_dev ? a.g_nsp_dev[0] * a.grad_scale : a.nsp_coeff * g_loss;
+  const float g_reg = a.g_reg_dev ? a.g_reg_dev[b] * a.grad_scale : a.reg_coeff * g_loss / (float)a.B;
   // per-row scalars (every thread computes them identically)
   const float mx = fmaxf(l0, l1);
   const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
@@ -159,21 +161,29 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const CrctHeadArgs a, 
   if (blockIdx.x == 0 && tid < 64) {
     // one wave reduces the per-row records
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float rl = 0.f;
+    float rl = 0.f, d5 = 0.f;
     for (int b = tid; b < a.B; b += 64) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) s[k] += scratch[b * 8 + k];
       rl += a.reg[1 * a.B + b];
+      d5 += a.reg[4 * a.B + b];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] = wave_sum(s[k]);
     rl = wave_sum(rl);
+    d5 = wave_sum(d5);
     if (tid == 0) {
       const float nsp = s[4] > 0.f ? s[3] / s[4] : 0.f;
       const float reg_mean = rl / (float)a.B;
       a.stats[0] = a.labels ? a.nsp_coeff * nsp + a.reg_coeff * reg_mean : 0.f;
       a.stats[1] = nsp; a.stats[2] = reg_mean; a.stats[3] = s[7]; a.stats[4] = s[5]; a.stats[5] = s[6];
       a.stats[6] = s[4]; a.stats[7] = 0.f;
+      // stats[8..16]: the 9 floats train.py:181-183 shares between the ranks every iteration, ready for the all-reduce
+      // (loss, lm_loss = 0, nsp_loss, mean reg_loss / mean reg_5_dist over the rows that need regression -- 0 when there
+      // are none, as the reference's isnan test does --, legend_loss = 0, num_regs, reg_5_right, reg_t_right)
+      a.stats[8] = a.stats[0]; a.stats[9] = 0.f; a.stats[10] = nsp;
+      a.stats[11] = s[7] > 0.f ? rl / s[7] : 0.f; a.stats[12] = s[7] > 0.f ? d5 / s[7] : 0.f; a.stats[13] = 0.f;
+      a.stats[14] = s[7]; a.stats[15] = s[5]; a.stats[16] = s[6];
       if (a.d_b_cls) { a.d_b_cls[0] += s[0]; a.d_b_cls[1] += s[1]; }
       if (a.d_b_f6) a.d_b_f6[0] += s[2];
     }

@@ -24,7 +24,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const float* __restrict__ seg_lr, const float* __restrict__ seg_wd,
                                                     const int32_t* __restrict__ blk_seg, const int64_t* __restrict__ blk_off,
                                                     float beta1, float beta2, float eps, float inv_bc1, float inv_sqrt_bc2,
-                                                    const float* __restrict__ inv_scale_dev, int n_blk, int zero_g) {
+                                                    const float* __restrict__ inv_scale_dev, const CrctAmpState amp, int n_blk, int zero_g) {
+ // loss scaling (torch.amp.GradScaler): a step whose gradients held an inf / nan is skipped as a whole, the scale divides
+ // the gradients, and the step count behind the bias corrections is the device counter that only advances on real steps
+ if (amp.found_inf && amp.found_inf[0] != 0.f) return;
+ if (amp.step) {
+   const float st = (float)amp.step[0];
+   inv_bc1 = 1.0f / (1.0f - powf(beta1, st));
+   inv_sqrt_bc2 = 1.0f / sqrtf(1.0f - powf(beta2, st));
+ }
  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
   const int sgi = blk_seg[blk];
   const int64_t off = blk_off[blk];
@@ -33,7 +41,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   if (n > ADAMW_CHUNK) n = ADAMW_CHUNK;
   const float lr = seg_lr[sgi], wd = seg_wd[sgi];
   const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
-  const float gsc = inv_scale_dev ? inv_scale_dev[0] : 1.0f;
+  float gsc = inv_scale_dev ? inv_scale_dev[0] : 1.0f;
+  if (amp.grad_scale) gsc /= amp.grad_scale[0];
   for (int64_t i = (int64_t)threadIdx.x * 4; i < n; i += 1024) {
     const int64_t e = base + i;
     if (i + 4 <= n) {
@@ -82,6 +91,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
  }
 }
+__global__ void adamw_advance_kernel(int32_t* step, const float* found_inf) {
+  if (threadIdx.x == 0 && (!found_inf || found_inf[0] == 0.f)) step[0] += 1;
+}
 // g[off[r] + blk_off .. ) = 0 over the chunk table of crct_adamw_plan (same chunking as the update itself)
 __global__ __launch_bounds__(256) void zero_runs_kernel(float* __restrict__ g, const int64_t* __restrict__ run_off,
                                                         const int64_t* __restrict__ run_len, const int32_t* __restrict__ blk_seg,
@@ -125,8 +137,11 @@ extern "C" int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* b
 extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, const int64_t* seg_off,
                                const int64_t* seg_len, const float* seg_lr, const float* seg_wd, const int32_t* blk_seg,
                                const int64_t* blk_off, int64_t n_blk, float beta1, float beta2, float eps, int step,
-                               const float* inv_scale_dev, int max_workgroups, int zero_grads, crct_stream_t stream) {
+                               const float* inv_scale_dev, const CrctAmpState* amp_state, int max_workgroups, int zero_grads,
+                               crct_stream_t stream) {
   CRCT_REQUIRE(step >= 1, "adamw: step must be >= 1 (got %d)", step);
+  CrctAmpState amp = {nullptr, nullptr, nullptr};
+  if (amp_state) amp = *amp_state;
   if (n_blk <= 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   // max_workgroups > 0: a grid-stride launch of at most that many workgroups.  An update that runs BESIDE the next
@@ -135,7 +150,14 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      seg_off, seg_len, seg_lr, seg_wd, blk_seg, blk_off, beta1, beta2, eps, (float)(1.0 / bc1),
-                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, (int)n_blk, zero_grads);
+                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, (int)n_blk, zero_grads);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_stream_t stream) {
+  CRCT_REQUIRE(step_dev, "adamw_advance: null step counter");
+  hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, found_inf_dev);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

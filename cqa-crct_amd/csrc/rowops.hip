@@ -856,6 +856,36 @@ int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_strea
   return 0;
 }
 
+// Key masks of the step from what the data loader ships (encoder_decorator.py:118-120, vilbert.py:1380-1396):
+//   text key t of row b is attended iff t < sep_indices[b][hist_len[b]] + 1      (sequence_mask of the step adapter)
+//   visual key v of row b is attended iff image_mask[b][v] != 0
+// One launch instead of the gather / add / arange / compare / cast kernels the torch expression costs.
+__global__ __launch_bounds__(256) void build_keymasks_kernel(const int64_t* __restrict__ sep_indices, const int64_t* __restrict__ hist_len,
+                                                             int sep_stride, const int64_t* __restrict__ image_mask,
+                                                             uint8_t* __restrict__ km_t, uint8_t* __restrict__ km_v, int B, int T, int V) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (km_t && i < B * T) {
+    const int b = i / T, t = i % T;
+    long h = hist_len[b];
+    h = h < 0 ? 0 : (h >= sep_stride ? sep_stride - 1 : h);
+    km_t[i] = (long)t < sep_indices[(long)b * sep_stride + h] + 1 ? 1 : 0;
+  }
+  if (km_v && i < B * V) km_v[i] = image_mask[i] != 0 ? 1 : 0;
+}
+
+extern "C" int crct_build_keymasks(const int64_t* sep_indices, const int64_t* hist_len, int sep_stride, const int64_t* image_mask,
+                                   uint8_t* km_t, uint8_t* km_v, int B, int T, int V, crct_stream_t stream) {
+  CRCT_REQUIRE(B > 0 && T > 0 && V > 0, "build_keymasks: bad sizes");
+  CRCT_REQUIRE(!km_t || (sep_indices && hist_len && sep_stride > 0), "build_keymasks: sep_indices / hist_len are required for the text mask");
+  CRCT_REQUIRE(!km_v || image_mask, "build_keymasks: image_mask is required for the visual mask");
+  if (!km_t && !km_v) return 0;
+  const int n = B * (T > V ? T : V);
+  hipLaunchKernelGGL(build_keymasks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sep_indices, hist_len, sep_stride,
+                     image_mask, km_t, km_v, B, T, V);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream) {
   if (n <= 0) return 0;
   long blocks = (n / 8 + 255) / 256;

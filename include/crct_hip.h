@@ -125,6 +125,10 @@ int crct_colsum_blocks(int M);
 int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int M, int N,
                      int accumulate, crct_stream_t stream);
 
+/* Key masks (uint8, 1 = attend) from the batch as the data loader ships it -- see CrctBatch.  km_t / km_v may be NULL. */
+int crct_build_keymasks(const int64_t* sep_indices, const int64_t* hist_len, int sep_stride, const int64_t* image_mask,
+                        uint8_t* km_t, uint8_t* km_v, int B, int T, int V, crct_stream_t stream);
+
 /* Row softmax fp32 [M][F] -> bf16 [M][F]  (F.softmax(image_feat), vilbert.py:1476). */
 int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_stream_t stream);
 
@@ -214,9 +218,12 @@ int crct_embed_image_bwd(const void* dy, const void* sum_saved, const float* mea
  * encoder_decorator.py:144-153 -- one launch, no host sync.
  *  pooled_t, pooled_v  bf16 [B][Hb] (relu'd pooler outputs), fus_h bf16 [B][256] (LeakyReLU(fusion.4(..)))
  *  outputs: logits fp32 [B][2]; reg fp32 [5][B] = pred*scale, reg_loss, reg_l1, raw tanh output, dist5;
- *           stats fp32 [8] = loss, nsp_loss, mean_B reg_loss, n_needs, n_right5, n_rightT, n_valid_labels, 0
- *  gradient seeds (upstream gradients: g_nsp_dev / g_reg_dev when given, else nsp_coeff*grad_scale and
- *  reg_coeff*grad_scale/B as in encoder_decorator.py:144-153): d_pooled_t / d_pooled_v
+ *           stats fp32 [17] = loss, nsp_loss, mean_B reg_loss, n_needs, n_right5, n_rightT, n_valid_labels, 0, then [8..16] =
+ *           the 9 floats train.py:181-189 all-reduces every iteration: loss, lm_loss (0), nsp_loss, mean reg_loss and mean
+ *           reg_5_dist over the rows that need regression (0 if none), legend_loss (0), num_regs, reg_5_right, reg_t_right
+ *  gradient seeds (upstream gradients: grad_scale * g_nsp_dev / g_reg_dev when given, else nsp_coeff*g and reg_coeff*g/B as
+ *  in encoder_decorator.py:144-153 with g = grad_scale * (*g_loss_dev, or 1); grad_scale is the data-parallel 1 / world):
+ *  d_pooled_t / d_pooled_v
  *  bf16 [B][Hb] = gradient w.r.t. the poolers' PRE-activations (dropout and ReLU undone),
  *  d_fus_h bf16 [B][256] = gradient w.r.t. fusion.4's pre-activation; parameter gradients of
  *  bi_seq_relationship / fusion.6 are ACCUMULATED into d_w_cls[2][Hb], d_b_cls[2], d_w_f6[256], d_b_f6[1].
@@ -232,6 +239,7 @@ typedef struct CrctHeadArgs {
   float* d_w_cls; float* d_b_cls; float* d_w_f6; float* d_b_f6;
   const float* g_nsp_dev;         /* optional device scalar: dLoss/d nsp_loss */
   const float* g_reg_dev;         /* optional device [B]:    dLoss/d reg_loss[b] */
+  const float* g_loss_dev;        /* optional device scalar: dLoss/d stats[0] (the combined loss); multiplies the default seeds */
   int32_t B, Hb;
   int32_t fusion_sum;             /* 0 = 'mul' (default, vilbert.py:163), 1 = 'sum' */
   int32_t use_l1;                 /* params['L1'] : L1Loss vs SmoothL1Loss(beta=0.5), vilbert.py:1525-1528 */
@@ -262,11 +270,17 @@ int crct_eval_select(const float* logits, const float* reg_out, const float* reg
  * zero_grads != 0: every gradient element is overwritten with 0 right after it has been read (optimizer.zero_grad()
  * folded into the update: the separate 953 MB memset disappears).
  */
+/* Loss scaling as torch.amp.GradScaler drives it (train.py:157,208-212: scaler.scale(loss).backward(); scaler.step(optimizer)):
+ * grad_scale = the scaler's scale (the gradients are divided by it inside the update), found_inf != 0 skips the whole step,
+ * step = device counter of the steps really taken (replaces the host `step` in the bias corrections; crct_adamw_advance
+ * increments it unless found_inf is set).  All device pointers, each may be NULL. */
+typedef struct CrctAmpState { const float* grad_scale; const float* found_inf; const int32_t* step; } CrctAmpState;
+int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_stream_t stream);
 int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap);
 int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
                     const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
                     const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk,
-                    float beta1, float beta2, float eps, int step, const float* inv_scale_dev,
+                    float beta1, float beta2, float eps, int step, const float* inv_scale_dev, const CrctAmpState* amp,
                     int max_workgroups, int zero_grads, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -302,15 +316,21 @@ typedef struct CrctBatch {
   const float* image_feat; const float* image_loc; const int64_t* image_target; const uint8_t* image_keymask;
   const float* R; const int64_t* labels;   /* labels NULL => evaluation */
   int32_t B, T, V;
+  /* When text_keymask / image_keymask is NULL the engine builds it in its workspace (one launch, crct_build_keymasks) from
+   * what the data loader ships: sep_indices int64 [B][sep_stride] + hist_len int64 [B] (key t attended iff
+   * t < sep_indices[b][hist_len[b]] + 1, encoder_decorator.py:118-120) / image_mask int64 [B][V] (attended iff != 0). */
+  const int64_t* sep_indices; const int64_t* hist_len; const int64_t* image_mask;
+  int32_t sep_stride;
 } CrctBatch;
 
 typedef struct CrctStepCfg {
   int32_t training;          /* dropout on/off */
   int32_t use_l1, kind_l1;
   float tol_margin, nsp_coeff, reg_coeff, grad_scale;
-  uint64_t seed;             /* dropout seed: the value, or (1<<63 | device address of a u64 holding it) */
+  uint64_t seed;             /* dropout seed: the value, or (1<<63 | device address of a u64 holding it, re-read at run time) */
   const float* g_nsp_dev;    /* optional upstream gradients from autograd (device) */
   const float* g_reg_dev;
+  const float* g_loss_dev;   /* optional device scalar: upstream gradient of the combined loss stats[0]; used when g_nsp_dev / g_reg_dev are NULL */
   const void* const* seg_ready_events;   /* optional HOST array [crct_engine_num_segments] of hipEvent_t (or NULL entries):
                                 forward makes the stream(s) of the layers of segment s wait for event s before they run --
                                 lets a per-segment optimizer update of step n overlap the forward of step n+1 */
@@ -319,8 +339,6 @@ typedef struct CrctStepCfg {
                                 on the four internal streams (text, text weight-gradient, visual, visual weight-gradient); once
                                 all four have fired, the gradient range of segments 0 .. s is final -- a data-parallel caller
                                 starts that range's all-reduce behind them while the rest of backward keeps running */
-  int32_t use_graph;         /* != 0: capture the call into a hipGraph on its 2nd occurrence and replay it afterwards;
-                                every pointer argument (and a memory-resident seed) must then be stable across calls */
   int32_t wgrad_overwrite;   /* backward only.  != 0: the caller guarantees that nothing has been accumulated into the weight
                                 gradients listed by crct_engine_wgrad_owned since they were last consumed; those gradients are
                                 then WRITTEN instead of added to (bit-identical to adding into zeros) and need not be zeroed --
@@ -342,19 +360,16 @@ int crct_engine_backward(crct_engine_t*, const float* params_f32, const void* pa
 /* Internal concurrency (default: both on): the visual stream's layers run on a second HIP stream and all
  * weight-gradient GEMMs / bias column sums on two more, forked from and joined to `stream` inside every call.
  * Results do not depend on the setting (tests compare them bit for bit). */
-/* The weight gradients (flat offsets / element counts into grads_f32) that exactly one weight-gradient GEMM per backward
- * pass produces and nothing else adds to, as observed over the backward passes run so far (call after at least one
- * complete pass; returns the count, fills up to `cap` entries).  Only gradients reported here are overwritten under
- * CrctStepCfg.wgrad_overwrite; the call freezes that set until it is called again. */
+/* The weight gradients (flat offsets / element counts into grads_f32, sorted by offset) that exactly one weight-gradient
+ * GEMM per backward pass produces and nothing else adds to: every Linear weight of the encoder layers, the image embedding,
+ * the poolers and the regressor pipes.  The set is fixed by the schedule at crct_engine_create (it does not depend on the
+ * batch size); only these gradients are overwritten under CrctStepCfg.wgrad_overwrite.  Returns the count, fills up to `cap`. */
 int crct_engine_wgrad_owned(crct_engine_t*, int64_t* offsets, int64_t* numels, int cap);
 /* fp32 zero fill of `n_runs` ranges base[off[i] .. off[i] + len[i]) (device arrays off / len; blk_* from crct_adamw_plan
  * over len): the gradients that stay accumulate-only under wgrad_overwrite.  Non-temporal stores. */
 int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
                    int64_t n_blk, crct_stream_t stream);
 int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
-/* hipGraph cache counters (experimental graph mode, CrctStepCfg.use_graph). */
-int crct_engine_graph_stats(const crct_engine_t*, int* n_keys, int* n_instantiated, int* broken);
-
 /* Debug taps: copy a named bf16 activation ("emb.t", "t3.t", "c0.v", "seq_t" ...) of the last
  * forward (batch B, T, V) into `out` (device, bf16); returns the element count or -1. */
 int64_t crct_engine_tap(crct_engine_t*, const void* workspace, const char* name, int B, int T, int V,

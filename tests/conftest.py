@@ -18,3 +18,57 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- the 2-rank data-parallel GPU test needs two FRESH processes on the GPU.  They are started here, at session start,
+# before this pytest process has initialised the GPU (a process that has must not exec another program on the GPU pool);
+# they run beside the other GPU tests and tests/test_ddp_gpu.py collects their results.
+_DDP = {"workers": None}
+
+
+def _gpu_selected(config):
+    m = config.getoption("-m") or ""
+    return "gpu" in m and "not gpu" not in m
+
+
+def pytest_sessionstart(session):
+    if not _gpu_selected(session.config) or os.environ.get("CRCT_NO_DDP_WORKERS"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:          # counting devices does not initialise the GPU
+            return
+    except Exception:
+        return
+    import socket
+    import subprocess
+    import tempfile
+    outdir = tempfile.mkdtemp(prefix="crct_ddp_")
+    procs = {}
+    for case in ("tiny", "full"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs[case] = []
+        for rank in range(2):
+            log_path = os.path.join(outdir, "%s_rank%d.log" % (case, rank))
+            log = open(log_path, "w")
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(rank), "2", str(port), outdir, case],
+                                  stdout=log, stderr=subprocess.STDOUT, env=env)
+            pr.log_path = log_path
+            procs[case].append(pr)
+    _DDP["workers"] = (outdir, procs)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _DDP["workers"]:
+        for prs in _DDP["workers"][1].values():
+            for pr in prs:
+                if pr.poll() is None:
+                    pr.kill()
+
+
+@pytest.fixture(scope="session")
+def ddp_workers():
+    return _DDP["workers"]

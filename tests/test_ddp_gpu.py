@@ -1,0 +1,96 @@
+"""-m gpu: crct.ddp.FlatGradDDP with a REAL second rank (train.py:138-143,181-189,205-215).
+
+Two fresh worker processes (tests/ddp_worker.py) share cuda:0 and exchange over gloo; they are started by
+tests/conftest.py at session start -- before this pytest process initialises the GPU -- and run beside the other GPU tests;
+this module waits for them and checks what rank 0 and rank 1 wrote against the CPU oracle:
+
+  * the all-reduced flat gradient (event mode: one engine backward call, bucketed all-reduces behind per-segment events)
+    equals the oracle's gradient of the loss over the CONCATENATED batch (= the mean of the two ranks' losses),
+  * ``no_sync()`` + ``batch_multiply = 2`` gives the same gradient, and nothing is exchanged on the first micro-step,
+  * both ranks hold identical gradients, rank 1 received rank 0's parameters at construction,
+  * the 9-float stats all-reduce returns the world average / sums.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from crct import config as C                       # noqa: E402
+from crct import synthetic as S                    # noqa: E402
+from oracle import crct_oracle as O                # noqa: E402
+from helpers import seeded_weights                 # noqa: E402
+
+
+def _results(case, ddp_workers):
+    if ddp_workers is None:
+        pytest.skip("the DDP workers were not started (no GPU visible at session start)")
+    outdir, procs = ddp_workers
+    for pr in procs[case]:
+        rc = pr.wait(timeout=240)
+        assert rc == 0, "DDP worker failed:\n" + open(pr.log_path).read()[-4000:]
+    res = []
+    for r in range(2):
+        with np.load(os.path.join(outdir, "%s_rank%d.npz" % (case, r))) as z:
+            res.append({k: z[k] for k in z.files})      # read every array ONCE (an NpzFile re-reads the file on each access)
+    return res
+
+
+def _cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("case", ["tiny", "full"])
+def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
+    r0, r1 = _results(case, ddp_workers)
+    if case == "tiny":
+        cfg = C.tiny_config()
+        params = C.default_params(categories=9)
+        batch = S.make_batch(8, 9, 6, cfg.v_feature_size, categories=9, vocab_size=cfg.vocab_size, seed=5)
+    else:
+        cfg = C.vilbert_config(v_feature_size=2048, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                               v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
+        params = C.default_params()
+        batch = S.make_batch(16, 20, 36, 2048, seed=5)
+        torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+    cpu_params = dict(params, device=torch.device("cpu"))
+    sd = seeded_weights(cfg, cpu_params, base_seed=7)           # rank 0's weights: rank 1 must have received them
+    ref = O.oracle_step(sd, cfg, cpu_params, batch, cls_dropout=0.0)
+    ref[0].backward()
+    from crct.layout import parameter_table
+    table, total = parameter_table(cfg, cpu_params)
+    assert int(r0["n_buckets"][0]) >= (4 if case == "tiny" else 8)
+    # identical on both ranks, and equal to the mean of the ranks' losses' gradient
+    for key in ("g_sync", "g_accum"):
+        assert np.array_equal(r0[key], r1[key]), key
+    mean_loss = 0.5 * (float(r0["loss"][0]) + float(r1["loss"][0]))
+    assert abs(mean_loss - float(ref[0])) <= 2e-2 * abs(float(ref[0]))
+    assert np.array_equal(r0["params_after_broadcast"], r1["params_after_broadcast"])
+    bad = []
+    for e in table:
+        if not e.used:
+            continue
+        r = sd[e.name].grad.flatten()
+        rn = float(r.double().norm())
+        for key in ("g_sync", "g_accum"):
+            g = torch.from_numpy(r0[key][e.offset:e.offset + e.numel])
+            if rn < 1e-7:
+                assert float(g.double().norm()) < 1e-3, (e.name, key)
+                continue
+            c, ratio = _cosine(g, r), float(g.double().norm()) / rn
+            # tiny: 0.99 as in test_tiny_step_matches_reference; full depth: the bounds of test_full_size_step_matches_oracle
+            tol_c, tol_r = (0.99, 0.08) if case == "tiny" else (0.97, 0.06)
+            if c < tol_c or abs(ratio - 1) > tol_r:
+                bad.append((key, e.name, round(c, 4), round(ratio, 4)))
+    assert not bad, (len(bad), bad[:10])
+    # no exchange on the accumulation-only micro-step: the two ranks' local gradients differ
+    assert not np.array_equal(r0["g_local_after_no_sync"], r1["g_local_after_no_sync"])
+    # stats: first six averaged over the ranks, last three summed (train.py:181-189)
+    s = r0["stats9"]
+    assert np.array_equal(s, r1["stats9"])
+    assert abs(float(s[0]) - mean_loss) < 1e-5
+    needs = batch["R"][:, 1] == 1
+    assert float(s[6]) == float(needs.sum())

@@ -351,7 +351,7 @@ def test_adamw_matches_torch():
         opt.step()
         L.check(lib.crct_adamw_step(p.data_ptr(), (grad * step).data_ptr(), m.data_ptr(), v.data_ptr(), pb.data_ptr(), seg_off.data_ptr(),
                                     seg_len.data_ptr(), seg_lr.data_ptr(), seg_wd.data_ptr(), bs.data_ptr(), bo.data_ptr(), bs.numel(),
-                                    0.9, 0.999, 1e-8, step, None, 2 if step == 2 else 0, 0, L.current_stream()))   # step 2: throttled grid
+                                    0.9, 0.999, 1e-8, step, None, None, 2 if step == 2 else 0, 0, L.current_stream()))   # step 2: throttled grid
     for rp, o, s in zip(ref_params, offs, sizes):
         assert torch.allclose(p[o:o + s].cpu(), rp.detach(), rtol=1e-5, atol=1e-7)
         assert torch.equal(pb[o:o + s].cpu(), p[o:o + s].cpu().to(torch.bfloat16))

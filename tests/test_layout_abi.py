@@ -81,13 +81,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "symbol %s declared in include/crct_hip.h is not exported" % name
     assert set(L.PROTOTYPES) <= set(declared)
     handle = L.load()
-    assert handle.crct_abi_version() == 1
+    assert handle.crct_abi_version() == 2
 
 
 def test_struct_mirrors_and_error_path():
     # sizes from the header's field lists (LP64)
     assert C.sizeof(L.GemmArgs) == 7 * 8 + 5 * 8 + 10 * 4 + 4 + 4 + 4 + 4 + 8 + 8     # ... seed, rowsum_out
-    assert C.sizeof(L.Batch) == 10 * 8 + 3 * 4 + 4
+    assert C.sizeof(L.Batch) == 10 * 8 + 3 * 4 + 4 + 3 * 8 + 4 + 4      # ... B, T, V, pad, sep_indices, hist_len, image_mask, sep_stride, pad
     assert C.sizeof(L.ModelDims) == 16 * 4 + 64 * 4 + 2 * 4 + 5 * 4
     lib = L.load()
     g = L.GemmArgs()
