@@ -84,7 +84,7 @@ def gemm_profile(model, run_step, n_steps):
     torch.cuda.synchronize()
     lib.crct_prof_enable(0)
     rows = []
-    for v in range(192):
+    for v in range(72):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue

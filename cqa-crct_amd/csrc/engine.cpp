@@ -119,7 +119,7 @@ struct crct_engine {
   struct { size_t sum, y, mean, rstd; } eta;
   struct { size_t soft, lin, sum, y, mean, rstd; } eva;
   LinearP t_pool, v_pool, cls, tp[4], vp[4], fu[4];
-  struct { size_t pooled_t, pooled_v, t[3], v[3], cat, f[3], scratch, d_pt, d_pv, g[4]; } ha;
+  struct { size_t pooled_t, pooled_v, t[3], v[3], cat, f[3], scratch, d_pt, d_pv, g[10]; } ha;   // g: one buffer per head gradient (see heads_bwd)
   StreamScratch st, sv;          // backward scratch per data stream (dy ping-pong lives in these)
   StreamScratch st2, sv2;        // second set: layers alternate sets so weight-gradient GEMMs may lag one layer behind
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
@@ -532,114 +532,115 @@ struct Run {
     lin_fwd(A(acts[1]), l[1].out, l[2], B, A(acts[2]), l[2].out, o);
     lin_fwd(A(acts[2]), l[2].out, l[3], B, out_last, ld_last, Opt());
   }
-  // backward of a pipe: du3 = grad of the last Linear's output (ld = ld3); writes dx0 (+= if acc)
+  // backward of a pipe: du3 = grad of the last Linear's output (ld = ld3); writes dx0 (+= if acc).  gb = three gradient
+  // buffers of this pipe alone (nothing is recycled: the weight-gradient GEMMs that read them run later, on the side stream)
   void pipe_bwd(const LinearP* l, const bf16_t* x0, int64_t ldx0, const size_t* acts, const bf16_t* du3, int64_t ld3,
-                bf16_t* dx0, int64_t lddx0, bool acc0, int B) {
-    const size_t ga = e->ha.g[0], gb = e->ha.g[1];
+                bf16_t* dx0, int64_t lddx0, bool acc0, int B, const size_t* gb) {
     bias_grad(du3, ld3, l[3], B);
     lin_wgrad(du3, ld3, A(acts[2]), l[2].out, l[3], B);
     Opt o; o.dact = ACT_LEAKY; o.dact_src = A(acts[2]); o.ld_aux = l[2].out;
-    lin_dgrad(du3, ld3, l[3], B, A(ga), l[2].out, o);                         // du2
-    bias_grad(A(ga), l[2].out, l[2], B);
-    lin_wgrad(A(ga), l[2].out, A(acts[1]), l[1].out, l[2], B);
+    lin_dgrad(du3, ld3, l[3], B, A(gb[0]), l[2].out, o);                      // du2
+    bias_grad(A(gb[0]), l[2].out, l[2], B);
+    lin_wgrad(A(gb[0]), l[2].out, A(acts[1]), l[1].out, l[2], B);
     o.dact_src = A(acts[1]); o.ld_aux = l[1].out;
-    lin_dgrad(A(ga), l[2].out, l[2], B, A(gb), l[1].out, o);                  // du1
-    bias_grad(A(gb), l[1].out, l[1], B);
-    lin_wgrad(A(gb), l[1].out, A(acts[0]), l[0].out, l[1], B);
+    lin_dgrad(A(gb[0]), l[2].out, l[2], B, A(gb[1]), l[1].out, o);            // du1
+    bias_grad(A(gb[1]), l[1].out, l[1], B);
+    lin_wgrad(A(gb[1]), l[1].out, A(acts[0]), l[0].out, l[1], B);
     o.dact_src = A(acts[0]); o.ld_aux = l[0].out;
-    lin_dgrad(A(gb), l[1].out, l[1], B, A(ga), l[0].out, o);                  // du0
-    bias_grad(A(ga), l[0].out, l[0], B);
-    lin_wgrad(A(ga), l[0].out, x0, ldx0, l[0], B);
-    if (dx0) { Opt od; od.acc = acc0; lin_dgrad(A(ga), l[0].out, l[0], B, dx0, lddx0, od); }
+    lin_dgrad(A(gb[1]), l[1].out, l[1], B, A(gb[2]), l[0].out, o);            // du0
+    bias_grad(A(gb[2]), l[0].out, l[0], B);
+    lin_wgrad(A(gb[2]), l[0].out, x0, ldx0, l[0], B);
+    if (dx0) { Opt od; od.acc = acc0; lin_dgrad(A(gb[2]), l[0].out, l[0], B, dx0, lddx0, od); }
   }
 
-  void heads_fwd(size_t seq_t, size_t seq_v, float* logits, float* reg, float* stats, bool with_grad) {
+  // Heads, forward.  The pooler and the regressor pipe of a stream only need that stream's last hidden states, so each data
+  // stream runs its own branch (this = text or visual Run) before the two join for the fusion MLP and the loss kernel.
+  void heads_branch_fwd(bool visual, size_t seq) {
     const CrctModelDims& D = e->d;
     const int B = b->B;
-    const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;     // CLS / IMG rows: hidden_states[:, 0]
+    const int64_t ld = visual ? (int64_t)b->V * D.Hv : (int64_t)b->T * D.H;  // CLS / IMG rows: hidden_states[:, 0]
     Opt orelu; orelu.act = ACT_RELU;
-    lin_fwd(A(seq_t), ldt, e->t_pool, B, A(e->ha.pooled_t), D.Hb, orelu);      // vilbert.py:955-961
-    lin_fwd(A(seq_v), ldv, e->v_pool, B, A(e->ha.pooled_v), D.Hb, orelu);      // :970-976
-    // regressor on the raw CLS / IMG states (vilbert.py:1599-1600); cat = (hv, hw)  regressor.py:39-41
-    pipe_fwd(e->vp, A(seq_v), ldv, e->ha.v, A(e->ha.cat), 512, B);
-    pipe_fwd(e->tp, A(seq_t), ldt, e->ha.t, A(e->ha.cat) + 256, 512, B);
+    if (visual) {
+      lin_fwd(A(seq), ld, e->v_pool, B, A(e->ha.pooled_v), D.Hb, orelu);     // vilbert.py:970-976
+      pipe_fwd(e->vp, A(seq), ld, e->ha.v, A(e->ha.cat), 512, B);            // regressor on the raw IMG state; cat = (hv, hw): regressor.py:39-41
+    } else {
+      lin_fwd(A(seq), ld, e->t_pool, B, A(e->ha.pooled_t), D.Hb, orelu);     // vilbert.py:955-961
+      pipe_fwd(e->tp, A(seq), ld, e->ha.t, A(e->ha.cat) + 256, 512, B);
+    }
+  }
+  void fill_head_args(CrctHeadArgs& h, float* logits, float* reg, float* stats, bool with_grad) {
+    const CrctModelDims& D = e->d;
+    memset(&h, 0, sizeof(h));
+    h.pooled_t = A(e->ha.pooled_t); h.pooled_v = A(e->ha.pooled_v); h.fus_h = A(e->ha.f[2]);
+    h.w_cls = P(e->cls.w); h.b_cls = P(e->cls.b); h.w_f6 = P(e->fu[3].w); h.b_f6 = P(e->fu[3].b);
+    h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
+    if (with_grad && g32) {
+      h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[0]);
+      h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
+    }
+    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev; h.g_loss_dev = c->g_loss_dev;
+    h.B = b->B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
+    h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
+    const Drop dc = drop(D.p_cls, 3);
+    h.drop_thr = dc.thr; h.drop_scale = dc.scale; h.drop_site = dc.site; h.seed = c->seed;
+  }
+  void heads_tail_fwd(float* logits, float* reg, float* stats) {
+    const int B = b->B;
     Opt o; o.act = ACT_LEAKY;
     lin_fwd(A(e->ha.cat), 512, e->fu[0], B, A(e->ha.f[0]), 512, o);
     lin_fwd(A(e->ha.f[0]), 512, e->fu[1], B, A(e->ha.f[1]), 256, o);
     lin_fwd(A(e->ha.f[1]), 256, e->fu[2], B, A(e->ha.f[2]), 256, o);
     if (rc) return;
     CrctHeadArgs h;
-    memset(&h, 0, sizeof(h));
-    h.pooled_t = A(e->ha.pooled_t); h.pooled_v = A(e->ha.pooled_v); h.fus_h = A(e->ha.f[2]);
-    h.w_cls = P(e->cls.w); h.b_cls = P(e->cls.b); h.w_f6 = P(e->fu[3].w); h.b_f6 = P(e->fu[3].b);
-    h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
-    if (with_grad && g32) {
-      h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
-      h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
-    }
-    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev; h.g_loss_dev = c->g_loss_dev;
-    h.B = B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
-    h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
-    const Drop dc = drop(D.p_cls, 3);
-    h.drop_thr = dc.thr; h.drop_scale = dc.scale; h.drop_site = dc.site; h.seed = c->seed;
+    fill_head_args(h, logits, reg, stats, false);
     fail(crct_head_loss(&h, s));
   }
-  // heads backward: fills the CLS / IMG rows of the running activation gradients (other rows zero)
-  void heads_bwd(size_t seq_t, size_t seq_v, size_t gt, size_t gv, float* logits, float* reg, float* stats) {
+  // Heads, backward (this = text stream, V = visual stream): fills the CLS / IMG rows of the running activation gradients
+  // (other rows zero).  On the critical chain are only the loss kernel and the 13 small data-gradient GEMMs -- the visual
+  // pooler / pipe on the visual stream beside the text ones; the 13 weight-gradient GEMMs and bias column sums are queued
+  // for the side streams like those of every encoder layer (every gradient buffer below has ONE producer and is not
+  // recycled within the call).
+  void heads_bwd(Run& V, size_t seq_t, size_t seq_v, size_t gt, size_t gv, float* logits, float* reg, float* stats) {
     const CrctModelDims& D = e->d;
     const int B = b->B;
     const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;
-    // the loss kernel is re-run with gradient outputs enabled (cheap: B rows) so that forward can
-    // be called alone for evaluation
-    // the head's small GEMM chain recycles two scratch buffers every other call: keep its weight-gradient
-    // GEMMs on this stream (in order) instead of the side stream
-    struct SwGuard { Run* r; hipStream_t keep; ~SwGuard() { r->sw = keep; r->defer_wgrad = true; } } guard{this, sw};
-    flush_wgrads();
-    sw = s;
-    defer_wgrad = false;
-    heads_fwd_grad_only(logits, reg, stats);
+    const size_t* g = e->ha.g;
+    // the loss kernel is re-run with gradient outputs enabled (cheap: B rows) so that forward can be called alone for evaluation
+    {
+      CrctHeadArgs h;
+      fill_head_args(h, logits, reg, stats, true);
+      if (!rc) fail(crct_head_loss(&h, s));
+    }
     if (rc) return;
+    if (!V.rc) V.fail(order_streams(e, s, V.s));                              // d_pooled_v is ready
     if (hipMemsetAsync(A(gt), 0, (size_t)B * b->T * D.H * 2, s) != hipSuccess ||
-        hipMemsetAsync(A(gv), 0, (size_t)B * b->V * D.Hv * 2, s) != hipSuccess) { crct_set_error("engine: memset failed"); rc = 1; return; }
+        hipMemsetAsync(V.A(gv), 0, (size_t)B * b->V * D.Hv * 2, V.s) != hipSuccess) { crct_set_error("engine: memset failed"); rc = 1; return; }
+    ++tick; ++V.tick;
     // poolers (gradients already w.r.t. the pre-activations)
     bias_grad(A(e->ha.d_pt), D.Hb, e->t_pool, B);
     lin_wgrad(A(e->ha.d_pt), D.Hb, A(seq_t), ldt, e->t_pool, B);
     lin_dgrad(A(e->ha.d_pt), D.Hb, e->t_pool, B, A(gt), ldt, Opt());
-    bias_grad(A(e->ha.d_pv), D.Hb, e->v_pool, B);
-    lin_wgrad(A(e->ha.d_pv), D.Hb, A(seq_v), ldv, e->v_pool, B);
-    lin_dgrad(A(e->ha.d_pv), D.Hb, e->v_pool, B, A(gv), ldv, Opt());
-    // fusion MLP: g[2] = grad of fusion.4's pre-activation
-    const size_t g2 = e->ha.g[2], g3 = e->ha.g[3];
-    bias_grad(A(g2), 256, e->fu[2], B);
-    lin_wgrad(A(g2), 256, A(e->ha.f[1]), 256, e->fu[2], B);
+    V.bias_grad(V.A(e->ha.d_pv), D.Hb, e->v_pool, B);
+    V.lin_wgrad(V.A(e->ha.d_pv), D.Hb, V.A(seq_v), ldv, e->v_pool, B);
+    V.lin_dgrad(V.A(e->ha.d_pv), D.Hb, e->v_pool, B, V.A(gv), ldv, Opt());
+    // fusion MLP: g[0] = grad of fusion.4's pre-activation (from the loss kernel)
+    bias_grad(A(g[0]), 256, e->fu[2], B);
+    lin_wgrad(A(g[0]), 256, A(e->ha.f[1]), 256, e->fu[2], B);
     Opt o; o.dact = ACT_LEAKY; o.dact_src = A(e->ha.f[1]); o.ld_aux = 256;
-    lin_dgrad(A(g2), 256, e->fu[2], B, A(g3), 256, o);                         // d fusion.2 pre-act
-    bias_grad(A(g3), 256, e->fu[1], B);
-    lin_wgrad(A(g3), 256, A(e->ha.f[0]), 512, e->fu[1], B);
+    lin_dgrad(A(g[0]), 256, e->fu[2], B, A(g[1]), 256, o);                     // d fusion.2 pre-act
+    bias_grad(A(g[1]), 256, e->fu[1], B);
+    lin_wgrad(A(g[1]), 256, A(e->ha.f[0]), 512, e->fu[1], B);
     o.dact_src = A(e->ha.f[0]); o.ld_aux = 512;
-    lin_dgrad(A(g3), 256, e->fu[1], B, A(g2), 512, o);                         // d fusion.0 pre-act [B,512]
-    bias_grad(A(g2), 512, e->fu[0], B);
-    lin_wgrad(A(g2), 512, A(e->ha.cat), 512, e->fu[0], B);
-    lin_dgrad(A(g2), 512, e->fu[0], B, A(g3), 512, Opt());                     // d cat [B,512] = (d hv, d hw)
+    lin_dgrad(A(g[1]), 256, e->fu[1], B, A(g[2]), 512, o);                     // d fusion.0 pre-act [B,512]
+    bias_grad(A(g[2]), 512, e->fu[0], B);
+    lin_wgrad(A(g[2]), 512, A(e->ha.cat), 512, e->fu[0], B);
+    lin_dgrad(A(g[2]), 512, e->fu[0], B, A(g[3]), 512, Opt());                 // d cat [B,512] = (d hv, d hw)
+    if (!rc && !V.rc) V.fail(order_streams(e, s, V.s));                        // d cat is ready
     // pipes; their input gradients accumulate onto the pooler's rows
-    pipe_bwd(e->vp, A(seq_v), ldv, e->ha.v, A(g3), 512, A(gv), ldv, true, B);
-    pipe_bwd(e->tp, A(seq_t), ldt, e->ha.t, A(g3) + 256, 512, A(gt), ldt, true, B);
-  }
-  void heads_fwd_grad_only(float* logits, float* reg, float* stats) {
-    const CrctModelDims& D = e->d;
-    CrctHeadArgs h;
-    memset(&h, 0, sizeof(h));
-    h.pooled_t = A(e->ha.pooled_t); h.pooled_v = A(e->ha.pooled_v); h.fus_h = A(e->ha.f[2]);
-    h.w_cls = P(e->cls.w); h.b_cls = P(e->cls.b); h.w_f6 = P(e->fu[3].w); h.b_f6 = P(e->fu[3].b);
-    h.R = b->R; h.labels = b->labels; h.logits = logits; h.reg = reg; h.stats = stats; h.scratch = F(e->ha.scratch);
-    h.d_pooled_t = A(e->ha.d_pt); h.d_pooled_v = A(e->ha.d_pv); h.d_fus_h = A(e->ha.g[2]);
-    h.d_w_cls = G(e->cls.w); h.d_b_cls = G(e->cls.b); h.d_w_f6 = G(e->fu[3].w); h.d_b_f6 = G(e->fu[3].b);
-    h.g_nsp_dev = c->g_nsp_dev; h.g_reg_dev = c->g_reg_dev; h.g_loss_dev = c->g_loss_dev;
-    h.B = b->B; h.Hb = D.Hb; h.fusion_sum = D.fusion_sum; h.use_l1 = c->use_l1; h.kind_l1 = c->kind_l1;
-    h.tol_margin = c->tol_margin; h.nsp_coeff = c->nsp_coeff; h.reg_coeff = c->reg_coeff; h.grad_scale = c->grad_scale;
-    const Drop dc = drop(D.p_cls, 3);
-    h.drop_thr = dc.thr; h.drop_scale = dc.scale; h.drop_site = dc.site; h.seed = c->seed;
-    fail(crct_head_loss(&h, s));
+    V.pipe_bwd(e->vp, V.A(seq_v), ldv, e->ha.v, V.A(g[3]), 512, V.A(gv), ldv, true, B, g + 4);
+    pipe_bwd(e->tp, A(seq_t), ldt, e->ha.t, A(g[3]) + 256, 512, A(gt), ldt, true, B, g + 7);
+    flush_wgrads();
+    V.flush_wgrads();
   }
 };
 
@@ -803,7 +804,7 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     size_t w = 512;
     if ((size_t)D.H > w) w = D.H;
     if ((size_t)D.Hv > w) w = D.Hv;
-    for (int k = 0; k < 4; ++k) e->ha.g[k] = ar.take(B * w * 2);
+    for (int k = 0; k < 10; ++k) e->ha.g[k] = ar.take(B * w * 2);
   }
   e->st = scratch_a(ar, Mt, D.H, D.I, D.Hb);
   e->sv = scratch_a(ar, Mv, D.Hv, D.Iv, D.Hb);
@@ -958,9 +959,12 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
     else if (st.kind == 'v') { Rv.self_fwd(e->vl[st.idx], e->vla[st.idx], xv, batch->image_keymask, batch->B, batch->V); xv = e->vla[st.idx].ffn.y; }
     else { Rt.conn_fwd(Rv, e->cl[st.idx], e->cla[st.idx], xv, xt); xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
   }
-  Rt.fail(order_streams(e, Rv.s, Rt.s));                 // join
   wait_params(Rt, 0);
-  Rt.heads_fwd(xt, xv, logits, reg, stats, false);
+  wait_params(Rv, 0);
+  Rt.heads_branch_fwd(false, xt);
+  Rv.heads_branch_fwd(true, xv);
+  Rt.fail(order_streams(e, Rv.s, Rt.s));                 // join
+  Rt.heads_tail_fwd(logits, reg, stats);
   return Rt.rc ? Rt.rc : Rv.rc;
 }
 
@@ -999,8 +1003,7 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   for (int sgi = s0; sgi < s1 && !Rt.rc && !Rv.rc; ++sgi) {
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
-      Rt.heads_bwd(e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
-      Rv.fail(order_streams(e, Rt.s, Rv.s));             // the visual stream picks up d(seq_v) written by the heads
+      Rt.heads_bwd(Rv, e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
     } else if (sgi == nseg - 1) {
       Rt.embed_text_bwd(e->st.dy[e->cur_t]);
       Rv.embed_image_bwd(e->sv.dy[e->cur_v]);

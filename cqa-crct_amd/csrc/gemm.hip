@@ -23,6 +23,7 @@
 // cdna_hip_programming.md T10(a) -- no transposed copies of weights or activations exist anywhere in HBM.
 #include <stdlib.h>
 
+#include <string>
 #include <vector>
 #include <utility>
 
@@ -738,294 +739,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tile_m, tile_n, tmap.dbg);
 }
 
-// ====================================================================================== flex
-// Tile-flexible LDS-DMA kernel (round 2).  Block tile (16*BM16) x (16*BN16): any multiple of 16 rows of a K-contiguous
-// operand, of 32 for a transposed one -- so that ONE round of workgroups covers the CRCT shapes (M = 1600 / 2880 rows
-// are not multiples of 128: 160 x 128 tiles give 240 workgroups for the text FFN-up GEMM instead of 2.4 rounds of
-// 128 x 64).  Few, large wave tiles (WM x WN waves, usually 2 x 2 with 80 x 64 / 64 x 64 per wave): one wave per SIMD
-// reads (WTM + WTN) fragments for WTM * WTN MFMAs, so LDS bandwidth is no longer the co-bound it was with 32 x 32 wave
-// tiles (8 x 16-cycle MFMAs against 8 ds_read_b128 per wave and K step, 8 waves sharing one LDS).
-// Main loop, per 64-deep K tile: the fragments of the two 32-deep halves live in two register sets; the reads of the next
-// half are always in flight while the MFMAs of the current one issue.  ONE s_barrier per K tile, placed in front of the
-// LAST half's MFMAs: by then every wave has all of this tile's fragments in registers (lgkmcnt(0)), so the tile's stage
-// goes straight back to the DMA (tile kt + NS), and the first half of tile kt + 1 -- whose DMA was waited for with a
-// counted vmcnt just before the barrier -- is requested before the MFMAs of the last half start.
-template <bool T, int ROWS>
-__device__ __forceinline__ unsigned flex_src_offset(int slot, int r0, int R, long ld) {
-  // slot = 16-byte slot index inside the (padded) operand image; byte offset of its source chunk at k0 = 0
-  if constexpr (!T) {
-    const int r = slot >> 3, ch = (slot & 7) ^ (r & 7);
-    return (r < ROWS && r0 + r < R) ? (unsigned)((((long)(r0 + r)) * ld + ch * 8) * 2) : OOB_OFF;
-  } else {
-    static_assert(ROWS % 32 == 0, "transposed operand tiles are multiples of 32 rows");
-    constexpr int RC = ROWS / 32;
-    const int byte = slot << 4;
-    const int grp = byte / (RC * 512), rem = byte % (RC * 512);
-    const int sub = rem >> 9, rem2 = rem & 511;
-    const int k = grp * 8 + (rem2 >> 6);
-    const int c3 = (rem2 & 63) >> 4;
-    const int ch = sub * 4 + (c3 ^ ((k >> 2) & 3));
-    return (k < BK && r0 + ch * 8 < R) ? (unsigned)(((long)k * ld + r0 + ch * 8) * 2) : OOB_OFF;
-  }
-}
-
-template <int BM16, int BN16, int WM, int WN, bool TA, bool TB, int NS>
-struct FlexGeom {
-  static constexpr int BM = 16 * BM16, BN = 16 * BN16, NW = WM * WN;
-  static constexpr int PA = (BM / 8 + NW - 1) / NW, PB = (BN / 8 + NW - 1) / NW;      // 1-KiB DMA pieces per wave per K tile
-  static constexpr int A_BYTES = PA * NW * 1024, B_BYTES = PB * NW * 1024, STAGE = A_BYTES + B_BYTES;
-  static constexpr int WTM = BM16 / WM, WTN = BN16 / WN;                              // 16 x 16 MFMA tiles per wave
-  static constexpr size_t LDS = (size_t)NS * STAGE;
-  static_assert(BM16 % WM == 0 && BN16 % WN == 0, "wave grid must divide the tile");
-  static_assert(!TA || (BM % 32 == 0 && (WTM == 1 || WTM % 2 == 0)), "transposed A: 32-row granularity per wave");
-  static_assert(!TB || (BN % 32 == 0 && (WTN == 1 || WTN % 2 == 0)), "transposed B: 32-row granularity per wave");
-  static_assert((WN & (WN - 1)) == 0, "row-sum sharing needs a power-of-two wave row");
-  static_assert(LDS <= 160 * 1024, "operand ring exceeds the LDS");
-};
-
-// MFMA with the accumulator pinned in place in the accumulator half of the register file.  Left to the register
-// allocator, the twice-per-iteration accumulate of the pipelined loop came out as a rotating assignment with ~150
-// v_accvgpr_read / _write copies per K tile (ROCm 7.2).  "memory" keeps the hand-written order of MFMAs, LDS reads, waits,
-// barriers and LDS-DMA issues exactly as written.
-__device__ __forceinline__ void mfma_inplace(f4_t& c, const bf8_t& a, const bf8_t& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
-}
-
-template <int BM16, int BN16, int WM, int WN, bool TA, bool TB, int NS>
-__device__ __forceinline__ void gemm_flex_body(const CrctGemmArgs& g, const int tile_m, const int tile_n) {
-  using G = FlexGeom<BM16, BN16, WM, WN, TA, TB, NS>;
-  constexpr int BM = G::BM, BN = G::BN, NW = G::NW, PA = G::PA, PB = G::PB, A_BYTES = G::A_BYTES, STAGE = G::STAGE;
-  constexpr int WTM = G::WTM, WTN = G::WTN, L = PA + PB;
-  constexpr bool RS = TA && TB;                     // row sums (bias gradients) exist for weight-gradient GEMMs only
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)OOB_OFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)OOB_OFF, 0x00020000);
-  unsigned offA[PA], offB[PB];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) offA[i] = flex_src_offset<TA, BM>((i * NW + wave) * 64 + lane, m0, g.M, g.lda);
-#pragma unroll
-  for (int i = 0; i < PB; ++i) offB[i] = flex_src_offset<TB, BN>((i * NW + wave) * 64 + lane, n0, g.N, g.ldb);
-  const int stepA = TA ? (int)(64 * g.lda * 2) : 128;     // bytes per K tile
-  const int stepB = TB ? (int)(64 * g.ldb * 2) : 128;
-
-  f4_t acc[WTN][WTM];
-#pragma unroll
-  for (int a = 0; a < WTN; ++a)
-#pragma unroll
-    for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-  // optional row sums of A' (bias gradient of a weight-gradient GEMM), see gemm_pipe_body
-  const bool do_rs = RS && g.rowsum_out != nullptr && tile_n == 0;
-  f4_t accb[RS ? WTM : 1];
-#pragma unroll
-  for (int b = 0; b < (RS ? WTM : 1); ++b) accb[b] = f4_t{0.f, 0.f, 0.f, 0.f};
-  bf8_t ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-  asm volatile("" : "+v"(ones));      // stays in registers: a re-materialising v_mov right in front of an inline-asm MFMA would be an unpadded hazard
-
-  const int nk = g.K / BK;
-  // One 1-KiB piece of tile kt into stage st: piece p < PA belongs to A', the others to B'.  `live` = false turns the
-  // piece into an out-of-range read (zeros, no memory traffic): tiles beyond K are still "issued" so that every wave
-  // always has the same number of DMAs in flight and the vmcnt waits are constants -- the main loop has no branch.
-  auto issue_piece = [&](int p, int kt, int st, bool live) {
-    char* base = smem + st * STAGE + wave * 1024;
-    if (p < PA)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + p * NW * 1024), 16, (int)(live ? offA[p < PA ? p : 0] : OOB_OFF), kt * stepA, 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + (p - PA) * NW * 1024), 16, (int)(live ? offB[p >= PA ? p - PA : 0] : OOB_OFF), kt * stepB, 0, 0);
-  };
-
-  using FA = FragBase<TA, BM / 32, WTM>;
-  using FB = FragBase<TB, BN / 32, WTN>;
-  FA fbA;
-  FB fbB;
-  fbA.init(0, wm * (BM / WM), lane);
-  fbB.init(A_BYTES, wn * (BN / WN), lane);
-  const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
-  constexpr int NREQ = WTM * (TA ? 2 : 1) + WTN * (TB ? 2 : 1);      // LDS reads of one half (a transposed fragment takes two)
-  constexpr int NWAIT = NREQ <= 15 ? NREQ : 15;
-  constexpr int NMFMA = WTM * WTN;
-  constexpr int DMA_EVERY = NMFMA / L > 0 ? NMFMA / L : 1;           // one DMA piece after every DMA_EVERY-th MFMA
-
-  bf8_t fa0[WTM], fb0[WTN], fa1[WTM], fb1[WTN];
-  uint32_t ca[FA::NB], cb[FB::NB];
-  // the MFMAs of one half
-  auto multiply = [&](bf8_t (&fm)[WTM], bf8_t (&fn)[WTN]) {
-#pragma unroll
-    for (int a = 0; a < WTN; ++a)
-#pragma unroll
-      for (int b = 0; b < WTM; ++b) mfma_inplace(acc[a][b], fn[a], fm[b]);
-  };
-  // ... with the L DMA pieces of tile kt_dma issued in between (a piece costs the issuing wave tens of cycles, during
-  // which the matrix pipe works off the MFMAs already issued)
-  auto multiply_dma = [&](bf8_t (&fm)[WTM], bf8_t (&fn)[WTN], int kt_dma, int st_dma, bool live) {
-#pragma unroll
-    for (int a = 0; a < WTN; ++a)
-#pragma unroll
-      for (int b = 0; b < WTM; ++b) {
-        mfma_inplace(acc[a][b], fn[a], fm[b]);
-        const int idx = a * WTM + b;
-        if (idx % DMA_EVERY == DMA_EVERY - 1 && idx / DMA_EVERY < L) issue_piece(idx / DMA_EVERY, kt_dma, st_dma, live);
-      }
-    if constexpr (NMFMA / DMA_EVERY < L) {
-#pragma unroll
-      for (int p = NMFMA / DMA_EVERY; p < L; ++p) issue_piece(p, kt_dma, st_dma, live);
-    }
-  };
-  auto rowsums = [&](int h, bf8_t (&fm)[WTM]) {      // the WN waves of a wave row take turns (h = half of the K tile)
-    if constexpr (RS) {
-      if (do_rs && (h & (WN - 1)) == wn) {
-        asm volatile("s_nop 1" ::: "memory");
-#pragma unroll
-        for (int b = 0; b < WTM; ++b) mfma_inplace(accb[b], ones, fm[b]);
-      }
-    }
-  };
-
-#pragma unroll
-  for (int t = 0; t < NS; ++t) {
-#pragma unroll
-    for (int p = 0; p < L; ++p) issue_piece(p, t, t, t < nk);
-  }
-  wait_vmcnt<(NS - 1) * L>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  fbA.at(smem_base, ca);
-  fbB.at(smem_base, cb);
-  FA::template read<0>(ca, fa0);
-  FB::template read<0>(cb, fb0);
-  int stg = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    FA::template read<1>(ca, fa1);                 // second half of tile kt
-    FB::template read<1>(cb, fb1);
-    frag_async_wait<NWAIT>();                      // first half is in registers
-    multiply(fa0, fb0);
-    rowsums(0, fa0);
-    frag_async_wait<0>();                          // every fragment of tile kt is in registers: its stage is free
-    const int nstg = stg + 1 == NS ? 0 : stg + 1;
-    wait_vmcnt<(NS - 2) * L>();                    // tile kt + 1 has landed (for this wave; the barrier makes it all waves)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    fbA.at(smem_base + nstg * STAGE, ca);
-    fbB.at(smem_base + nstg * STAGE, cb);
-    FA::template read<0>(ca, fa0);                 // first half of tile kt + 1 (after the last tile: stale bytes, never used)
-    FB::template read<0>(cb, fb0);
-    multiply_dma(fa1, fb1, kt + NS, stg, kt + NS < nk);   // tile kt + NS goes into the stage that tile kt has just left
-    rowsums(1, fa1);
-    stg = nstg;
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the out-of-range tail pieces and the stale reads have drained
-#pragma unroll
-  for (int i = 0; i < WTM; ++i) frag_async_use(fa0[i]);         // ... and their destination registers stay reserved until here
-#pragma unroll
-  for (int i = 0; i < WTN; ++i) frag_async_use(fb0[i]);
-  // MFMA results are read by compiler-generated code from here on: the hardware does not interlock an inline-asm MFMA's
-  // destination against later readers (cdna_hip_programming.md 5.7 item 2)
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-
-  if constexpr (RS) {
-    if (do_rs) {
-      static_assert(!RS || WN * BM * 4 <= NS * STAGE, "row-sum staging");
-      float* rs = reinterpret_cast<float*>(smem);            // [WN][BM]
-      __syncthreads();                                       // every wave is done reading the operand ring
-      if (lane < 16) {
-#pragma unroll
-        for (int b = 0; b < WTM; ++b) rs[wn * BM + wm * (BM / WM) + b * 16 + lane] = accb[b][0];
-      }
-      __syncthreads();
-      for (int i = tid; i < BM; i += NW * 64) {
-        if (m0 + i < g.M) {
-          float v = 0.f;
-#pragma unroll
-          for (int w = 0; w < WN; ++w) v += rs[w * BM + i];  // fixed order: reproducible
-          g.rowsum_out[m0 + i] += v;
-        }
-      }
-    }
-  }
-  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
-}
-
-template <int BM16, int BN16, int WM, int WN, bool TA, bool TB, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_flex_kernel(const CrctGemmArgs g, const TileMap tmap) {
-  int tile_m, tile_n;
-  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
-  gemm_flex_body<BM16, BN16, WM, WN, TA, TB, NS>(g, tile_m, tile_n);
-}
-
-template <class Kern>
-hipError_t flex_lds_attr(Kern kern, size_t lds, bool& attr_set) {
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  return hipSuccess;
-}
-
-// MODES: bit 0 = forward (NT), bit 1 = dgrad (A K-contiguous, B transposed), bit 2 = wgrad (both transposed); only the
-// instantiations a configuration is used for are compiled
-template <int BM16, int BN16, int WM, int WN, int NS, int MODES>
-hipError_t launch_flex(const CrctGemmArgs& g, hipStream_t s) {
-  constexpr int BM = 16 * BM16, BN = 16 * BN16;
-  int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
-  hipError_t e = hipErrorInvalidValue;
-#define CRCT_LAUNCH_FLEX(TA_, TB_)                                                                                         \
-  do {                                                                                                                     \
-    using G = FlexGeom<BM16, BN16, WM, WN, TA_, TB_, NS>;                                                                  \
-    auto kern = gemm_flex_kernel<BM16, BN16, WM, WN, TA_, TB_, NS>;                                                        \
-    static bool attr_set = false;                                                                                          \
-    e = flex_lds_attr(kern, G::LDS, attr_set);                                                                             \
-    if (e != hipSuccess) return e;                                                                                         \
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), G::LDS, s, g, tmap);                                         \
-    e = hipGetLastError();                                                                                                 \
-  } while (0)
-  if constexpr ((MODES & 1) != 0) { if (!g.ta && !g.tb) CRCT_LAUNCH_FLEX(false, false); }
-  if constexpr ((MODES & 2) != 0) { if (!g.ta && g.tb) CRCT_LAUNCH_FLEX(false, true); }
-  if constexpr ((MODES & 4) != 0) { if (g.ta && g.tb) CRCT_LAUNCH_FLEX(true, true); }
-#undef CRCT_LAUNCH_FLEX
-  return e;
-}
-
-// Flex configurations by id (CrctGemmArgs.tile = 32 + id; tools/gemm_lab sweeps them):
-//   id  tile      waves      stages   built for
-//    0  160 x 128  2 x 2      3        fwd, dgrad      (text M = 1600: N = 3072 -> 240 workgroups)
-//    1  160 x  96  2 x 2      3        fwd             (text QKV N = 2304 -> 240)
-//    2   96 x 128  2 x 2      3        fwd, dgrad      (visual M = 2880, N = 1024 -> 240)
-//    3   96 x  64  2 x 2      4        fwd, dgrad      (text N = 768 -> 204)
-//    4  192 x 192  2 x 4      3        fwd             (visual N = 3072 -> 240)
-//    5  128 x 128  2 x 2      3        all             (weight gradients)
-//    6  128 x 128  2 x 4      3        all             (A/B against the 4-wave form)
-//    7  160 x 128  2 x 4      3        fwd, dgrad      (A/B: 8 waves)
-//    8   80 x  64  1 x 4      4        fwd             (text N = 768 -> 240)
-//    9  192 x 128  2 x 2      3        fwd, dgrad      (visual N = 1024 -> 120; N = 3072 -> 360)
-//   10  160 x  64  2 x 2      4        fwd, dgrad      (text N = 768 -> 120)
-constexpr int FLEX_BASE = 32, FLEX_COUNT = 11;
-hipError_t launch_flex_id(int id, const CrctGemmArgs& g, hipStream_t s) {
-  switch (id) {
-    case 0: return launch_flex<10, 8, 2, 2, 3, 3>(g, s);
-    case 1: return launch_flex<10, 6, 2, 2, 3, 1>(g, s);
-    case 2: return launch_flex<6, 8, 2, 2, 3, 3>(g, s);
-    case 3: return launch_flex<6, 4, 2, 2, 4, 3>(g, s);
-    case 4: return launch_flex<12, 12, 2, 4, 3, 1>(g, s);
-    case 5: return launch_flex<8, 8, 2, 2, 3, 7>(g, s);
-    case 6: return launch_flex<8, 8, 2, 4, 3, 7>(g, s);
-    case 7: return launch_flex<10, 8, 2, 4, 3, 3>(g, s);
-    case 8: return launch_flex<5, 4, 1, 4, 4, 1>(g, s);
-    case 9: return launch_flex<12, 8, 2, 2, 3, 3>(g, s);
-    case 10: return launch_flex<10, 4, 2, 2, 4, 3>(g, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
 // ---- grouped launch: up to 8 independent GEMMs of the same mode in ONE grid (the weight gradients of one
 // layer: 4-6 small problems that individually leave most CUs idle).  Block -> (problem, tile) by prefix table.
 constexpr int GROUP_MAX = 8;
@@ -1158,24 +871,52 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 //   12: 128x64, 8 waves (4x2), 2 stages    15: the same with 3 stages (narrow output, long K)    3: 64x64, 4 waves, 4 stages
 //   grouped weight gradients: 4 = 128x128, 8 waves (2x4), 3 stages
 static int env_cfg(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
+// Shape classes of the step's forward / data-gradient GEMMs and the configuration each one runs with (ids of the switch in
+// crct_gemm_launch).  CRCT_GEMM_CLS="tw=9,vm=15,..." overrides single classes for A/B runs of the whole step (developer
+// knob: every id computes the same result).
+//   tw   text rows (M <= 2000), wide output (N >= 2304)          FFN-up / QKV forward, FFN-down data gradient
+//   tn   text rows, narrow output (N <= 1024), K <= 1024          attention-output / dense2 forward and data gradient
+//   tnl  text rows, narrow output, long K (> 1024)                FFN-down forward, FFN-up / QKV data gradient
+//   vw   visual rows (M > 2000), wide output                      visual / co-attention QKV forward
+//   vm   visual rows, N <= 1024, K <= 1024                        visual projections and FFN, both directions
+//   vml  visual rows, N <= 1024, long K                           QKV data gradient, image-embedding forward
+// Round 2 tried a tile-flexible variant of the LDS-DMA kernel (160 x 128, 96 x 64, 192 x 192 ... tiles that cover M = 1600 /
+// 2880 in ONE round of workgroups, 4 or 8 waves, 3-4 stages, in-place inline-asm MFMAs, half-tile register double buffering;
+// commit 11e1801).  Stand-alone with cold weights it won 10-17 % on several shapes (profiles/r2_gemm_lab_cold.txt), in the
+// step EVERY class lost 0.1-0.4 ms (profiles/r2_gemm_flex_step_ab.txt): its 108-160 KB of LDS allow one workgroup per CU,
+// so the kernels of the other internal streams can no longer share the CUs.  The 48-72 KB configurations below stay.
+enum { CLS_TW, CLS_TN, CLS_TNL, CLS_VW, CLS_VM, CLS_VML, CLS_COUNT };
+static const int* class_table() {
+  static int tab[CLS_COUNT] = {12, 12, 15, 12, 12, 15};
+  static bool init = false;
+  if (!init) {
+    init = true;
+    const char* names[CLS_COUNT] = {"tw", "tn", "tnl", "vw", "vm", "vml"};
+    if (const char* e = getenv("CRCT_GEMM_CLS")) {
+      std::string str(e);
+      for (int c = 0; c < CLS_COUNT; ++c) {
+        const std::string key = std::string(names[c]) + "=";
+        size_t pos = 0;
+        while ((pos = str.find(key, pos)) != std::string::npos) {
+          if (pos == 0 || str[pos - 1] == ',') { tab[c] = atoi(str.c_str() + pos + key.size()); break; }
+          pos += key.size();
+        }
+      }
+    }
+  }
+  return tab;
+}
 static int pick_pipe_config(const CrctGemmArgs& g) {
-  // developer overrides for A/B runs of the whole step: CRCT_GEMM_FWD / _DGRAD / _WGRAD = configuration id
-  static const int ov_f = env_cfg("CRCT_GEMM_FWD"), ov_d = env_cfg("CRCT_GEMM_DGRAD"), ov_w = env_cfg("CRCT_GEMM_WGRAD");
   if (g.M <= 96) return 3;                                          // head / regressor GEMMs: B rows
-  if (g.ta) {                                                       // wgrad
+  if (g.ta) {                                                       // single weight gradient (grouped ones: crct_gemm_launch_grouped)
+    static const int ov_w = env_cfg("CRCT_GEMM_WGRAD");
     if (ov_w >= 0) return ov_w;
     return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 9;
   }
-  if (g.tb) {
-    if (ov_d >= 0) return ov_d;
-    static const int ov_dl = env_cfg("CRCT_GEMM_DGRAD_LONGK");
-    if (g.N <= 1024 && g.K >= 2048) return ov_dl >= 0 ? ov_dl : 15;  // narrow output, long K
-    return 12;
-  }
-  if (ov_f >= 0) return ov_f;
-  static const int ov_fl = env_cfg("CRCT_GEMM_FWD_LONGK");
-  if (g.N <= 1024 && g.K >= 2048) return ov_fl >= 0 ? ov_fl : 15;   // narrow output, long K
-  return 12;
+  const bool text = g.M <= 2000, wide = g.N >= 2304, longk = g.K > 1024;
+  const int cls = text ? (wide ? CLS_TW : (longk ? CLS_TNL : CLS_TN)) : (wide ? CLS_VW : (longk ? CLS_VML : CLS_VM));
+  const int t = class_table()[cls];
+  return (t < 0 || t > 15) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
 }
 
 // ---- optional live profiling: HIP events around every GEMM launch, on the launch stream ----------
@@ -1186,7 +927,7 @@ struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
-  static constexpr int NV = 3 * 64;    // configuration ids 0..15 LDS-DMA (round 1), 16..19 register-staged, 32.. flex; x {fwd, dgrad, wgrad}
+  static constexpr int NV = 72;        // (16 LDS-DMA configurations + 4 register-staged + spare) x {fwd, dgrad, wgrad}
   double flops[NV] = {0}; long count[NV] = {0};
 } g_prof;
 }  // namespace
@@ -1225,8 +966,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   const bool pipe = pipe_ok(g) && !g_force_generic;
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  const bool flex = pipe && t >= FLEX_BASE && t < FLEX_BASE + FLEX_COUNT;
-  if (t > 15 && !flex) t = 12;
+  if (t > 15) t = 12;
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
   ProfSlot* slot = nullptr;
@@ -1243,9 +983,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
     if (hipEventRecord(slot->a, s) != hipSuccess) return hipErrorUnknown;
   }
   hipError_t e;
-  if (flex) {
-    e = launch_flex_id(t - FLEX_BASE, g, s);
-  } else if (pipe) {
+  if (pipe) {
     switch (t) {
       case 0: e = launch_pipe<4, 4, 2, 2, 3>(g, s); break;
       case 1: e = launch_pipe<4, 2, 2, 2, 4>(g, s); break;
