@@ -1,23 +1,31 @@
 """bench.py -- QA-pairs/sec of the CRCT co-attention training step on MI355X.
 
-One "step" = forward + joint CE/L1 loss + backward (+ RCCL gradient all-reduce, overlapped, when
-N > 1) + fused AdamW + LR-schedule step, on one batch of synthetic PlotQA-shaped inputs that is already
-resident in HBM (a pool of 8 pre-staged batches is rotated), dropout ENABLED (p = 0.1), config
-``config/vilbert.json`` with ``v_feature_size = 2048`` (BASELINE.json configs[1]).
+One "step" = forward + joint CE/L1 loss + backward (+ RCCL gradient all-reduce, overlapped, and the 9-float stats
+all-reduce of train.py:181-189 when N > 1) + fused AdamW + LR-schedule step, on one batch of synthetic PlotQA-shaped
+inputs, dropout ENABLED (p = 0.1), config ``config/vilbert.json`` with ``v_feature_size = 2048`` (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (metric contract in the task statement), carrying
-  roofline     : the GEMM variant with the largest share of step time; achieved = algorithmic FLOPs per
-                 launch / average launch duration, measured with HIP events on the launch stream
-                 over extra profiled steps in this process; peak = 2.5 PFLOP/s dense bf16 MFMA.
-  cpu_baseline : the CPU oracle (fp32 PyTorch restatement, ``kind: port``) doing forward+backward of the
-                 same batch shape on this node's host cores (rank 0, N = 1 only, bounded sample).
+Prints ONE JSON line on rank 0:
+  value        : whole-job QA-pairs/s with the batches already resident in HBM when the timed region starts (a pool of 8
+                 pre-staged batches is rotated).
+  config.h2d_inclusive : the same step fed from PAGEABLE HOST batches through crct.input_pipeline.DevicePrefetcher (one
+                 pinned staging buffer and ONE async copy per batch on a copy stream, double-buffered; features shipped
+                 as bf16 unless --host-feat fp32), measured in the same run -- the PCIe-inclusive rate.
+  roofline     : the GEMM variant with the largest share of step time; achieved = algorithmic FLOPs per launch / average
+                 kernel duration measured live: during --profile-steps extra steps every GEMM kernel is dispatched with a
+                 start / stop event pair (hipExtLaunchKernelGGL), i.e. the begin / end stamps of the kernel itself -- the
+                 quantity ``rocprofv3 --kernel-trace --stats`` averages (profiles/r2_rocprof_kernel_stats_bench.csv);
+                 peak = 2.5 PFLOP/s dense bf16 MFMA.  traffic = fabric-side bytes per launch from the committed PMC passes
+                 (profiles/r2_pmc_traffic.json), used only while the kernel sources still hash to what was measured.
+  cpu_baseline : the CPU oracle (fp32 PyTorch restatement, ``kind: port``) doing forward+backward of the same batch
+                 shape on this node's host cores (rank 0, N = 1 only, bounded sample).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -42,6 +50,7 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x128w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
               10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 15: "dma128x64w8s3", 16: "reg128x128", 17: "reg128x64",
               18: "reg64x128", 19: "reg64x64"}
+KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
 def parse():
@@ -58,9 +67,11 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--input", choices=("resident", "prefetch", "sync"), default="resident",
-                    help="resident: batches already in HBM (the headline metric); prefetch: pageable host batches through "
-                         "crct.input_pipeline.DevicePrefetcher; sync: pageable host batches moved by the step adapter's "
-                         "synchronous .to(device), as the reference does (PCIe-inclusive rates for DESIGN.md)")
+                    help="what `value` is measured on.  resident: batches already in HBM (the contract's headline); prefetch: pageable "
+                         "host batches through crct.input_pipeline.DevicePrefetcher; sync: pageable host batches moved by the step "
+                         "adapter's synchronous .to(device), as the reference does")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the PCIe-inclusive leg (config.h2d_inclusive)")
+    ap.add_argument("--host-feat", choices=("bf16", "fp32"), default="bf16", help="dtype of image_feat in the host batches of the prefetch legs")
     ap.add_argument("--fuse-zero-grad", action="store_true", help="AdamW zeroes the gradients it consumes (measured: no gain)")
     ap.add_argument("--eager-zero-grad", action="store_true", help="zero_grad() fills the whole gradient buffer and backward "
                     "accumulates into it (default: lazy clear + overwritten weight gradients, same results, -0.3 ms per step)")
@@ -74,8 +85,8 @@ def stage(batch, dev):
     return {k: v.to(dev) for k, v in batch.items()}
 
 
-def gemm_profile(model, run_step, n_steps):
-    """HIP-event timing of every GEMM launch over `n_steps` extra steps (same process, same stream)."""
+def gemm_profile(run_step, n_steps):
+    """Begin / end stamps of every GEMM kernel over `n_steps` extra steps (same process, every internal stream)."""
     lib = L.load()
     lib.crct_prof_reset()
     lib.crct_prof_enable(1)
@@ -95,10 +106,19 @@ def gemm_profile(model, run_step, n_steps):
     return rows
 
 
+def source_hash():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_label):
     """Fabric-side bytes per launch of a GEMM variant from the committed PMC passes of this same command
-    (profiles/r*_pmc_traffic.json, made by tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
-    FETCH_SIZE doubled per MI355X_MICROARCH.md); None when no such measurement is on disk."""
+    (profiles/r*_pmc_traffic.json, made by tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md).  A table is used only if it is stamped with the hash of the kernel sources as they are
+    now (``source_hash``): a measurement of other code is not reported.  None otherwise."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
@@ -107,11 +127,24 @@ def pmc_traffic(kernel_label):
                 table = json.load(f)
         except (OSError, ValueError):
             continue
-        cand = [v for v in table.values() if v.get("bench_label") == kernel_label]
+        if table.get("_source_hash", {}).get("value") != source_hash():
+            continue
+        cand = [v for k, v in table.items() if not k.startswith("_") and v.get("bench_label") == kernel_label]
         if cand:
             tot = sum(v["launches"] for v in cand)
             best = sum(v["bytes_per_launch"] * v["launches"] for v in cand) / max(tot, 1)
     return best
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
@@ -138,8 +171,8 @@ def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
         reps += 1
     return dict(value=Bs * reps / dt, unit="QA-pairs/s", cores=threads, kind="port",
                 sample="%d x forward+backward of the fp32 CPU oracle (oracle/crct_oracle.py) at B=%d (sized from a B=4 probe of %.2f s "
-                       "for a ~%.0f s budget), V=%d, T=%d, F_v=%d, dropout on; %.1f s in total on %d threads (of %d cores)"
-                       % (reps, Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1))
+                       "for a ~%.0f s budget), V=%d, T=%d, F_v=%d, dropout on; %.1f s in total on %d threads of %d logical cores (%s)"
+                       % (reps, Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1, cpu_model()))
 
 
 def main():
@@ -147,6 +180,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        raise SystemExit("bench.py --gpus %d must equal WORLD_SIZE=%d (launch N > 1 with torch.distributed.run, one rank per GPU)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
     if os.environ.get("CRCT_BENCH_SHARE_GPU"):       # developer check of the N > 1 code path on a 1-GPU box (gloo, every rank on cuda:0)
@@ -163,7 +198,8 @@ def main():
     from crct.model import VisualDialogEncoder
     from crct.optim import get_optimizer, WarmupLinearScheduleNonZero
     from crct.step_adapter import forward as step_forward
-    from crct.ddp import FlatGradDDP
+    from crct.ddp import FlatGradDDP, all_reduce_stats
+    from crct.input_pipeline import DevicePrefetcher
 
     cfg = CFG.vilbert_config(v_feature_size=a.feat)
     params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0)
@@ -180,24 +216,36 @@ def main():
     if a.opt_early and opt.overlap:
         opt.set_early(True)                          # ... or start per segment as soon as backward has finished it
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
-    ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb) if world > 1 else None
+    ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb) if world > 1 else None   # noqa: F841 -- attaches itself to the model
     host_pool = [S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i) for i in range(8)]
-    pool = [stage(b, dev) for b in host_pool] if a.input == "resident" else host_pool
-    it = [0]
-    feed = None
-    if a.input == "prefetch":
-        from crct.input_pipeline import DevicePrefetcher
+    dev_pool = [stage(b, dev) for b in host_pool]
+    host_feed = host_pool
+    if a.host_feat == "bf16":                        # the data loader ships bf16 features: half the H2D bytes of the step
+        host_feed = [dict(b, image_feat=b["image_feat"].to(torch.bfloat16)) for b in host_pool]
 
-        def forever():
-            while True:
-                for b in host_pool:
-                    yield b
-        feed = iter(DevicePrefetcher(forever(), dev, depth=2))
+    def forever(pool):
+        while True:
+            for b in pool:
+                yield b
+
+    feeds = {"resident": forever(dev_pool), "sync": forever(host_pool)}
+    prefetcher = None
+
+    def feed_of(kind):
+        nonlocal prefetcher
+        if kind == "prefetch":
+            if prefetcher is None:
+                prefetcher = iter(DevicePrefetcher(forever(host_feed), dev, depth=2))
+            return prefetcher
+        return feeds[kind]
+
+    cur = {"feed": feed_of(a.input)}
 
     def run_step():
-        batch = next(feed) if feed is not None else pool[it[0] % len(pool)]
-        it[0] += 1
+        batch = next(cur["feed"])
         loss = step_forward(model, batch, params)[0]
+        if world > 1:
+            all_reduce_stats(core.last_stats[8:17], world)       # the reference's per-iteration stats exchange (train.py:181-189)
         loss.backward()
         opt.step()
         opt.zero_grad()
@@ -210,19 +258,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = run_step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        return dt, loss
+
     for _ in range(a.warmup):
         run_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = run_step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    dt, loss = timed(a.steps)
     final_loss = float(loss.detach())
+    qa_per_s = a.batch * world * a.steps / dt
+
+    h2d = None
+    if a.input == "resident" and not a.no_h2d_leg:
+        cur["feed"] = feed_of("prefetch")
+        for _ in range(max(3, a.warmup // 2)):
+            run_step()
+        dt2, _ = timed(a.steps)
+        feat_bytes = 2 if a.host_feat == "bf16" else 4
+        h2d = {"input": "pageable host batches -> DevicePrefetcher (pinned staging, one async copy per batch on a copy stream, 2 slots), "
+                        "image_feat shipped as %s" % a.host_feat,
+               "ms_per_step": dt2 / a.steps * 1e3, "qa_pairs_per_s": a.batch * world * a.steps / dt2,
+               "bytes_per_step_per_gpu": int(sum(v.numel() * (feat_bytes if k == "image_feat" else v.element_size())
+                                                 for k, v in host_pool[0].items()))}
+        cur["feed"] = feed_of("resident")
+
     comm = None
     if world > 1:
         # evidence for the data-parallel exchange: the flat gradient buffer all-reduced on its own, after the
@@ -239,19 +307,18 @@ def main():
         ar = (time.perf_counter() - t1) / 5
         comm = {"allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
                 "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9}
-    qa_per_s = a.batch * world * a.steps / dt
 
-    out = None
+    # profiled steps run on EVERY rank (they contain the collectives of a normal step); only rank 0 reads the stamps
+    rows = gemm_profile(run_step, a.profile_steps) if a.profile_steps > 0 else []
     if rank == 0:
-        rows = gemm_profile(model, run_step, a.profile_steps) if a.profile_steps > 0 else []
         flop_qa = FLOP_PER_QA.get((a.vis, a.tokens, a.feat))
         out = {"metric": "QA-pairs/sec training step (whole node)", "value": qa_per_s, "unit": "QA-pairs/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss" % (a.feat, a.batch, a.vis, a.feat, a.tokens),
-                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input, "gradient_allreduce": comm,
-                          "gemm_variants": rows}}
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input,
+                          "h2d_inclusive": h2d, "gradient_allreduce": comm, "gemm_variants": rows}}
         if flop_qa:
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
         if rows:
@@ -259,7 +326,8 @@ def main():
             traffic = pmc_traffic(dom["kernel"]) if (a.batch, a.vis, a.tokens, a.feat) == (80, 36, 20, 2048) else None
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
-                               "gflop_per_launch": dom["gflop_per_launch"], "us_per_launch": dom["us_per_launch"]}
+                               "gflop_per_launch": dom["gflop_per_launch"], "us_per_launch": dom["us_per_launch"],
+                               "timing": "kernel begin / end stamps (hipExtLaunchKernelGGL start / stop events), %d profiled steps" % a.profile_steps}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(core, cfg, params, a.cpu_batch, a.tokens, a.vis, a.feat)
         print(json.dumps(out), flush=True)

@@ -82,6 +82,7 @@ class StepEngine(object):
         if t.get("sep_indices") is not None:
             b.sep_indices, b.hist_len, b.sep_stride = L.ptr(t["sep_indices"]), L.ptr(t["hist_len"]), t["sep_indices"].shape[1]
         b.image_mask = L.ptr(t.get("image_mask"))
+        b.image_feat_bf16 = int(t["image_feat"].dtype == torch.bfloat16)
         b.R, b.labels = L.ptr(t["R"]), L.ptr(t.get("labels"))
         b.B, b.T, b.V = t["tokens"].shape[0], t["tokens"].shape[1], t["image_feat"].shape[1]
         return b

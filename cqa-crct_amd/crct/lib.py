@@ -43,7 +43,7 @@ class Batch(C.Structure):
     _fields_ = [("tokens", vp), ("segments", vp), ("loc", vp), ("text_keymask", vp), ("image_feat", vp), ("image_loc", vp),
                 ("image_target", vp), ("image_keymask", vp), ("R", vp), ("labels", vp),
                 ("B", c_i32), ("T", c_i32), ("V", c_i32),
-                ("sep_indices", vp), ("hist_len", vp), ("image_mask", vp), ("sep_stride", c_i32)]
+                ("sep_indices", vp), ("hist_len", vp), ("image_mask", vp), ("sep_stride", c_i32), ("image_feat_bf16", c_i32)]
 
 
 class AmpState(C.Structure):
@@ -77,6 +77,7 @@ PROTOTYPES = {
     "crct_colsum_bf16": (C.c_int, [vp, c_i64, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "crct_build_keymasks": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "crct_softmax_rows_bf16_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),

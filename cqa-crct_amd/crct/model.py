@@ -357,7 +357,8 @@ class CrctModel(nn.Module):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         t = dict(tokens=to(input_ids, torch.int64), segments=to(token_type_ids, torch.int64), loc=to(txt_loc, torch.float32),
-                 image_feat=to(image_feat, torch.float32), image_loc=to(image_loc, torch.float32),
+                 image_feat=to(image_feat, torch.bfloat16 if image_feat.dtype == torch.bfloat16 else torch.float32),   # bf16 features are taken as shipped
+                 image_loc=to(image_loc, torch.float32),
                  image_target=to(image_target, torch.int64), R=to(R, torch.float32))
         # key masks: the engine builds them from sep_indices / hist_len (SequenceMask) and the integer image mask; any other
         # mask tensor is reduced to uint8 here

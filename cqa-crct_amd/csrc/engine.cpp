@@ -494,7 +494,8 @@ struct Run {
     const CrctModelDims& D = e->d;
     const int Mv = b->B * b->V;
     const Drop dv = drop(D.p_hidden, 2);       // also the TEXT probability (vilbert.py:1470)
-    if (!rc) fail(crct_softmax_rows_f32_bf16(b->image_feat, A(e->eva.soft), Mv, D.Fv, s));
+    if (!rc) fail(b->image_feat_bf16 ? crct_softmax_rows_bf16_bf16(b->image_feat, A(e->eva.soft), Mv, D.Fv, s)
+                                     : crct_softmax_rows_f32_bf16((const float*)b->image_feat, A(e->eva.soft), Mv, D.Fv, s));
     lin_fwd(A(e->eva.soft), D.Fv, e->ev.img, Mv, A(e->eva.lin), D.Hv, Opt());
     if (!rc) fail(crct_embed_image_fwd(A(e->eva.lin), b->image_loc, b->image_target, P(e->ev.wloc), P(e->ev.bloc), P(e->ev.color),
                                        P(e->ev.ln.g), P(e->ev.ln.b), A(e->eva.sum), A(e->eva.y), F(e->eva.mean), F(e->eva.rstd),

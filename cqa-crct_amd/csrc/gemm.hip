@@ -23,6 +23,9 @@
 // cdna_hip_programming.md T10(a) -- no transposed copies of weights or activations exist anywhere in HBM.
 #include <stdlib.h>
 
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
 #include <string>
 #include <vector>
 #include <utility>
@@ -31,6 +34,16 @@
 #include "crct_internal.h"
 
 namespace {
+
+// Live measurement (crct_prof_*): while a timing slot is armed the GEMM kernels are dispatched through hipExtLaunchKernelGGL
+// with a start / stop event pair, which stamps the begin and the end of THAT kernel (what rocprofv3 --kernel-trace reports)
+// instead of bracketing the launch with two extra event-record packets on the stream.
+thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+template <class K, class... A>
+inline void launch_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... a) {
+  if (g_time_start) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, g_time_start, g_time_stop, 0u, a...);
+  else hipLaunchKernelGGL(kern, grid, block, lds, s, a...);
+}
 
 constexpr int BK = 64;
 #ifndef CRCT_GEMM_NT_F32
@@ -793,7 +806,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL(kern, dim3(total), dim3(WM * WN * 64), lds, s, ga);                                                 \
+    launch_kernel(kern, dim3(total), dim3(WM * WN * 64), lds, s, ga);                                                 \
   } while (0)
   if (gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(true, true);
   else if (!gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(false, true);
@@ -819,7 +832,7 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                            \
+    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                            \
   } while (0)
   if (!g.ta && !g.tb) CRCT_LAUNCH_PIPE(false, false);
   else if (!g.ta && g.tb) CRCT_LAUNCH_PIPE(false, true);
@@ -846,9 +859,9 @@ hipError_t launch_cfg(const CrctGemmArgs& g, hipStream_t s) {
   int tiles = 0;
   const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)(BM + BN) * BK * 2;
-  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(tiles), dim3(256), lds, s, g, tmap);
-  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(tiles), dim3(256), lds, s, g, tmap);
-  else if (g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(tiles), dim3(256), lds, s, g, tmap);
+  if (!g.ta && !g.tb) launch_kernel(gemm_kernel<TM, TN, false, false>, dim3(tiles), dim3(256), lds, s, g, tmap);
+  else if (!g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, false, true>, dim3(tiles), dim3(256), lds, s, g, tmap);
+  else if (g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, true, true>, dim3(tiles), dim3(256), lds, s, g, tmap);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -980,7 +993,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
     slot->variant = (pipe ? t : 16 + (t & 3)) * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
     g_prof.count[slot->variant] += 1;
     g_prof.flops[slot->variant] += 2.0 * g.M * g.N * g.K;
-    if (hipEventRecord(slot->a, s) != hipSuccess) return hipErrorUnknown;
+    g_time_start = slot->a; g_time_stop = slot->b;
   }
   hipError_t e;
   if (pipe) {
@@ -1010,7 +1023,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
       default: e = launch_cfg<2, 2>(g, s); break;
     }
   }
-  if (slot && hipEventRecord(slot->b, s) != hipSuccess) return hipErrorUnknown;
+  g_time_start = g_time_stop = nullptr;
   return e;
 }
 
@@ -1042,10 +1055,10 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
     slot->variant = (cfg == 12 || cfg == 9 ? cfg : 4) * 3 + (gs[0].ta ? 2 : (gs[0].tb ? 1 : 0));
     g_prof.count[slot->variant] += 1;
     for (int i = 0; i < n; ++i) g_prof.flops[slot->variant] += 2.0 * gs[i].M * gs[i].N * gs[i].K;
-    (void)hipEventRecord(slot->a, s);
+    g_time_start = slot->a; g_time_stop = slot->b;
   }
   const hipError_t e = cfg == 12 ? launch_group<4, 2, 4, 2, 2>(gs, n, s)
                        : cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s);
-  if (slot) (void)hipEventRecord(slot->b, s);
+  g_time_start = g_time_stop = nullptr;
   return e;
 }

@@ -512,25 +512,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   *reinterpret_cast<float4*>(partials + (long)blockIdx.y * N + c) = o;
 }
 
-// ------------------------------------------------------------------------------ row softmax f32 -> bf16
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int M, int F) {
+// ------------------------------------------------------------------------------ row softmax f32 | bf16 -> bf16
+// IN_BF16: the features crossed PCIe as bf16 (half the bytes of the step's only large host -> device copy)
+template <bool IN_BF16>
+__device__ __forceinline__ float4 softmax_load4(const void* xr, int c) {
+  if constexpr (!IN_BF16) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xr) + c);
+  else {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(xr) + c);
+    return make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+  }
+}
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const void* __restrict__ x, bf16_t* __restrict__ y, int M, int F) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const float* xr = x + row * F;
+    const void* xr = IN_BF16 ? (const void*)(reinterpret_cast<const bf16_t*>(x) + row * F) : (const void*)(reinterpret_cast<const float*>(x) + row * F);
     float mx = -INFINITY;
     for (int c = lane * 4; c < F; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      const float4 v = softmax_load4<IN_BF16>(xr, c);
       mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }
     mx = wave_max(mx);
     float s = 0.f;
     for (int c = lane * 4; c < F; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      const float4 v = softmax_load4<IN_BF16>(xr, c);
       s += expf(v.x - mx) + expf(v.y - mx) + expf(v.z - mx) + expf(v.w - mx);
     }
     const float inv = 1.0f / wave_sum(s);
     for (int c = lane * 4; c < F; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      const float4 v = softmax_load4<IN_BF16>(xr, c);
       uint2 o = make_uint2(pack2bf(expf(v.x - mx) * inv, expf(v.y - mx) * inv), pack2bf(expf(v.z - mx) * inv, expf(v.w - mx) * inv));
       *reinterpret_cast<uint2*>(y + row * F + c) = o;
     }
@@ -851,7 +861,15 @@ int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int
 int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_stream_t stream) {
   CRCT_REQUIRE(F % 4 == 0, "softmax_rows: F=%d must be a multiple of 4", F);
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, M, F);
+  hipLaunchKernelGGL(softmax_rows_kernel<false>, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, (const void*)x, (bf16_t*)y, M, F);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_stream_t stream) {
+  CRCT_REQUIRE(F % 4 == 0, "softmax_rows: F=%d must be a multiple of 4", F);
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, M, F);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -131,6 +131,8 @@ int crct_build_keymasks(const int64_t* sep_indices, const int64_t* hist_len, int
 
 /* Row softmax fp32 [M][F] -> bf16 [M][F]  (F.softmax(image_feat), vilbert.py:1476). */
 int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_stream_t stream);
+/* The same from bf16 features (a data loader / input pipeline that ships bf16 halves the step's host -> device bytes). */
+int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_stream_t stream);
 
 /* fp32 -> bf16 copy (weight shadow refresh). */
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
@@ -313,7 +315,8 @@ int crct_engine_segment_range(const crct_engine_t*, int seg, int64_t* lo, int64_
 
 typedef struct CrctBatch {
   const int64_t* tokens; const int64_t* segments; const float* loc; const uint8_t* text_keymask;
-  const float* image_feat; const float* image_loc; const int64_t* image_target; const uint8_t* image_keymask;
+  const void* image_feat;    /* fp32 [B][V][Fv], or bf16 when image_feat_bf16 is set */
+  const float* image_loc; const int64_t* image_target; const uint8_t* image_keymask;
   const float* R; const int64_t* labels;   /* labels NULL => evaluation */
   int32_t B, T, V;
   /* When text_keymask / image_keymask is NULL the engine builds it in its workspace (one launch, crct_build_keymasks) from
@@ -321,6 +324,7 @@ typedef struct CrctBatch {
    * t < sep_indices[b][hist_len[b]] + 1, encoder_decorator.py:118-120) / image_mask int64 [B][V] (attended iff != 0). */
   const int64_t* sep_indices; const int64_t* hist_len; const int64_t* image_mask;
   int32_t sep_stride;
+  int32_t image_feat_bf16;                 /* != 0: image_feat points at bf16 [B][V][Fv] instead of fp32 */
 } CrctBatch;
 
 typedef struct CrctStepCfg {

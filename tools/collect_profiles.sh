@@ -1,10 +1,10 @@
 # End-of-round evidence, collected on the GPU box in one call:  bash tools/collect_profiles.sh <tag>
 # writes gpurun_out/<tag>_*; the PMC table is also put under profiles/ of the box's copy so that the bench line that
 # follows reads its roofline.traffic from the same build.
-tag=${1:-r1}
+tag=${1:-r2}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --profile-steps 0"
+BENCH="python3 $R/bench.py --no-cpu-baseline --profile-steps 0 --no-h2d-leg"
 rm -rf /tmp/pf /tmp/pw /tmp/ks
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- $BENCH --steps 3 --warmup 2 > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- $BENCH --steps 3 --warmup 2 > /tmp/pw.log 2>&1
@@ -16,6 +16,5 @@ cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/${tag}_rocprof_kernel_
 python $R/tools/trace_timeline.py $(find /tmp/ks -name "*kernel_trace.csv" | head -1) > $O/${tag}_step_timeline.txt 2>&1
 cd $R
 python tools/step_phases.py > $O/${tag}_step_phases.txt 2>&1
-./tools/gemm_lab.bin 50 > $O/${tag}_gemm_lab.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench_n1.err
 tail -c 1500 $O/${tag}_bench_n1.json
