@@ -95,6 +95,10 @@ class StepEngine(object):
         c.wgrad_overwrite = int(bool(step.get("wgrad_overwrite", False)))
         c.seed = int(step["seed"])
         c.g_nsp_dev, c.g_reg_dev, c.g_loss_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg")), L.ptr(step.get("g_loss"))
+        f8 = step.get("fp8")
+        if f8 is not None:          # (flat e4m3 weight shadow, weight scales, activation scales, activation amax): device tensors
+            c.fp8 = 1
+            c.params_fp8, c.fp8_w_scale, c.fp8_act_scale, c.fp8_act_amax = (L.ptr(t) for t in f8)
         evs = step.get("seg_events")
         if evs is not None:
             arr = (C.c_void_p * len(evs))(*[ev.cuda_event for ev in evs])
@@ -106,6 +110,14 @@ class StepEngine(object):
             step["_seg_done_keepalive"] = arr
             c.seg_done_events = C.cast(arr, C.c_void_p)
         return c
+
+    def fp8_layout(self):
+        """(number of activation scale sites, [(flat offset, numel)] of the weights with an e4m3 shadow; index = scale slot)."""
+        n = self.lib.crct_engine_fp8_weights(self.handle, None, None, 0)
+        off, num = (C.c_int64 * max(n, 1))(), (C.c_int64 * max(n, 1))()
+        if n > 0:
+            assert self.lib.crct_engine_fp8_weights(self.handle, off, num, n) == n
+        return self.lib.crct_engine_fp8_sites(self.handle), list(zip(off[:n], num[:n]))
 
     def wgrad_owned(self):
         """(offsets, numels) of the weight gradients the engine overwrites under CrctStepCfg.wgrad_overwrite: fixed by the

@@ -18,7 +18,8 @@ class GemmArgs(C.Structure):
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ld_aux", c_i64), ("ld_add", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ta", c_i32), ("tb", c_i32), ("act", c_i32), ("dact", c_i32),
                 ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
-                ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp)]
+                ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp),
+                ("fp8", c_i32), ("scale_a", vp), ("scale_b", vp), ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("ld_q", c_i64)]
 
 
 class HeadArgs(C.Structure):
@@ -50,10 +51,16 @@ class AmpState(C.Structure):
     _fields_ = [("grad_scale", vp), ("found_inf", vp), ("step", vp)]
 
 
+class Fp8Shadow(C.Structure):
+    _fields_ = [("q", vp), ("seg_slot", vp), ("scale", vp), ("amax", vp)]
+
+
 class StepCfg(C.Structure):
     _fields_ = [("training", c_i32), ("use_l1", c_i32), ("kind_l1", c_i32), ("tol_margin", c_f32), ("nsp_coeff", c_f32),
                 ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("g_loss_dev", vp),
-                ("seg_ready_events", vp), ("seg_done_events", vp), ("wgrad_overwrite", c_i32)]
+                ("seg_ready_events", vp), ("seg_done_events", vp),
+                ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
+                ("wgrad_overwrite", c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/crct_hip.h declares
@@ -78,6 +85,10 @@ PROTOTYPES = {
     "crct_build_keymasks": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_bf16_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "crct_layernorm_fwd_q": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp, vp, vp, vp]),
+    "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
+    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, vp]),
+    "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
@@ -89,7 +100,7 @@ PROTOTYPES = {
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
     "crct_eval_select": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, vp, vp, vp, vp, vp, vp]),
     "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
-    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
     "crct_adamw_advance": (C.c_int, [vp, vp, vp]),
     "crct_engine_create": (vp, [C.POINTER(ModelDims), C.c_char_p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crct_engine_destroy": (None, [vp]),
@@ -100,6 +111,8 @@ PROTOTYPES = {
     "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
     "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
+    "crct_engine_fp8_sites": (C.c_int, [vp]),
+    "crct_engine_fp8_weights": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_zero_runs": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp]),
     "crct_engine_tap": (c_i64, [vp, vp, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),
 }

@@ -99,6 +99,9 @@ class CrctModel(nn.Module):
         self._shadow_ver = -1
         self._rebound = None
         self._const_zeros = None
+        # fp8 forward (BASELINE configs[4], params['fp8']): e4m3 shadow of the QKV / FFN weights + per-tensor delayed scaling
+        self.fp8 = bool(params.get("fp8", False)) if params else False
+        self._fp8 = None
         self._entries = {e.name: e for e in self.table}
         self._build_tree()
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -178,6 +181,51 @@ class CrctModel(nn.Module):
         if self._shadow_ver != v:
             ops.cast_bf16(self._flat_p, out=self._flat_b16)
             self._shadow_ver = v
+            if self._fp8 is not None:
+                self._fp8_requantize()
+
+    # ------------------------------------------------------------------ fp8 forward state
+    def _fp8_state(self, eng):
+        """Device state of the fp8 forward, created with the first engine: e4m3 weight shadow (same element offsets as the
+        flat fp32 buffer), weight scales / amax per shadowed weight, activation scales / amax per producer site."""
+        if self._fp8 is None:
+            n_sites, weights = eng.fp8_layout()
+            dev = self._flat_p.device
+            st = dict(n_sites=n_sites, weights=weights,
+                      q=torch.zeros(self.total, dtype=torch.uint8, device=dev),
+                      w_scale=torch.ones(max(len(weights), 1), device=dev), w_amax=torch.zeros(max(len(weights), 1), device=dev),
+                      a_scale=torch.ones(max(n_sites, 1), device=dev), a_amax=torch.zeros(max(n_sites, 1), device=dev),
+                      calibrated=False)
+            # chunk table over the shadowed weights themselves (one segment per weight, slot = its index)
+            lens = [n for _, n in weights]
+            blk_seg, blk_off = ops.adamw_plan(lens) if lens else (torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int64))
+            st["seg_off"] = torch.tensor([o for o, _ in weights], dtype=torch.int64, device=dev)
+            st["seg_len"] = torch.tensor(lens, dtype=torch.int64, device=dev)
+            st["seg_slot"] = torch.arange(len(weights), dtype=torch.int32, device=dev)
+            st["blk_seg"], st["blk_off"] = blk_seg.to(dev), blk_off.to(dev)
+            self._fp8 = st
+            self._fp8_requantize()
+        return self._fp8
+
+    def _fp8_requantize(self):
+        """Exact per-tensor quantisation of the current fp32 weights (start-up, load_state_dict, foreign optimizers); the
+        fused AdamW keeps the shadow current by itself afterwards."""
+        st = self._fp8
+        if not st["weights"]:
+            return
+        L.check(L.load().crct_fp8_quantize_weights(self._flat_p.data_ptr(), st["q"].data_ptr(), st["seg_off"].data_ptr(),
+                                                   st["seg_len"].data_ptr(), st["seg_slot"].data_ptr(), st["blk_seg"].data_ptr(),
+                                                   st["blk_off"].data_ptr(), st["blk_seg"].numel(), st["w_scale"].data_ptr(),
+                                                   st["w_amax"].data_ptr(), len(st["weights"]), L.current_stream()), "fp8_quantize_weights")
+
+    def _fp8_step_args(self, eng):
+        st = self._fp8_state(eng)
+        return (st["q"], st["w_scale"], st["a_scale"], st["a_amax"])
+
+    def _fp8_update_act_scales(self):
+        st = self._fp8
+        L.check(L.load().crct_fp8_update_scales(st["a_scale"].data_ptr(), st["a_amax"].data_ptr(), st["n_sites"], L.current_stream()),
+                "fp8_update_scales")
 
     def _apply(self, fn, recurse=True):
         probe = fn(torch.zeros(1, device=self._flat_p.device))
@@ -405,6 +453,14 @@ class CrctModel(nn.Module):
                     seg_events=self._param_events)
         self._param_events = None
         dev = self._flat_p.device
+        if self.fp8:
+            step["fp8"] = self._fp8_step_args(eng)
+            if not self._fp8["calibrated"]:            # first fp8 forward: one dry pass collects every activation amax
+                eng.forward(self._flat_p, self._flat_b16, tensors, dict(step, seg_events=None))
+                self._fp8["calibrated"] = True
+            if self.training or not self._fp8.get("scaled"):
+                self._fp8_update_act_scales()          # delayed scaling: this pass quantises with the previous pass's amax
+                self._fp8["scaled"] = True
         if train_branch and torch.is_grad_enabled():
             loss, nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)
         else:

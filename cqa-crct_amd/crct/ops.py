@@ -54,6 +54,26 @@ def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=No
     return out
 
 
+def gemm_fp8(Aq, Bq, scale_a, scale_b, M, N, K, bias=None, act="none", preact_out=None, addend=None, p_drop=0.0, site=0, seed=0,
+             out_f32=False, q_out=None, q_scale=None, q_amax=None):
+    """y = act((Aq / sa) (Bq / sb)^T + bias) from OCP e4m3 operands (uint8 / float8_e4m3fn tensors [M][K], [N][K]); scale_* are
+    device fp32 scalars.  q_out: e4m3 copy of y quantised with q_scale, max |y| max-ed into q_amax."""
+    lib = L.load()
+    out = torch.empty(M, N, device=Aq.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    g = L.GemmArgs()
+    g.A, g.B, g.C = L.ptr(Aq), L.ptr(Bq), L.ptr(out)
+    g.bias, g.preact_out, g.addend = L.ptr(bias), L.ptr(preact_out), L.ptr(addend)
+    g.lda, g.ldb, g.ldc, g.ld_aux, g.ld_add = K, K, N, N, N
+    g.M, g.N, g.K = M, N, K
+    g.act, g.c_is_f32, g.tile, g.alpha = ACT[act], int(out_f32), -1, 1.0
+    g.drop_thr, g.drop_scale, g.drop_site = _drop(p_drop, site)
+    g.seed = seed
+    g.fp8, g.scale_a, g.scale_b = 1, L.ptr(scale_a), L.ptr(scale_b)
+    g.q_out, g.q_scale, g.q_amax, g.ld_q = L.ptr(q_out), L.ptr(q_scale), L.ptr(q_amax), N
+    L.check(lib.crct_gemm_bf16(C.byref(g), L.current_stream()), "gemm_fp8")
+    return out
+
+
 def gemm_wgrad_grouped(problems):
     """``problems`` = [(dy[R][N], x[R][K], out[N][K] fp32[, db[N] fp32])]: out += dy^T x (db += colsum dy), ONE launch."""
     lib = L.load()

@@ -79,6 +79,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._wd_dev = torch.empty(len(self._segs), dtype=torch.float32, device=dev)
         self._last = None
         self._step_dev, self._amp_arg, self._amp_keep = None, None, None
+        self._fp8_keep = None
         # overlap mode: the update runs as one launch per engine backward-segment on its own stream, in first-use
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
@@ -134,7 +135,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                          core.flat_shadow.data_ptr(), self._seg_off.data_ptr(), self._seg_len.data_ptr(),
                                          self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr() + 4 * b0,
                                          self._blk_off.data_ptr() + 8 * b0, b1 - b0, g0["betas"][0], g0["betas"][1], g0["eps"],
-                                         max(self._step, 1), L.ptr(inv_scale), self._amp_arg, int(max_workgroups),
+                                         max(self._step, 1), L.ptr(inv_scale), self._amp_arg, self._fp8_arg(), int(max_workgroups),
                                          int(self.fuse_zero_grad), stream), "adamw_step")
 
     # ---- torch.amp.GradScaler (train.py:157,208-212).  ``scaler.step(optimizer)`` sees ``_step_supports_amp_scaling`` and
@@ -163,6 +164,34 @@ class FusedAdamW(torch.optim.Optimizer):
         self._amp_keep = (scale32, found32, st)
         self._amp_arg = C.byref(st)
         return True
+
+    def _fp8_arg(self):
+        """CrctFp8Shadow of the model's e4m3 weight shadow (None unless the model runs the fp8 forward)."""
+        core = self.core
+        st = getattr(core, "_fp8", None)
+        if not getattr(core, "fp8", False) or st is None or not st["weights"]:
+            return None
+        if self._fp8_keep is None or self._fp8_keep[0] is not st:
+            import bisect
+            import ctypes as C
+            starts = [o for o, _ in st["weights"]]
+            slots = []
+            for e in self._segs:                         # AdamW segments are parameter tensors: a fused QKV weight spans three
+                k = bisect.bisect_right(starts, e.offset) - 1
+                inside = k >= 0 and e.offset + e.numel <= st["weights"][k][0] + st["weights"][k][1]
+                slots.append(k if inside else -1)
+            seg_slot = torch.tensor(slots, dtype=torch.int32, device=core.flat_params.device)
+            sh = L.Fp8Shadow()
+            sh.q, sh.seg_slot, sh.scale, sh.amax = st["q"].data_ptr(), seg_slot.data_ptr(), st["w_scale"].data_ptr(), st["w_amax"].data_ptr()
+            self._fp8_keep = (st, seg_slot, sh, C.byref(sh))
+        return self._fp8_keep[3]
+
+    def _fp8_before_update(self, stream):
+        """Delayed scaling of the weight shadow: the scales this update quantises with come from the amax the previous update saw."""
+        if self._fp8_arg() is not None:
+            st = self.core._fp8
+            L.check(L.load().crct_fp8_update_scales(st["w_scale"].data_ptr(), st["w_amax"].data_ptr(), len(st["weights"]), stream),
+                    "fp8_update_scales")
 
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
@@ -206,6 +235,7 @@ class FusedAdamW(torch.optim.Optimizer):
             else:
                 self._upload_hyper(self._opt_stream)          # not behind the backward pass that `cur` still runs
                 order = range(n)                              # the order backward finishes them: heads ... embeddings
+            self._fp8_before_update(self._opt_stream.cuda_stream)
             for sgi in order:
                 b0, b1 = self._seg_blocks[sgi]
                 if done is not None:
@@ -220,6 +250,7 @@ class FusedAdamW(torch.optim.Optimizer):
             core._opt_stream = self._opt_stream               # ... and the next backward for the whole stream
         else:
             self._upload_hyper()
+            self._fp8_before_update(L.current_stream())
             self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
         core.note_params_updated_natively()
         self._grads_cleared = bool(self.fuse_zero_grad)

@@ -94,8 +94,8 @@ struct SelfLayerP { LinearP qkv; ProjP proj; FfnP ffn; int H, heads; float p_att
 struct ConnLayerP { LinearP qkv1, qkv2; ProjP proj_v, proj_t; FfnP ffn_v, ffn_t; uint32_t site; };
 
 // ---- activation offsets (bytes into the workspace)
-struct FfnA { size_t u, h, s, y, mean, rstd; };
-struct ProjA { size_t s, a, mean, rstd; };
+struct FfnA { size_t u, h, s, y, mean, rstd, hq, yq; int site_h, site_y; };      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
+struct ProjA { size_t s, a, mean, rstd, aq; int site_a; };
 struct SelfLayerA { size_t qkv, ctx; ProjA proj; FfnA ffn; };
 struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
 struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b; };
@@ -116,8 +116,8 @@ struct crct_engine {
   std::vector<ConnLayerA> cla;
   struct { int64_t word, pos, type, wloc, bloc; LnP ln; } et;
   struct { LinearP img; int64_t color, wloc, bloc; LnP ln; } ev;
-  struct { size_t sum, y, mean, rstd; } eta;
-  struct { size_t soft, lin, sum, y, mean, rstd; } eva;
+  struct { size_t sum, y, mean, rstd, yq; int site; } eta;
+  struct { size_t soft, lin, sum, y, mean, rstd, yq; int site; } eva;
   LinearP t_pool, v_pool, cls, tp[4], vp[4], fu[4];
   struct { size_t pooled_t, pooled_v, t[3], v[3], cat, f[3], scratch, d_pt, d_pv, g[10]; } ha;   // g: one buffer per head gradient (see heads_bwd)
   StreamScratch st, sv;          // backward scratch per data stream (dy ping-pong lives in these)
@@ -125,6 +125,10 @@ struct crct_engine {
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
   size_t embed_rows[2], embed_idx[2];   // embedding backward: fp32 row gradients + table indices for the gather-sum pass
   size_t km_t = 0, km_v = 0;
+  // fp8 forward (BASELINE configs[4]): scale slot of every Linear weight that has an e4m3 shadow, number of activation scale sites
+  std::unordered_map<int64_t, int> wq_slot;
+  std::vector<std::pair<int64_t, int64_t>> wq_list;      // slot -> (flat offset, numel)
+  int n_sites = 0;
   size_t ws_bytes = 0;
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
@@ -173,15 +177,19 @@ LinearP fused3(crct_engine* e, const std::string& a, const std::string& b, const
   return l;
 }
 
-FfnA ffn_a(Arena& ar, size_t M, int H, int I) {
+FfnA ffn_a(Arena& ar, size_t M, int H, int I, int& sites) {
   FfnA a;
   a.u = ar.take(M * I * 2); a.h = ar.take(M * I * 2); a.s = ar.take(M * H * 2); a.y = ar.take(M * H * 2);
   a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
+  a.hq = ar.take(M * I); a.yq = ar.take(M * H);
+  a.site_h = sites++; a.site_y = sites++;
   return a;
 }
-ProjA proj_a(Arena& ar, size_t M, int H) {
+ProjA proj_a(Arena& ar, size_t M, int H, int& sites) {
   ProjA a;
   a.s = ar.take(M * H * 2); a.a = ar.take(M * H * 2); a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
+  a.aq = ar.take(M * H);
+  a.site_a = sites++;
   return a;
 }
 StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
@@ -297,6 +305,24 @@ struct Run {
     o.bias = P(l.b);
     gemm(x, ldx, false, PB(l.w), l.in, false, y, ldy, M, l.out, l.in, o);
   }
+  // ---- fp8 forward (CrctStepCfg.fp8): the same Linear from the e4m3 copies of its input (scale site `site_in`) and of its
+  // weight; optionally also emits the e4m3 copy of its own output (hq, site_out) for the next fp8 GEMM
+  bool f8() const { return c->fp8 && c->params_fp8 && c->fp8_w_scale && c->fp8_act_scale && c->fp8_act_amax; }
+  bool f8_lin(const LinearP& l) const { return f8() && e->wq_slot.count(l.w) != 0; }
+  void lin_fwd_f8(size_t xq, int site_in, const LinearP& l, int M, void* y, int64_t ldy, Opt o, size_t hq = (size_t)-1, int site_out = -1) {
+    if (rc) return;
+    ++tick;
+    CrctGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = W<uint8_t>(xq); g.B = reinterpret_cast<const uint8_t*>(c->params_fp8) + l.w; g.C = y; g.bias = P(l.b);
+    g.preact_out = o.preact; g.dact_src = o.dact_src; g.addend = o.addend;
+    g.lda = l.in; g.ldb = l.in; g.ldc = ldy; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
+    g.M = M; g.N = l.out; g.K = l.in; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
+    g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
+    g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
+    if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + site_out; }
+    fail(crct_gemm_bf16(&g, s));
+  }
   // dW[out][in] += dy^T x
   // with_bias: also db[out] += column sums of dy.  When the contraction length qualifies for the LDS-DMA kernel the
   // sums come out of the weight-gradient kernel itself (CrctGemmArgs.rowsum_out); otherwise a column-sum launch.
@@ -341,10 +367,12 @@ struct Run {
     if (rc) return;
     fail(crct_colsum_bf16(dy, lddy, G(l.b), F(sw != s ? colsum_part_w : colsum_part), M, l.out, 1, sw));
   }
-  void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H) {
+  void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H, size_t yq, int site) {
     if (rc) return;
     ++tick;
-    fail(crct_layernorm_fwd(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, s));
+    if (f8()) fail(crct_layernorm_fwd_q(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed,
+                                        W<uint8_t>(yq), c->fp8_act_scale + site, c->fp8_act_amax + site, s));
+    else fail(crct_layernorm_fwd(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, s));
   }
   // returns the buffer that holds the gradient of the producing Linear's output
   size_t ln_bwd(size_t dy, size_t x, size_t mean, size_t rstd, const LnP& ln, const LinearP& lin, size_t dres, size_t dlin,
@@ -380,7 +408,7 @@ struct Run {
   void proj_fwd(const ProjP& p, const ProjA& a, size_t ctx, size_t x, int M, const Drop& dr) {
     Opt o; o.drop = dr; o.addend = A(x); o.ld_add = p.dense.out;
     lin_fwd(A(ctx), p.dense.in, p.dense, M, A(a.s), p.dense.out, o);
-    ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out);
+    ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out, a.aq, a.site_a);
   }
   // in: g = grad of a.  out: dres (residual gradient), dctx.  Parameter gradients accumulated.
   void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, size_t part, int M, const Drop& dr) {
@@ -389,12 +417,16 @@ struct Run {
     lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
   }
   // y = LN(dropout(down(gelu(up(x)))) + x)   vilbert.py:454-471 / :585-602 / :782-786
-  void ffn_fwd(const FfnP& p, const FfnA& a, size_t x, int M, const Drop& dr) {
+  // xq / site_x: the e4m3 copy of x and its scale site (the LayerNorm that produced x wrote both)
+  void ffn_fwd(const FfnP& p, const FfnA& a, size_t x, size_t xq, int site_x, int M, const Drop& dr) {
     Opt o; o.preact = A(a.u); o.ld_aux = p.up.out; o.act = ACT_GELU;
-    lin_fwd(A(x), p.up.in, p.up, M, A(a.h), p.up.out, o);
+    const bool q_up = f8_lin(p.up), q_dn = f8_lin(p.down);
+    if (q_up) lin_fwd_f8(xq, site_x, p.up, M, A(a.h), p.up.out, o, a.hq, q_dn ? a.site_h : -1);
+    else lin_fwd(A(x), p.up.in, p.up, M, A(a.h), p.up.out, o);
     Opt o2; o2.drop = dr; o2.addend = A(x); o2.ld_add = p.down.out;
-    lin_fwd(A(a.h), p.down.in, p.down, M, A(a.s), p.down.out, o2);
-    ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out);
+    if (q_up && q_dn) lin_fwd_f8(a.hq, a.site_h, p.down, M, A(a.s), p.down.out, o2);
+    else lin_fwd(A(a.h), p.down.in, p.down, M, A(a.s), p.down.out, o2);
+    ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out, a.yq, a.site_y);
   }
   // in: g = grad of a.y.  out: gx = grad of x.
   void ffn_bwd(const FfnP& p, const FfnA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc, int M, const Drop& dr) {
@@ -409,12 +441,13 @@ struct Run {
   }
 
   // ---------------------------------------------------------------- self-attention layer
-  void self_fwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, const uint8_t* km, int B, int T) {
+  void self_fwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t xq, int site_x, const uint8_t* km, int B, int T) {
     const int M = B * T, H = p.H, d = H / p.heads;
-    lin_fwd(A(x), H, p.qkv, M, A(a.qkv), 3 * H, Opt());
+    if (f8_lin(p.qkv)) lin_fwd_f8(xq, site_x, p.qkv, M, A(a.qkv), 3 * H, Opt());
+    else lin_fwd(A(x), H, p.qkv, M, A(a.qkv), 3 * H, Opt());
     attn_fwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(a.ctx), H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
     proj_fwd(p.proj, a.proj, a.ctx, x, M, drop(p.p_hid, p.site + 1));
-    ffn_fwd(p.ffn, a.ffn, a.proj.a, M, drop(p.p_hid, p.site + 2));
+    ffn_fwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, M, drop(p.p_hid, p.site + 2));
   }
   void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const uint8_t* km, int B, int T) {
     const int M = B * T, H = p.H, d = H / p.heads;
@@ -431,11 +464,13 @@ struct Run {
 
   // ---------------------------------------------------------------- connection layer (vilbert.py:774-788)
   // `this` drives the TEXT stream, `V` the VISUAL stream (they may share one HIP stream).
-  void conn_fwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt) {
+  void conn_fwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xvq, int site_v, size_t xt, size_t xtq, int site_t) {
     const CrctModelDims& D = e->d;
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
-    V.lin_fwd(V.A(xv), D.Hv, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
-    lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());            // query2/key2/value2  :673-675
+    if (V.f8_lin(p.qkv1)) V.lin_fwd_f8(xvq, site_v, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());
+    else V.lin_fwd(V.A(xv), D.Hv, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
+    if (f8_lin(p.qkv2)) lin_fwd_f8(xtq, site_t, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());
+    else lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());            // query2/key2/value2  :673-675
     if (!rc) fail(order_streams(e, V.s, s));          // text needs k1, v1
     if (!V.rc) V.fail(order_streams(e, s, V.s));      // visual needs k2, v2
     // text queries over visual keys/values -> ctx1 [B,T,Hb]  :684-701 (dropout1 = v_attention prob)
@@ -447,8 +482,8 @@ struct Run {
     // cross wiring :780 -- visual stream takes ctx2, text stream takes ctx1
     V.proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2));
     proj_fwd(p.proj_t, a.proj_t, a.ctx1, xt, Mt, drop(D.p_hidden, p.site + 3));
-    V.ffn_fwd(p.ffn_v, a.ffn_v, a.proj_v.a, Mv, drop(D.p_v_hidden, p.site + 4));
-    ffn_fwd(p.ffn_t, a.ffn_t, a.proj_t.a, Mt, drop(D.p_hidden, p.site + 5));
+    V.ffn_fwd(p.ffn_v, a.ffn_v, a.proj_v.a, a.proj_v.aq, a.proj_v.site_a, Mv, drop(D.p_v_hidden, p.site + 4));
+    ffn_fwd(p.ffn_t, a.ffn_t, a.proj_t.a, a.proj_t.aq, a.proj_t.site_a, Mt, drop(D.p_hidden, p.site + 5));
   }
   void conn_bwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
     const CrctModelDims& D = e->d;
@@ -489,6 +524,8 @@ struct Run {
     if (!rc) fail(crct_embed_text_fwd(b->tokens, b->segments, b->loc, P(e->et.word), P(e->et.pos), P(e->et.type), P(e->et.wloc),
                                       P(e->et.bloc), P(e->et.ln.g), P(e->et.ln.b), A(e->eta.sum), A(e->eta.y), F(e->eta.mean),
                                       F(e->eta.rstd), b->B, b->T, D.H, D.n_pos, 1e-12f, dt.thr, dt.scale, dt.site, c->seed, s));
+    if (!rc && f8()) fail(crct_fp8_quantize_bf16(A(e->eta.y), W<uint8_t>(e->eta.yq), c->fp8_act_scale + e->eta.site,
+                                                 c->fp8_act_amax + e->eta.site, (int64_t)b->B * b->T * D.H, s));
   }
   void embed_image_fwd() {
     const CrctModelDims& D = e->d;
@@ -500,6 +537,8 @@ struct Run {
     if (!rc) fail(crct_embed_image_fwd(A(e->eva.lin), b->image_loc, b->image_target, P(e->ev.wloc), P(e->ev.bloc), P(e->ev.color),
                                        P(e->ev.ln.g), P(e->ev.ln.b), A(e->eva.sum), A(e->eva.y), F(e->eva.mean), F(e->eva.rstd),
                                        Mv, D.Hv, 1e-12f, dv.thr, dv.scale, dv.site, c->seed, s));
+    if (!rc && f8()) fail(crct_fp8_quantize_bf16(A(e->eva.y), W<uint8_t>(e->eva.yq), c->fp8_act_scale + e->eva.site,
+                                                 c->fp8_act_amax + e->eva.site, (int64_t)Mv * D.Hv, s));
   }
   void embed_text_bwd(size_t gt) {
     const CrctModelDims& D = e->d;
@@ -769,6 +808,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     for (int j = 0; j < 4; ++j) { own(e->tp[j]); own(e->vp[j]); }
     for (int j = 0; j < 3; ++j) own(e->fu[j]);     // fusion.6 (fu[3]) and bi_seq_relationship are produced by the head kernel: accumulate-only
   }
+  {
+    // fp8 forward: the QKV and FFN Linears whose input width is a whole number of 128-deep fp8 K tiles get an e4m3 weight
+    // shadow and a scale slot (the attention-output / dense1 / dense2 projections read bf16 context rows and stay bf16)
+    auto slot = [&](const LinearP& l) {
+      if (l.in % 128 != 0 || l.out % 8 != 0) return;
+      e->wq_slot[l.w] = (int)e->wq_list.size();
+      e->wq_list.push_back({l.w, (int64_t)l.in * l.out});
+    };
+    for (const SelfLayerP& l : e->tl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); }
+    for (const SelfLayerP& l : e->vl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); }
+    for (const ConnLayerP& l : e->cl) { slot(l.qkv1); slot(l.qkv2); slot(l.ffn_v.up); slot(l.ffn_v.down); slot(l.ffn_t.up); slot(l.ffn_t.down); }
+  }
 
   // ---- workspace
   Arena ar;
@@ -776,23 +827,25 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->eta.sum = ar.take(Mt * D.H * 2); e->eta.y = ar.take(Mt * D.H * 2); e->eta.mean = ar.take(Mt * 4); e->eta.rstd = ar.take(Mt * 4);
   e->eva.soft = ar.take(Mv * D.Fv * 2); e->eva.lin = ar.take(Mv * D.Hv * 2); e->eva.sum = ar.take(Mv * D.Hv * 2);
   e->eva.y = ar.take(Mv * D.Hv * 2); e->eva.mean = ar.take(Mv * 4); e->eva.rstd = ar.take(Mv * 4);
+  e->eta.yq = ar.take(Mt * D.H); e->eva.yq = ar.take(Mv * D.Hv);
+  e->eta.site = e->n_sites++; e->eva.site = e->n_sites++;
   e->taps.push_back({"emb.t", e->eta.y, 't'});
   e->taps.push_back({"emb.v", e->eva.y, 'v'});
   e->tla.resize(D.L); e->vla.resize(D.Lv); e->cla.resize(D.n_conn);
   for (int i = 0; i < D.L; ++i) {
     SelfLayerA& a = e->tla[i];
-    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.proj = proj_a(ar, Mt, D.H); a.ffn = ffn_a(ar, Mt, D.H, D.I);
+    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.proj = proj_a(ar, Mt, D.H, e->n_sites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites);
   }
   for (int i = 0; i < D.Lv; ++i) {
     SelfLayerA& a = e->vla[i];
-    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.proj = proj_a(ar, Mv, D.Hv); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv);
+    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.proj = proj_a(ar, Mv, D.Hv, e->n_sites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites);
   }
   for (int i = 0; i < D.n_conn; ++i) {
     ConnLayerA& a = e->cla[i];
     a.qkv1 = ar.take(Mv * 3 * D.Hb * 2); a.qkv2 = ar.take(Mt * 3 * D.Hb * 2);
     a.ctx1 = ar.take(Mt * D.Hb * 2); a.ctx2 = ar.take(Mv * D.Hb * 2);
-    a.proj_v = proj_a(ar, Mv, D.Hv); a.proj_t = proj_a(ar, Mt, D.H);
-    a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv); a.ffn_t = ffn_a(ar, Mt, D.H, D.I);
+    a.proj_v = proj_a(ar, Mv, D.Hv, e->n_sites); a.proj_t = proj_a(ar, Mt, D.H, e->n_sites);
+    a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites); a.ffn_t = ffn_a(ar, Mt, D.H, D.I, e->n_sites);
   }
   e->ha.pooled_t = ar.take(B * D.Hb * 2); e->ha.pooled_v = ar.take(B * D.Hb * 2);
   e->ha.t[0] = ar.take(B * D.H * 2); e->ha.t[1] = ar.take(B * 512 * 2); e->ha.t[2] = ar.take(B * 256 * 2);
@@ -949,6 +1002,8 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   Rt.embed_text_fwd();
   Rv.embed_image_fwd();
   size_t xt = e->eta.y, xv = e->eva.y;
+  size_t xtq = e->eta.yq, xvq = e->eva.yq;               // e4m3 copies of the running hidden states and their scale sites (fp8 forward)
+  int site_t = e->eta.site, site_v = e->eva.site;
   int step_i = 0;
   for (const Step& st : e->sched) {
     const int seg = (int)e->sched.size() - step_i;       // backward segment of this schedule step
@@ -956,9 +1011,20 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
     if (st.kind == 't') wait_params(Rt, seg);
     else if (st.kind == 'v') wait_params(Rv, seg);
     else { wait_params(Rt, seg); wait_params(Rv, seg); }
-    if (st.kind == 't') { Rt.self_fwd(e->tl[st.idx], e->tla[st.idx], xt, batch->text_keymask, batch->B, batch->T); xt = e->tla[st.idx].ffn.y; }
-    else if (st.kind == 'v') { Rv.self_fwd(e->vl[st.idx], e->vla[st.idx], xv, batch->image_keymask, batch->B, batch->V); xv = e->vla[st.idx].ffn.y; }
-    else { Rt.conn_fwd(Rv, e->cl[st.idx], e->cla[st.idx], xv, xt); xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
+    if (st.kind == 't') {
+      const SelfLayerA& a = e->tla[st.idx];
+      Rt.self_fwd(e->tl[st.idx], a, xt, xtq, site_t, batch->text_keymask, batch->B, batch->T);
+      xt = a.ffn.y; xtq = a.ffn.yq; site_t = a.ffn.site_y;
+    } else if (st.kind == 'v') {
+      const SelfLayerA& a = e->vla[st.idx];
+      Rv.self_fwd(e->vl[st.idx], a, xv, xvq, site_v, batch->image_keymask, batch->B, batch->V);
+      xv = a.ffn.y; xvq = a.ffn.yq; site_v = a.ffn.site_y;
+    } else {
+      const ConnLayerA& a = e->cla[st.idx];
+      Rt.conn_fwd(Rv, e->cl[st.idx], a, xv, xvq, site_v, xt, xtq, site_t);
+      xv = a.ffn_v.y; xvq = a.ffn_v.yq; site_v = a.ffn_v.site_y;
+      xt = a.ffn_t.y; xtq = a.ffn_t.yq; site_t = a.ffn_t.site_y;
+    }
   }
   wait_params(Rt, 0);
   wait_params(Rv, 0);
@@ -1063,6 +1129,14 @@ extern "C" int crct_engine_wgrad_owned(crct_engine_t* e, int64_t* offsets, int64
     if (offsets && numels && n < cap) { offsets[n] = kv.first; numels[n] = kv.second; }
     ++n;
   }
+  return n;
+}
+
+extern "C" int crct_engine_fp8_sites(const crct_engine_t* e) { return e ? e->n_sites : 0; }
+extern "C" int crct_engine_fp8_weights(const crct_engine_t* e, int64_t* offsets, int64_t* numels, int cap) {
+  if (!e) return -1;
+  const int n = (int)e->wq_list.size();
+  for (int i = 0; i < n && i < cap && offsets && numels; ++i) { offsets[i] = e->wq_list[i].first; numels[i] = e->wq_list[i].second; }
   return n;
 }
 

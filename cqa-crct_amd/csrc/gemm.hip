@@ -390,6 +390,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g, const T
 // of a row (full 128-byte row segments).  Same arithmetic, same Philox element indexing as gemm_epilogue.
 // As many wave rows per pass as the ring holds (RING bytes): usually the whole tile in ONE pass (2 workgroup barriers
 // in all and every thread busy) instead of one pass per wave row.
+// OCP e4m3: largest finite value 448; the hardware conversion does not saturate, so clamp first
+__device__ __forceinline__ float f8_clamp(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
+
 template <int BM, int BN, int WM, int RING>
 constexpr int epilogue_passes() {
   for (int p = 1; p <= WM; p *= 2)
@@ -411,6 +414,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
   const float* bias = g.bias;
   const uint32_t thr = g.drop_thr;
   const float dscale = g.drop_scale;
+  // fp8 operands were quantised as q = x * scale: the product is divided by both scales (device scalars, delayed scaling)
+  const float alpha = g.scale_a ? g.alpha / (g.scale_a[0] * g.scale_b[0]) : g.alpha;
+  const float qs = g.q_out ? g.q_scale[0] : 0.f;
+  float q_amax = 0.f;
   __syncthreads();                           // every wave is done reading the operand ring
 #pragma unroll 1
   for (int pass = 0; pass < P; ++pass) {
@@ -431,9 +438,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
       const float4 lo = *reinterpret_cast<const float4*>(ct + r * LDC + ch * 8);
       const float4 hi = *reinterpret_cast<const float4*>(ct + r * LDC + ch * 8 + 4);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      if (g.alpha != 1.0f) {
+      if (alpha != 1.0f) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= g.alpha;
+        for (int j = 0; j < 8; ++j) v[j] *= alpha;
       }
       if (bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
@@ -469,6 +476,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16)); }
       }
+      if (g.q_out) {       // e4m3 copy of the output for the next fp8 GEMM (FFN-up -> FFN-down), amax for the next step's scale
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q_amax = fmaxf(q_amax, fabsf(v[j]));
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[0] * qs), f8_clamp(v[1] * qs), w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[2] * qs), f8_clamp(v[3] * qs), w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[4] * qs), f8_clamp(v[5] * qs), w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[6] * qs), f8_clamp(v[7] * qs), w1, true);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(g.q_out) + (long)m * g.ld_q + n) = make_uint2(w0, w1);
+      }
       if (g.c_is_f32) {
 #if CRCT_GEMM_NT_F32   // fp32 outputs are weight gradients: written once per step, read by AdamW / the all-reduce much later
         f4_t* dst = reinterpret_cast<f4_t*>(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n);
@@ -500,6 +517,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
       }
     }
     if (pass + 1 < P) __syncthreads();       // the staging tile is rewritten by the next group of wave rows
+  }
+  if (g.q_out && g.q_amax) {                 // one atomic per wave; |x| >= 0, so the integer order of the bits is the float order
+    q_amax = wave_max(q_amax);
+    if (lane == 0) atomicMax(reinterpret_cast<int*>(g.q_amax), __float_as_int(q_amax));
   }
 }
 
@@ -752,6 +773,144 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tile_m, tile_n, tmap.dbg);
 }
 
+// ====================================================================================== fp8 forward (BASELINE configs[4])
+// y = x W^T with OCP e4m3 operands (per-tensor delayed scaling), fp32 accumulation, the same fused epilogues.  A 128-deep
+// fp8 K tile is a row of 128 BYTES, exactly like a 64-deep bf16 one, so the LDS images, the DMA pieces, the swizzle and the
+// fragment addresses are those of the bf16 kernel: a lane's 16-byte fragment read now holds TWO 8-byte MFMA operands
+// (v_mfma_f32_16x16x32_fp8_fp8 takes 8 e4m3 per lane).  The k index a lane's bytes stand for is permuted against the
+// natural order of the instruction, identically for both operands, which a dot product does not see.  Half the operand
+// bytes per K element travel HBM -> L2 -> LDS -> registers; the non-scaled fp8 MFMA itself runs at the bf16 rate.
+typedef long l2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned f8_src_offset(int slot, int r0, int R, long ld) {
+  const int r = slot >> 3, ch = (slot & 7) ^ (r & 7);
+  return (r0 + r < R) ? (unsigned)(((long)(r0 + r)) * ld + ch * 16) : OOB_OFF;
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  int tile_m, tile_n;
+  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
+  constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW, L = PA + PB;
+  constexpr int WTM = BM / WM / 16, WTN = BN / WN / 16;
+  static_assert(PA >= 1 && PB >= 1 && PA * NW * 1024 == A_BYTES && PB * NW * 1024 == B_BYTES, "tile / wave-grid mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)OOB_OFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)OOB_OFF, 0x00020000);
+  unsigned offA[PA], offB[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) offA[i] = f8_src_offset((i * NW + wave) * 64 + lane, m0, g.M, g.lda);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) offB[i] = f8_src_offset((i * NW + wave) * 64 + lane, n0, g.N, g.ldb);
+
+  f4_t acc[WTN][WTM];
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / 128;
+  auto issue = [&](int kt, int st) {
+    char* base = smem + st * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + i * NW * 1024), 16, (int)offA[i], kt * 128, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NW * 1024), 16, (int)offB[i], kt * 128, 0, 0);
+  };
+  const int npre = nk < NS - 1 ? nk : NS - 1;
+  for (int t = 0; t < npre; ++t) issue(t, t);
+
+  using FA = FragBase<false, TM, WTM>;
+  using FB = FragBase<false, TN, WTN>;
+  FA fbA;
+  FB fbB;
+  fbA.init(0, wm * (BM / WM), lane);
+  fbB.init(A_BYTES, wn * (BN / WN), lane);
+  const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+  constexpr int N_HALF = WTM + WTN;
+  auto wait_tile = [&](int t) {        // tile t has landed; the younger tiles issued so far may stay in flight
+    const int ahead = (nk - 1 < t + NS - 2 ? nk - 1 : t + NS - 2) - t;
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+  };
+  auto multiply = [&](int h, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN]) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+    for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+#pragma unroll
+    for (int a = 0; a < WTN; ++a) {
+      const l2_t bn = __builtin_bit_cast(l2_t, fn[h][a]);
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) {
+        const l2_t am = __builtin_bit_cast(l2_t, fm[h][b]);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bn[0], am[0], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bn[1], am[1], acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+  int st = 0, st_next = NS - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_tile(kt);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
+    bf8_t fm[2][WTM], fn[2][WTN];
+    uint32_t ca[FA::NB], cb[FB::NB];
+    fbA.at(smem_base + st * STAGE, ca);
+    fbB.at(smem_base + st * STAGE, cb);
+    FA::template read<0>(ca, fm[0]);
+    FB::template read<0>(cb, fn[0]);
+    FA::template read<1>(ca, fm[1]);
+    FB::template read<1>(cb, fn[1]);
+    frag_async_wait<(N_HALF <= 15 ? N_HALF : 0)>();
+    multiply(0, fm, fn);
+    asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));     // keep the first half's MFMAs in front of the second wait
+    frag_async_wait<0>();
+    multiply(1, fm, fn);
+    st_next = st;
+    st = st + 1 == NS ? 0 : st + 1;
+  }
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  int tiles = 0;
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  auto kern = gemm_f8_kernel<TM, TN, WM, WN, NS>;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);
+  return hipGetLastError();
+}
+
+// the fp8 kernel needs whole 128-deep K tiles and 16-byte aligned rows of both operands
+inline bool f8_ok(const CrctGemmArgs& g) {
+  if (g.ta || g.tb || g.K % 128 != 0 || g.K < 128 || g.lda % 16 != 0 || g.ldb % 16 != 0) return false;
+  if (g.N % 8 != 0 || g.ldc % 8 != 0 || !g.scale_a || !g.scale_b || g.rowsum_out) return false;
+  if ((g.preact_out || g.dact_src) && g.ld_aux % 8 != 0) return false;
+  if (g.addend && g.ld_add % 8 != 0) return false;
+  if (g.q_out && (g.ld_q % 8 != 0 || !g.q_scale)) return false;
+  return (long)g.M * g.lda < 0x7f000000L && (long)g.N * g.ldb < 0x7f000000L;
+}
+
 // ---- grouped launch: up to 8 independent GEMMs of the same mode in ONE grid (the weight gradients of one
 // layer: 4-6 small problems that individually leave most CUs idle).  Block -> (problem, tile) by prefix table.
 constexpr int GROUP_MAX = 8;
@@ -976,6 +1135,12 @@ extern "C" int crct_prof_read(int variant, long* count, double* flops, double* m
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
+  if (g.fp8) {
+    if (!f8_ok(g)) return hipErrorInvalidValue;
+    // same tile as the bf16 forward of this shape class; 3 stages for the long-K / narrow GEMMs
+    return (g.N <= 1024 && g.K >= 2048) ? launch_f8<4, 2, 4, 2, 3>(g, s) : launch_f8<4, 2, 4, 2, 2>(g, s);
+  }
+  if (g.q_out) return hipErrorInvalidValue;                     // the e4m3 output copy exists in the fp8 kernel only
   const bool pipe = pipe_ok(g) && !g_force_generic;
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));

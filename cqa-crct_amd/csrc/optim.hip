@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const float* __restrict__ seg_lr, const float* __restrict__ seg_wd,
                                                     const int32_t* __restrict__ blk_seg, const int64_t* __restrict__ blk_off,
                                                     float beta1, float beta2, float eps, float inv_bc1, float inv_sqrt_bc2,
-                                                    const float* __restrict__ inv_scale_dev, const CrctAmpState amp, int n_blk, int zero_g) {
+                                                    const float* __restrict__ inv_scale_dev, const CrctAmpState amp, const CrctFp8Shadow f8,
+                                                    int n_blk, int zero_g) {
  // loss scaling (torch.amp.GradScaler): a step whose gradients held an inf / nan is skipped as a whole, the scale divides
  // the gradients, and the step count behind the bias corrections is the device counter that only advances on real steps
  if (amp.found_inf && amp.found_inf[0] != 0.f) return;
@@ -43,6 +44,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
   float gsc = inv_scale_dev ? inv_scale_dev[0] : 1.0f;
   if (amp.grad_scale) gsc /= amp.grad_scale[0];
+  // e4m3 shadow of the weights the fp8 forward GEMMs read (BASELINE configs[4]): written with the tensor's CURRENT scale
+  // (from the amax one step back: delayed scaling, saturating), while max |w| of the new values feeds the next scale
+  const int qslot = f8.q ? f8.seg_slot[sgi] : -1;
+  const float qs = qslot >= 0 ? f8.scale[qslot] : 0.f;
+  float qmax = 0.f;
   for (int64_t i = (int64_t)threadIdx.x * 4; i < n; i += 1024) {
     const int64_t e = base + i;
     if (i + 4 <= n) {
@@ -74,6 +80,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       *reinterpret_cast<float4*>(v + e) = make_float4(va[0], va[1], va[2], va[3]);
 #endif
       if (pb) *reinterpret_cast<uint2*>(pb + e) = make_uint2(pack2bf(pa[0], pa[1]), pack2bf(pa[2], pa[3]));
+      if (qslot >= 0) {
+        qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(pa[0]), fabsf(pa[1]))), fmaxf(fabsf(pa[2]), fabsf(pa[3])));
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(pa[0] * qs, -448.f), 448.f), fminf(fmaxf(pa[1] * qs, -448.f), 448.f), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(pa[2] * qs, -448.f), 448.f), fminf(fmaxf(pa[3] * qs, -448.f), 448.f), w, true);
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(f8.q) + e) = w;
+      }
       if (zero_g) __builtin_nontemporal_store(f4_t{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4_t*>(g + e));
     } else {
       for (int64_t k = i; k < n; ++k) {
@@ -88,6 +101,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         if (zero_g) g[q] = 0.f;
       }
     }
+  }
+  if (qslot >= 0) {          // fp8-shadowed tensors are multiples of 4 elements (Linear weights): the scalar tail never holds them
+    qmax = wave_max(qmax);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(f8.amax + qslot), __float_as_int(qmax));
   }
  }
 }
@@ -137,11 +154,14 @@ extern "C" int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* b
 extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, const int64_t* seg_off,
                                const int64_t* seg_len, const float* seg_lr, const float* seg_wd, const int32_t* blk_seg,
                                const int64_t* blk_off, int64_t n_blk, float beta1, float beta2, float eps, int step,
-                               const float* inv_scale_dev, const CrctAmpState* amp_state, int max_workgroups, int zero_grads,
-                               crct_stream_t stream) {
+                               const float* inv_scale_dev, const CrctAmpState* amp_state, const CrctFp8Shadow* fp8_shadow,
+                               int max_workgroups, int zero_grads, crct_stream_t stream) {
   CRCT_REQUIRE(step >= 1, "adamw: step must be >= 1 (got %d)", step);
   CrctAmpState amp = {nullptr, nullptr, nullptr};
   if (amp_state) amp = *amp_state;
+  CrctFp8Shadow f8 = {nullptr, nullptr, nullptr, nullptr};
+  if (fp8_shadow) f8 = *fp8_shadow;
+  CRCT_REQUIRE(!f8.q || (f8.seg_slot && f8.scale && f8.amax), "adamw: incomplete fp8 shadow description");
   if (n_blk <= 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   // max_workgroups > 0: a grid-stride launch of at most that many workgroups.  An update that runs BESIDE the next
@@ -150,7 +170,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      seg_off, seg_len, seg_lr, seg_wd, blk_seg, blk_off, beta1, beta2, eps, (float)(1.0 / bc1),
-                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, (int)n_blk, zero_grads);
+                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, f8, (int)n_blk, zero_grads);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

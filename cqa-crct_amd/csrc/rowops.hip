@@ -47,6 +47,32 @@ __device__ __forceinline__ void row_store_bf16(const Row<NCH>& r, bf16_t* p, int
     }
   }
 }
+// OCP e4m3 copy of a row, q = clamp(x * qs, +-448); returns max |x| over this lane's elements (the NEXT step's scale)
+__device__ __forceinline__ float f8_clamp(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
+__device__ __forceinline__ uint2 pack8_fp8(const float (&v)[8], float qs) {
+  uint32_t w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[0] * qs), f8_clamp(v[1] * qs), w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[2] * qs), f8_clamp(v[3] * qs), w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[4] * qs), f8_clamp(v[5] * qs), w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[6] * qs), f8_clamp(v[7] * qs), w1, true);
+  return make_uint2(w0, w1);
+}
+template <int NCH>
+__device__ __forceinline__ float row_store_fp8(const Row<NCH>& r, uint8_t* p, int H, int lane, float qs) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      // the bf16 copy is what backward and the bf16 GEMMs see: quantise the bf16-rounded value, so both copies agree
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = bf2f(f2bf(r.v[i][j])); amax = fmaxf(amax, fabsf(v[j])); }
+      *reinterpret_cast<uint2*>(p + c) = pack8_fp8(v, qs);
+    }
+  }
+  return amax;
+}
 template <int NCH>
 __device__ __forceinline__ void row_load_f32(Row<NCH>& r, const float* p, int H, int lane) {
   float4 a[NCH], b[NCH];
@@ -346,11 +372,14 @@ template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H, float eps,
-                                                     uint32_t thr, float scale, uint32_t site, uint64_t seed) {
+                                                     uint32_t thr, float scale, uint32_t site, uint64_t seed,
+                                                     uint8_t* __restrict__ q_out, const float* __restrict__ q_scale, float* __restrict__ q_amax) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   Row<NCH> g, b;
   row_load_f32(g, gamma, H, lane);
   row_load_f32(b, beta, H, lane);
+  const float qs = q_out ? q_scale[0] : 0.f;
+  float amax = 0.f;
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
     Row<NCH> r;
     row_load_bf16(r, x + row * H, H, lane);
@@ -358,7 +387,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     row_stats(r, H, lane, eps, mean, rstd);
     row_normalize(r, g, b, H, lane, mean, rstd, row, thr, scale, site, seed);
     row_store_bf16(r, y + row * H, H, lane);
+    if (q_out) amax = fmaxf(amax, row_store_fp8(r, q_out + row * H, H, lane, qs));     // the fp8 GEMMs' operand (BASELINE configs[4])
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+  if (q_out && q_amax) {
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(reinterpret_cast<int*>(q_amax), __float_as_int(amax));
   }
 }
 
@@ -772,7 +806,21 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
                                      (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr,
-                                     drop_scale, drop_site, seed));
+                                     drop_scale, drop_site, seed, (uint8_t*)nullptr, (const float*)nullptr, (float*)nullptr));
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int M, int H, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site,
+                         uint64_t seed, void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream) {
+  CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm: H=%d must be a positive multiple of 8", H);
+  CRCT_REQUIRE(q_out && q_scale, "layernorm_fwd_q: q_out and q_scale are required");
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
+                                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr,
+                                     drop_scale, drop_site, seed, (uint8_t*)q_out, q_scale, q_amax));
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -900,6 +948,108 @@ extern "C" int crct_build_keymasks(const int64_t* sep_indices, const int64_t* hi
   const int n = B * (T > V ? T : V);
   hipLaunchKernelGGL(build_keymasks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sep_indices, hist_len, sep_stride,
                      image_mask, km_t, km_v, B, T, V);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+// ---------------------------------------------------------------------------------- fp8 (OCP e4m3) quantisation passes
+// bf16 tensor -> e4m3 with a given scale + amax (the embedding outputs, which no LayerNorm launch of ours re-reads)
+__global__ __launch_bounds__(256) void fp8_quantize_bf16_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
+                                                                const float* __restrict__ scale, float* __restrict__ amax_out, long n) {
+  const float qs = scale[0];
+  float amax = 0.f;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i + 8 <= n; i += (long)gridDim.x * 256 * 8) {
+    const uint4 u = *reinterpret_cast<const uint4*>(x + i);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    *reinterpret_cast<uint2*>(q + i) = pack8_fp8(v, qs);
+  }
+  if (amax_out) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(amax_out), __float_as_int(amax));
+  }
+}
+// fp32 weights of the tensors listed by (seg_off, seg_len, seg_slot) over the chunk table of crct_adamw_plan:
+// MODE 0: amax[slot] = max |w|;  MODE 1: q = e4m3(w * scale[slot]) at the same flat element offset
+template <int MODE>
+__global__ __launch_bounds__(256) void fp8_weights_kernel(const float* __restrict__ p, uint8_t* __restrict__ q,
+                                                          const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_len,
+                                                          const int32_t* __restrict__ seg_slot, const int32_t* __restrict__ blk_seg,
+                                                          const int64_t* __restrict__ blk_off, const float* __restrict__ scale,
+                                                          float* __restrict__ amax, int n_blk) {
+  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    const int sgi = blk_seg[blk], slot = seg_slot[sgi];
+    if (slot < 0) continue;
+    const int64_t off = blk_off[blk], base = seg_off[sgi] + off;
+    int64_t n = seg_len[sgi] - off;
+    if (n > 4096) n = 4096;
+    const float qs = MODE == 1 ? scale[slot] : 0.f;
+    float am = 0.f;
+    for (int64_t i = (int64_t)threadIdx.x * 4; i + 4 <= n; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(p + base + i);
+      if (MODE == 0) am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      else {
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v.x * qs), f8_clamp(v.y * qs), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v.z * qs), f8_clamp(v.w * qs), w, true);
+        *reinterpret_cast<uint32_t*>(q + base + i) = w;
+      }
+    }
+    if (MODE == 0) {
+      am = wave_max(am);
+      if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(amax + slot), __float_as_int(am));
+    }
+  }
+}
+// delayed scaling: scale[i] = 448 / amax[i] for the entries that saw data, amax[i] = 0 for the next round
+__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float a = amax[i];
+    if (a > 0.f) scale[i] = 448.0f / a;
+    amax[i] = 0.f;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* amax, int64_t n, crct_stream_t stream) {
+  CRCT_REQUIRE(x && q && scale && n % 8 == 0, "fp8_quantize_bf16: bad arguments");
+  if (n <= 0) return 0;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fp8_quantize_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (uint8_t*)q, scale, amax, (long)n);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int crct_fp8_update_scales(float* scale, float* amax, int n, crct_stream_t stream) {
+  CRCT_REQUIRE(scale && amax && n >= 0, "fp8_update_scales: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scale, amax, n);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, const int64_t* seg_len, const int32_t* seg_slot,
+                              const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk, float* scale, float* amax, int n_slots,
+                              crct_stream_t stream) {
+  CRCT_REQUIRE(p && q && seg_off && seg_len && seg_slot && blk_seg && blk_off && scale && amax, "fp8_quantize_weights: null argument");
+  if (n_blk <= 0 || n_slots <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = n_blk > 2048 ? 2048 : (int)n_blk;
+  CRCT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)n_slots * 4, s));
+  hipLaunchKernelGGL(fp8_weights_kernel<0>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
+                     (const float*)scale, amax, (int)n_blk);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, scale, amax, n_slots);
+  hipLaunchKernelGGL(fp8_weights_kernel<1>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
+                     (const float*)scale, amax, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -58,6 +58,13 @@ typedef struct CrctGemmArgs {
                                weight gradient dW = dy^T x (ta = tb = 1) this is the BIAS gradient, computed by the
                                same kernel from the dy tiles it already holds (one extra MFMA against a fragment of
                                ones).  LDS-DMA kernel only (K % 64 == 0); other shapes are rejected. */
+  /* fp8 forward (BASELINE configs[4]): fp8 != 0 -> A [M][lda] and B [N][ldb] are OCP e4m3 BYTES (ta = tb = 0, K % 128 == 0,
+   * lda / ldb % 16 == 0), quantised per tensor as q = x * scale; the fp32 product is divided by (*scale_a) * (*scale_b)
+   * (device scalars: delayed scaling never syncs the host).  q_out: optional e4m3 copy of the epilogue's result
+   * [M][ld_q], quantised with *q_scale, while max |result| is max-ed into *q_amax (fp32 bits, >= 0) for the next step's scale. */
+  int32_t fp8;
+  const float* scale_a; const float* scale_b;
+  void* q_out; const float* q_scale; float* q_amax; int64_t ld_q;
 } CrctGemmArgs;
 
 int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
@@ -90,6 +97,26 @@ int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
                        float* mean, float* rstd, int M, int H, float eps,
                        uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                        crct_stream_t stream);
+
+/* The same, also writing an OCP e4m3 copy q_out [M][H] of y (quantised as q = y * *q_scale, saturating at +-448) and
+ * max-ing max |y| into *q_amax (fp32 bits): the operand of the fp8 forward GEMMs (BASELINE configs[4]). */
+int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y,
+                         float* mean, float* rstd, int M, int H, float eps,
+                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                         void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream);
+
+/* fp8 (OCP e4m3, per-tensor delayed scaling) helpers.  All scales / amax values are device fp32.
+ *  crct_fp8_quantize_bf16   q[i] = e4m3(x[i] * *scale), *amax = max(*amax, max |x|)            (n % 8 == 0)
+ *  crct_fp8_update_scales   scale[i] = 448 / amax[i] where amax[i] > 0; amax[i] = 0            (once per step per table)
+ *  crct_fp8_quantize_weights  exact per-tensor scaling of fp32 weights into the flat e4m3 shadow (same element offsets as
+ *                           the fp32 buffer): tensors (seg_off, seg_len) with scale slot seg_slot[s] >= 0, chunk table
+ *                           (blk_seg, blk_off) from crct_adamw_plan; writes scale[slot] = 448 / max |w|.  Used at start-up
+ *                           and after a load_state_dict; the optimizer keeps the shadow current afterwards (CrctFp8Shadow). */
+int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* amax, int64_t n, crct_stream_t stream);
+int crct_fp8_update_scales(float* scale, float* amax, int n, crct_stream_t stream);
+int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, const int64_t* seg_len, const int32_t* seg_slot,
+                              const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk, float* scale, float* amax, int n_slots,
+                              crct_stream_t stream);
 
 /* LayerNorm backward.  dy bf16 [M][H] (gradient w.r.t. y, or w.r.t. post-norm-dropout output when
  * post_* is set), x = saved pre-norm rows.  Writes
@@ -278,12 +305,17 @@ int crct_eval_select(const float* logits, const float* reg_out, const float* reg
  * increments it unless found_inf is set).  All device pointers, each may be NULL. */
 typedef struct CrctAmpState { const float* grad_scale; const float* found_inf; const int32_t* step; } CrctAmpState;
 int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_stream_t stream);
+/* e4m3 shadow of the weights the fp8 forward GEMMs read: q = flat byte buffer with the element offsets of the fp32 buffer,
+ * seg_slot[s] = scale slot of AdamW segment s (-1: tensor has no fp8 shadow), scale / amax = device fp32 [n_slots].  The update
+ * quantises the NEW weights with scale[slot] and max-es max |w| into amax[slot]; the caller runs crct_fp8_update_scales on
+ * (scale, amax) before the NEXT update (delayed scaling).  All pointers device memory; q == NULL switches it off. */
+typedef struct CrctFp8Shadow { void* q; const int32_t* seg_slot; const float* scale; float* amax; } CrctFp8Shadow;
 int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap);
 int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
                     const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
                     const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk,
                     float beta1, float beta2, float eps, int step, const float* inv_scale_dev, const CrctAmpState* amp,
-                    int max_workgroups, int zero_grads, crct_stream_t stream);
+                    const CrctFp8Shadow* fp8_shadow, int max_workgroups, int zero_grads, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Step engine: the whole forward + loss + backward of one batch as one native call
@@ -343,6 +375,14 @@ typedef struct CrctStepCfg {
                                 on the four internal streams (text, text weight-gradient, visual, visual weight-gradient); once
                                 all four have fired, the gradient range of segments 0 .. s is final -- a data-parallel caller
                                 starts that range's all-reduce behind them while the rest of backward keeps running */
+  /* fp8 forward (BASELINE configs[4]).  fp8 != 0 with all four pointers set: the QKV and FFN Linears whose input width is a
+   * multiple of 128 run as e4m3 GEMMs (fp32 accumulate); everything else, and the whole backward pass, stays bf16.
+   *   params_fp8      flat e4m3 weight shadow, element offsets of params_f32 (kept current by crct_adamw_step / CrctFp8Shadow)
+   *   fp8_w_scale     device fp32 [crct_engine_fp8_weights()]: scale of weight slot i (q = w * scale)
+   *   fp8_act_scale   device fp32 [crct_engine_fp8_sites()]: scales the producers quantise the activations with
+   *   fp8_act_amax    device fp32 [same]: max |activation| seen by this pass, for the caller's crct_fp8_update_scales */
+  int32_t fp8;
+  const void* params_fp8; const float* fp8_w_scale; const float* fp8_act_scale; float* fp8_act_amax;
   int32_t wgrad_overwrite;   /* backward only.  != 0: the caller guarantees that nothing has been accumulated into the weight
                                 gradients listed by crct_engine_wgrad_owned since they were last consumed; those gradients are
                                 then WRITTEN instead of added to (bit-identical to adding into zeros) and need not be zeroed --
@@ -374,6 +414,10 @@ int crct_engine_wgrad_owned(crct_engine_t*, int64_t* offsets, int64_t* numels, i
 int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
                    int64_t n_blk, crct_stream_t stream);
 int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
+/* fp8 forward: number of activation scale sites, and the (flat offset, element count) of every weight that has an e4m3 shadow
+ * (index = its slot in CrctStepCfg.fp8_w_scale).  Both are fixed at crct_engine_create. */
+int crct_engine_fp8_sites(const crct_engine_t*);
+int crct_engine_fp8_weights(const crct_engine_t*, int64_t* offsets, int64_t* numels, int cap);
 /* Debug taps: copy a named bf16 activation ("emb.t", "t3.t", "c0.v", "seq_t" ...) of the last
  * forward (batch B, T, V) into `out` (device, bf16); returns the element count or -1. */
 int64_t crct_engine_tap(crct_engine_t*, const void* workspace, const char* name, int B, int T, int V,

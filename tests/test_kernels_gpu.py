@@ -351,9 +351,71 @@ def test_adamw_matches_torch():
         opt.step()
         L.check(lib.crct_adamw_step(p.data_ptr(), (grad * step).data_ptr(), m.data_ptr(), v.data_ptr(), pb.data_ptr(), seg_off.data_ptr(),
                                     seg_len.data_ptr(), seg_lr.data_ptr(), seg_wd.data_ptr(), bs.data_ptr(), bo.data_ptr(), bs.numel(),
-                                    0.9, 0.999, 1e-8, step, None, None, 2 if step == 2 else 0, 0, L.current_stream()))   # step 2: throttled grid
+                                    0.9, 0.999, 1e-8, step, None, None, None, 2 if step == 2 else 0, 0, L.current_stream()))   # step 2: throttled grid
     for rp, o, s in zip(ref_params, offs, sizes):
         assert torch.allclose(p[o:o + s].cpu(), rp.detach(), rtol=1e-5, atol=1e-7)
         assert torch.equal(pb[o:o + s].cpu(), p[o:o + s].cpu().to(torch.bfloat16))
     # padding between tensors is never touched
     assert float(m[sizes[0]:offs[1]].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (BASELINE configs[4])
+def _q8(x, scale):
+    """OCP e4m3 quantisation as the kernels do it: q = e4m3(clamp(x * scale, +-448)), round-to-nearest-even."""
+    return (x.float() * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("M,N,K", [(1600, 3072, 768), (1600, 768, 3072), (2880, 3072, 1024), (80, 256, 128)])
+def test_gemm_fp8_forward(M, N, K):
+    """e4m3 x e4m3 -> fp32 accumulate -> fused epilogue, against fp32 matmul of the SAME dequantised operands (the kernel's
+    only freedom is the summation order and the bf16 rounding of its outputs), plus the e4m3 copy of the output."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 1.5
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    sa, sb = 448.0 / float(x.abs().max()), 448.0 / float(w.abs().max())
+    xq, wq = _q8(x, sa).to(DEV), _q8(w, sb).to(DEV)
+    sa_d, sb_d = torch.tensor([sa], device=DEV), torch.tensor([sb], device=DEV)
+    ref = (xq.float() / sa) @ (wq.float() / sb).t() + b
+    y = ops.gemm_fp8(xq, wq, sa_d, sb_d, M, N, K, bias=b, out_f32=True)
+    assert float((y - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    # GELU epilogue + pre-activation + e4m3 copy of the output (what the FFN-up GEMM does)
+    pre = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    q_out = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+    href = torch.nn.functional.gelu(ref)
+    qs = torch.tensor([448.0 / float(href.abs().max()) * 0.9], device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    h = ops.gemm_fp8(xq, wq, sa_d, sb_d, M, N, K, bias=b, act="gelu", preact_out=pre, q_out=q_out, q_scale=qs, q_amax=amax)
+    assert float((pre.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+    assert float((h.float() - href).abs().max()) <= 1e-2 * float(href.abs().max())
+    assert abs(float(amax) - float(href.abs().max())) <= 1e-2 * float(href.abs().max())
+    deq = q_out.view(torch.float8_e4m3fn).float() / float(qs)
+    # e4m3 keeps 3 mantissa bits: relative error <= 2^-4 of the value (plus the subnormal step near zero)
+    tol = 0.0625 * href.abs() + 0.002 / float(qs) + 1e-2 * float(href.abs().max())       # + the subnormal step, + the kernel's own bf16-level differences
+    assert float(((deq - href).abs() - tol).max()) <= 0.0
+
+
+def test_fp8_quantisers_and_layernorm_copy():
+    lib = L.load()
+    # bf16 -> e4m3 pass
+    x = (torch.randn(1600 * 768, device=DEV) * 2).to(torch.bfloat16)
+    q = torch.zeros(x.numel(), device=DEV, dtype=torch.uint8)
+    sc, am = torch.tensor([17.0], device=DEV), torch.zeros(1, device=DEV)
+    L.check(lib.crct_fp8_quantize_bf16(x.data_ptr(), q.data_ptr(), sc.data_ptr(), am.data_ptr(), x.numel(), L.current_stream()))
+    assert torch.equal(q.view(torch.float8_e4m3fn).float(), _q8(x, 17.0).float())
+    assert float(am) == float(x.float().abs().max())
+    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, L.current_stream()))
+    assert abs(float(sc) - 448.0 / float(x.float().abs().max())) < 1e-4 * float(sc) and float(am) == 0.0
+    # LayerNorm with the e4m3 copy: the copy is the quantisation of the bf16 output the kernel stores
+    xs = (torch.randn(1600, 768, device=DEV)).to(torch.bfloat16)
+    gamma, beta = torch.rand(768, device=DEV) + 0.5, torch.randn(768, device=DEV) * 0.1
+    y = torch.empty_like(xs)
+    mean, rstd = torch.empty(1600, device=DEV), torch.empty(1600, device=DEV)
+    yq = torch.zeros(1600, 768, device=DEV, dtype=torch.uint8)
+    sc2, am2 = torch.tensor([30.0], device=DEV), torch.zeros(1, device=DEV)
+    L.check(lib.crct_layernorm_fwd_q(xs.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     1600, 768, 1e-12, 0, 1.0, 0, 0, yq.data_ptr(), sc2.data_ptr(), am2.data_ptr(), L.current_stream()))
+    y_plain, _, _ = ops.layernorm_fwd(xs, gamma, beta)
+    assert torch.equal(y, y_plain)
+    assert torch.equal(yq.view(torch.float8_e4m3fn).float(), _q8(y, 30.0).float())
+    assert float(am2) == float(y.float().abs().max())
