@@ -49,7 +49,7 @@ VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
               5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x128w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
               10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 15: "dma128x64w8s3", 16: "reg128x128", 17: "reg128x64",
-              18: "reg64x128", 19: "reg64x64"}
+              18: "reg64x128", 19: "reg64x64", 20: "f8e4m3_128x64w8s2", 21: "f8e4m3_128x64w8s3"}
 KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--adamw-wgs", type=int, default=-1, help="workgroups per overlapped AdamW launch (0 = full width; default: the optimizer's)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
+    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
+                    help="bf16: the headline (BASELINE configs[1]).  fp8: BASELINE configs[4] -- the QKV / FFN GEMMs of the forward pass on "
+                         "OCP e4m3 operands with per-tensor delayed scaling and fp32 accumulation, backward and everything else bf16")
     return ap.parse_args()
 
 
@@ -202,7 +205,7 @@ def main():
     from crct.input_pipeline import DevicePrefetcher
 
     cfg = CFG.vilbert_config(v_feature_size=a.feat)
-    params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0)
+    params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0, fp8=a.dtype == "fp8")
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
@@ -314,9 +317,10 @@ def main():
         flop_qa = FLOP_PER_QA.get((a.vis, a.tokens, a.feat))
         out = {"metric": "QA-pairs/sec training step (whole node)", "value": qa_per_s, "unit": "QA-pairs/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
-                                      "%d text tokens, dropout 0.1, L1 regression loss" % (a.feat, a.batch, a.vis, a.feat, a.tokens),
+                                      "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
+                                      "; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.dtype == "fp8" else ""),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input,
                           "h2d_inclusive": h2d, "gradient_allreduce": comm, "gemm_variants": rows}}
         if flop_qa:

@@ -115,3 +115,11 @@ __device__ __forceinline__ float act_grad(int act, float s) {
     default: return 1.f;
   }
 }
+
+// ------------------------------------------------------------------ running maximum of |x| (fp8 delayed scaling)
+// *dst = max(*dst, v) for v >= 0 (the integer order of the bits is the float order).  Thousands of waves report into ONE
+// word per tensor: a wave first looks at the current value (a stale read only costs a redundant atomic, never a wrong
+// maximum) and issues the memory-side atomic only if it would raise it -- a handful per launch instead of one per wave.
+__device__ __forceinline__ void amax_update(float* dst, float v) {
+  if (v > __builtin_nontemporal_load(dst)) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));
+}

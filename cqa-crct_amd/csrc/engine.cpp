@@ -645,6 +645,9 @@ struct Run {
     const int B = b->B;
     const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;
     const size_t* g = e->ha.g;
+    static const bool inline_wgrads = getenv("CRCT_HEADS_INLINE") != nullptr;      // developer A/B: weight gradients of the heads in order on the data streams
+    struct Guard { Run* a; Run* b; hipStream_t ka, kb; ~Guard() { a->sw = ka; b->sw = kb; a->defer_wgrad = b->defer_wgrad = true; } } guard{this, &V, sw, V.sw};
+    if (inline_wgrads) { flush_wgrads(); V.flush_wgrads(); sw = s; V.sw = V.s; defer_wgrad = V.defer_wgrad = false; }
     // the loss kernel is re-run with gradient outputs enabled (cheap: B rows) so that forward can be called alone for evaluation
     {
       CrctHeadArgs h;

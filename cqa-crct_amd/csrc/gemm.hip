@@ -520,7 +520,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
   }
   if (g.q_out && g.q_amax) {                 // one atomic per wave; |x| >= 0, so the integer order of the bits is the float order
     q_amax = wave_max(q_amax);
-    if (lane == 0) atomicMax(reinterpret_cast<int*>(g.q_amax), __float_as_int(q_amax));
+    if (lane == 0) amax_update(g.q_amax, q_amax);
   }
 }
 
@@ -1135,16 +1135,18 @@ extern "C" int crct_prof_read(int variant, long* count, double* flops, double* m
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
-  if (g.fp8) {
-    if (!f8_ok(g)) return hipErrorInvalidValue;
-    // same tile as the bf16 forward of this shape class; 3 stages for the long-K / narrow GEMMs
-    return (g.N <= 1024 && g.K >= 2048) ? launch_f8<4, 2, 4, 2, 3>(g, s) : launch_f8<4, 2, 4, 2, 2>(g, s);
-  }
-  if (g.q_out) return hipErrorInvalidValue;                     // the e4m3 output copy exists in the fp8 kernel only
-  const bool pipe = pipe_ok(g) && !g_force_generic;
+  if (g.fp8 && !f8_ok(g)) return hipErrorInvalidValue;
+  if (g.q_out && !g.fp8) return hipErrorInvalidValue;           // the e4m3 output copy exists in the fp8 kernel only
+  const bool pipe = g.fp8 || (pipe_ok(g) && !g_force_generic);
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
   if (t > 15) t = 12;
+  // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21); a developer override
+  // CRCT_GEMM_F8=<stages> forces one of them
+  if (g.fp8) {
+    static const int ov = env_cfg("CRCT_GEMM_F8");
+    t = (ov == 2 || ov == 3) ? 18 + ov : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
+  }
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
   ProfSlot* slot = nullptr;
@@ -1161,7 +1163,9 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
     g_time_start = slot->a; g_time_stop = slot->b;
   }
   hipError_t e;
-  if (pipe) {
+  if (g.fp8) {
+    e = t == 21 ? launch_f8<4, 2, 4, 2, 3>(g, s) : launch_f8<4, 2, 4, 2, 2>(g, s);
+  } else if (pipe) {
     switch (t) {
       case 0: e = launch_pipe<4, 4, 2, 2, 3>(g, s); break;
       case 1: e = launch_pipe<4, 2, 2, 2, 4>(g, s); break;

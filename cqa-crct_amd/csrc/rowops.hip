@@ -367,6 +367,43 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
   }
 }
 
+// word_embeddings gradient without float atomics: table[ids[r]][:] += rows[r][:] summed in a FIXED order.  One wave per token
+// row r: if an earlier row carries the same id the wave has nothing to do; otherwise it owns that table row and adds the
+// fp32 gradient rows of ALL tokens with this id in increasing row order (ballot over 64 ids at a time).  The 30 522-row
+// table is touched by <= B*T rows, most ids occur once, [PAD] / [CLS] / [SEP] a few hundred times: the result is bitwise
+// reproducible, which the atomics were not (arrival-order rounding: 1 of ~12 runs ended a 38-step training run on a
+// different loss, round-2 tools/det_check.sh).
+__global__ __launch_bounds__(64) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
+                                                          float* __restrict__ table) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int64_t id = ids[r];
+  bool earlier = false;
+  for (int i = lane; i < r; i += 64) earlier |= ids[i] == id;
+  if (__ballot(earlier) != 0ull) return;
+  float* dst = table + id * (long)H;
+  for (int c0 = 0; c0 < H; c0 += 256) {                  // 4 columns per lane per pass, accumulators in registers
+    const int c = c0 + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = r & ~63; base < M; base += 64) {
+      const int i = base + lane;
+      unsigned long long m = __ballot(i >= r && i < M && ids[i] == id);
+      while (m) {
+        const int j = base + __builtin_ctzll(m);
+        m &= m - 1;
+        if (c < H) {
+          const float4 x = *reinterpret_cast<const float4*>(rows + (long)j * H + c);
+          acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+      }
+    }
+    if (c < H) {
+      float4 o = *reinterpret_cast<float4*>(dst + c);
+      o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+      *reinterpret_cast<float4*>(dst + c) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ LayerNorm fwd
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
@@ -392,7 +429,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
   if (q_out && q_amax) {
     amax = wave_max(amax);
-    if (lane == 0) atomicMax(reinterpret_cast<int*>(q_amax), __float_as_int(amax));
+    if (lane == 0) amax_update(q_amax, amax);
   }
 }
 
@@ -665,7 +702,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     row_load_bf16(x, sum_p + row * H, H, lane);
     row_apply_dropmask(dy, H, lane, row, thr, scale, site, seed);
     row_ln_bwd(dy, x, gamma, H, lane, mean_p[row], rstd_p[row], adg, adb);
-    row_atomic_add(dy, d_word + ids[row] * (long)H, H, lane);          // 30k-row table: collisions are rare
+    if (!rows_scratch) row_atomic_add(dy, d_word + ids[row] * (long)H, H, lane);     // fall-back only: see word_scatter_kernel
     int pid = -1;
     if (qa) {
       const int fq = first_qa_index(segs + (long)b * T, T, lane);
@@ -973,7 +1010,7 @@ __global__ __launch_bounds__(256) void fp8_quantize_bf16_kernel(const bf16_t* __
   }
   if (amax_out) {
     amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(amax_out), __float_as_int(amax));
+    if ((threadIdx.x & 63) == 0) amax_update(amax_out, amax);
   }
 }
 // fp32 weights of the tensors listed by (seg_off, seg_len, seg_slot) over the chunk table of crct_adamw_plan:
@@ -1004,7 +1041,7 @@ __global__ __launch_bounds__(256) void fp8_weights_kernel(const float* __restric
     }
     if (MODE == 0) {
       am = wave_max(am);
-      if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(amax + slot), __float_as_int(am));
+      if ((threadIdx.x & 63) == 0) amax_update(amax + slot, am);
     }
   }
 }
@@ -1103,6 +1140,8 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
     const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
     hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s,
                        rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
+    CRCT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(word_scatter_kernel, dim3((int)M), dim3(64), 0, s, (const float*)rows_scratch, ids, (int)M, H, d_word);
     CRCT_CHECK_HIP(hipGetLastError());
   }
   FinalizeArgs fa = {};

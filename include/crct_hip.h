@@ -202,9 +202,9 @@ int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* lo
                         int B, int T, int H, int n_pos, float eps,
                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                         crct_stream_t stream);
-/* Backward: scatter-add (fp32 atomics) into the word table; position / type tables (a few dozen rows hit by
- * thousands of tokens) through rows_scratch (fp32 [B*T][H]) + idx_scratch (int32 [2][B*T]) and a deterministic
- * gather-sum pass (one workgroup per table row); with rows_scratch == NULL they use atomics as well.  Reduces the
+/* Backward.  With rows_scratch (fp32 [B*T][H]) + idx_scratch (int32 [2][B*T]) every table gradient is summed in a fixed order
+ * (bitwise reproducible): the word table by one wave per token row (the first row of each id adds all rows of that id), the
+ * position / type tables by one workgroup per table row; with rows_scratch == NULL all three fall back to fp32 atomics.  Reduces the
  * loc-Linear and LayerNorm parameter gradients.  partials: fp32 [9][4 * nblk][H], nblk = crct_layernorm_bwd_blocks(B*T)
  * (7 row sets + the sums of token types 0 and 1).
  * n_types = rows of the type table.  All parameter-gradient outputs are ACCUMULATED (caller zeroes per step). */
