@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrct_hip.so")
 
 c_i32, c_i64, c_u32, c_u64, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+FP8_AMAX_LANES = 64          # CRCT_FP8_AMAX_LANES of include/crct_hip.h: fp32 words per amax value
 vp = C.c_void_p
 
 
@@ -87,7 +88,7 @@ PROTOTYPES = {
     "crct_softmax_rows_bf16_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_layernorm_fwd_q": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp, vp, vp, vp]),
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
-    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, vp]),
+    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),

@@ -193,8 +193,8 @@ class CrctModel(nn.Module):
             dev = self._flat_p.device
             st = dict(n_sites=n_sites, weights=weights,
                       q=torch.zeros(self.total, dtype=torch.uint8, device=dev),
-                      w_scale=torch.ones(max(len(weights), 1), device=dev), w_amax=torch.zeros(max(len(weights), 1), device=dev),
-                      a_scale=torch.ones(max(n_sites, 1), device=dev), a_amax=torch.zeros(max(n_sites, 1), device=dev),
+                      w_scale=torch.ones(max(len(weights), 1), device=dev), w_amax=torch.zeros(max(len(weights), 1) * L.FP8_AMAX_LANES, device=dev),
+                      a_scale=torch.ones(max(n_sites, 1), device=dev), a_amax=torch.zeros(max(n_sites, 1) * L.FP8_AMAX_LANES, device=dev),
                       calibrated=False)
             # chunk table over the shadowed weights themselves (one segment per weight, slot = its index)
             lens = [n for _, n in weights]
@@ -222,10 +222,13 @@ class CrctModel(nn.Module):
         st = self._fp8_state(eng)
         return (st["q"], st["w_scale"], st["a_scale"], st["a_amax"])
 
+    FP8_AMAX_WINDOW = 256      # steps between resets of the running activation / weight maxima (see crct_fp8_update_scales)
+
     def _fp8_update_act_scales(self):
         st = self._fp8
-        L.check(L.load().crct_fp8_update_scales(st["a_scale"].data_ptr(), st["a_amax"].data_ptr(), st["n_sites"], L.current_stream()),
-                "fp8_update_scales")
+        st["updates"] = st.get("updates", 0) + 1
+        L.check(L.load().crct_fp8_update_scales(st["a_scale"].data_ptr(), st["a_amax"].data_ptr(), st["n_sites"],
+                                                int(st["updates"] % self.FP8_AMAX_WINDOW == 0), L.current_stream()), "fp8_update_scales")
 
     def _apply(self, fn, recurse=True):
         probe = fn(torch.zeros(1, device=self._flat_p.device))

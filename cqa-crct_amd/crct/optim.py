@@ -190,8 +190,8 @@ class FusedAdamW(torch.optim.Optimizer):
         """Delayed scaling of the weight shadow: the scales this update quantises with come from the amax the previous update saw."""
         if self._fp8_arg() is not None:
             st = self.core._fp8
-            L.check(L.load().crct_fp8_update_scales(st["w_scale"].data_ptr(), st["w_amax"].data_ptr(), len(st["weights"]), stream),
-                    "fp8_update_scales")
+            L.check(L.load().crct_fp8_update_scales(st["w_scale"].data_ptr(), st["w_amax"].data_ptr(), len(st["weights"]),
+                                                    int(self._step % self.core.FP8_AMAX_WINDOW == 0), stream), "fp8_update_scales")
 
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""

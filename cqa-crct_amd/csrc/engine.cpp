@@ -320,7 +320,7 @@ struct Run {
     g.M = M; g.N = l.out; g.K = l.in; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
     g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
-    if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + site_out; }
+    if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; }
     fail(crct_gemm_bf16(&g, s));
   }
   // dW[out][in] += dy^T x
@@ -371,7 +371,7 @@ struct Run {
     if (rc) return;
     ++tick;
     if (f8()) fail(crct_layernorm_fwd_q(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed,
-                                        W<uint8_t>(yq), c->fp8_act_scale + site, c->fp8_act_amax + site, s));
+                                        W<uint8_t>(yq), c->fp8_act_scale + site, c->fp8_act_amax + (int64_t)site * CRCT_FP8_AMAX_LANES, s));
     else fail(crct_layernorm_fwd(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, s));
   }
   // returns the buffer that holds the gradient of the producing Linear's output
@@ -525,7 +525,7 @@ struct Run {
                                       P(e->et.bloc), P(e->et.ln.g), P(e->et.ln.b), A(e->eta.sum), A(e->eta.y), F(e->eta.mean),
                                       F(e->eta.rstd), b->B, b->T, D.H, D.n_pos, 1e-12f, dt.thr, dt.scale, dt.site, c->seed, s));
     if (!rc && f8()) fail(crct_fp8_quantize_bf16(A(e->eta.y), W<uint8_t>(e->eta.yq), c->fp8_act_scale + e->eta.site,
-                                                 c->fp8_act_amax + e->eta.site, (int64_t)b->B * b->T * D.H, s));
+                                                 c->fp8_act_amax + (int64_t)e->eta.site * CRCT_FP8_AMAX_LANES, (int64_t)b->B * b->T * D.H, s));
   }
   void embed_image_fwd() {
     const CrctModelDims& D = e->d;
@@ -538,7 +538,7 @@ struct Run {
                                        P(e->ev.ln.g), P(e->ev.ln.b), A(e->eva.sum), A(e->eva.y), F(e->eva.mean), F(e->eva.rstd),
                                        Mv, D.Hv, 1e-12f, dv.thr, dv.scale, dv.site, c->seed, s));
     if (!rc && f8()) fail(crct_fp8_quantize_bf16(A(e->eva.y), W<uint8_t>(e->eva.yq), c->fp8_act_scale + e->eva.site,
-                                                 c->fp8_act_amax + e->eva.site, (int64_t)Mv * D.Hv, s));
+                                                 c->fp8_act_amax + (int64_t)e->eva.site * CRCT_FP8_AMAX_LANES, (int64_t)Mv * D.Hv, s));
   }
   void embed_text_bwd(size_t gt) {
     const CrctModelDims& D = e->d;
@@ -645,9 +645,6 @@ struct Run {
     const int B = b->B;
     const int64_t ldt = (int64_t)b->T * D.H, ldv = (int64_t)b->V * D.Hv;
     const size_t* g = e->ha.g;
-    static const bool inline_wgrads = getenv("CRCT_HEADS_INLINE") != nullptr;      // developer A/B: weight gradients of the heads in order on the data streams
-    struct Guard { Run* a; Run* b; hipStream_t ka, kb; ~Guard() { a->sw = ka; b->sw = kb; a->defer_wgrad = b->defer_wgrad = true; } } guard{this, &V, sw, V.sw};
-    if (inline_wgrads) { flush_wgrads(); V.flush_wgrads(); sw = s; V.sw = V.s; defer_wgrad = V.defer_wgrad = false; }
     // the loss kernel is re-run with gradient outputs enabled (cheap: B rows) so that forward can be called alone for evaluation
     {
       CrctHeadArgs h;

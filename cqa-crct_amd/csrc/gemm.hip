@@ -1145,7 +1145,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   // CRCT_GEMM_F8=<stages> forces one of them
   if (g.fp8) {
     static const int ov = env_cfg("CRCT_GEMM_F8");
-    t = (ov == 2 || ov == 3) ? 18 + ov : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
+    t = (g.tile == 20 || g.tile == 21) ? g.tile : (ov == 2 || ov == 3) ? 18 + ov : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   }
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)

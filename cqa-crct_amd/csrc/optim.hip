@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
   if (qslot >= 0) {          // fp8-shadowed tensors are multiples of 4 elements (Linear weights): the scalar tail never holds them
     qmax = wave_max(qmax);
-    if ((threadIdx.x & 63) == 0) amax_update(f8.amax + qslot, qmax);
+    if ((threadIdx.x & 63) == 0) amax_update(f8.amax + (long)qslot * CRCT_FP8_AMAX_LANES, qmax);
   }
  }
 }

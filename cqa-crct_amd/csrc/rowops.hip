@@ -373,35 +373,35 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
 // table is touched by <= B*T rows, most ids occur once, [PAD] / [CLS] / [SEP] a few hundred times: the result is bitwise
 // reproducible, which the atomics were not (arrival-order rounding: 1 of ~12 runs ended a 38-step training run on a
 // different loss, round-2 tools/det_check.sh).
-__global__ __launch_bounds__(64) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
-                                                          float* __restrict__ table) {
-  const int r = blockIdx.x, lane = threadIdx.x;
-  const int64_t id = ids[r];
+// One workgroup of 4 waves serves 4 consecutive token rows (one wave each); the ids of ALL rows sit in LDS (int32, one
+// coalesced pass), so the scans are LDS reads.  A wave keeps its whole output row in registers (H / 64 columns per lane, 16-byte
+// pieces) and walks the matching rows ONCE.
+template <int NCH>
+__global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
+                                                           float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* sid = reinterpret_cast<int*>(smem);               // [M]
+  for (int i = threadIdx.x; i < M; i += 256) sid[i] = (int)ids[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const int id = sid[r];
   bool earlier = false;
-  for (int i = lane; i < r; i += 64) earlier |= ids[i] == id;
-  if (__ballot(earlier) != 0ull) return;
-  float* dst = table + id * (long)H;
-  for (int c0 = 0; c0 < H; c0 += 256) {                  // 4 columns per lane per pass, accumulators in registers
-    const int c = c0 + lane * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = r & ~63; base < M; base += 64) {
-      const int i = base + lane;
-      unsigned long long m = __ballot(i >= r && i < M && ids[i] == id);
-      while (m) {
-        const int j = base + __builtin_ctzll(m);
-        m &= m - 1;
-        if (c < H) {
-          const float4 x = *reinterpret_cast<const float4*>(rows + (long)j * H + c);
-          acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-        }
-      }
-    }
-    if (c < H) {
-      float4 o = *reinterpret_cast<float4*>(dst + c);
-      o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-      *reinterpret_cast<float4*>(dst + c) = o;
+  for (int i = lane; i < r; i += 64) earlier |= sid[i] == id;
+  if (__ballot(earlier) != 0ull) return;                 // an earlier row owns this table row
+  Row<NCH> acc;
+  row_zero(acc);
+  for (int base = r & ~63; base < M; base += 64) {
+    const int i = base + lane;
+    unsigned long long m = __ballot(i >= r && i < M && sid[i] == id);
+    while (m) {                                          // increasing row order: a fixed summation order
+      const int j = base + __builtin_ctzll(m);
+      m &= m - 1;
+      row_add_f32(acc, rows + (long)j * H, H, lane);
     }
   }
+  row_add_f32(acc, table + (long)id * H, H, lane);
+  row_store_f32(acc, table + (long)id * H, H, lane);
 }
 
 // ------------------------------------------------------------------------------ LayerNorm fwd
@@ -1041,19 +1041,24 @@ __global__ __launch_bounds__(256) void fp8_weights_kernel(const float* __restric
     }
     if (MODE == 0) {
       am = wave_max(am);
-      if ((threadIdx.x & 63) == 0) amax_update(amax + slot, am);
+      if ((threadIdx.x & 63) == 0) amax_update(amax + (long)slot * CRCT_FP8_AMAX_LANES, am);
     }
   }
 }
-// delayed scaling: scale[i] = 448 / amax[i] for the entries that saw data, amax[i] = 0 for the next round
-__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const float a = amax[i];
-    if (a > 0.f) scale[i] = 448.0f / a;
-    amax[i] = 0.f;
+// delayed scaling: scale[i] = 448 / max(amax[i][0 .. LANES)) for the entries that saw data.  The maxima are RUNNING maxima
+// (reset != 0 clears them: the caller does that every few hundred steps, the "max over a history window" of the usual fp8
+// recipes): a wave only issues an atomic when it raises the word it reports into, so after the first steps of a window the
+// kernels issue none at all -- resetting every step cost 2.4 ms per step in atomic storms (round-2 measurement).
+__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n, int reset) {
+  const int i = blockIdx.x * (blockDim.x / CRCT_FP8_AMAX_LANES) + threadIdx.x / CRCT_FP8_AMAX_LANES, l = threadIdx.x % CRCT_FP8_AMAX_LANES;
+  if (i < n) {          // one wave (64 lanes = LANES) per entry
+    float* w = amax + (long)i * CRCT_FP8_AMAX_LANES + l;
+    const float a = wave_max(*w);
+    if (reset) *w = 0.f;
+    if (l == 0 && a > 0.f) scale[i] = 448.0f / a;
   }
 }
+
 }  // namespace
 
 extern "C" {
@@ -1067,10 +1072,10 @@ int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* am
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int crct_fp8_update_scales(float* scale, float* amax, int n, crct_stream_t stream) {
+int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, crct_stream_t stream) {
   CRCT_REQUIRE(scale && amax && n >= 0, "fp8_update_scales: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scale, amax, n);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1081,10 +1086,10 @@ int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, c
   if (n_blk <= 0 || n_slots <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int grid = n_blk > 2048 ? 2048 : (int)n_blk;
-  CRCT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)n_slots * 4, s));
+  CRCT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)n_slots * CRCT_FP8_AMAX_LANES * 4, s));
   hipLaunchKernelGGL(fp8_weights_kernel<0>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, scale, amax, n_slots);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0);
   hipLaunchKernelGGL(fp8_weights_kernel<1>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
@@ -1141,7 +1146,8 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
     hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s,
                        rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
     CRCT_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(word_scatter_kernel, dim3((int)M), dim3(64), 0, s, (const float*)rows_scratch, ids, (int)M, H, d_word);
+    DISPATCH_NCH(H, hipLaunchKernelGGL((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
+                                       (size_t)M * sizeof(int), s, (const float*)rows_scratch, ids, (int)M, H, d_word));
     CRCT_CHECK_HIP(hipGetLastError());
   }
   FinalizeArgs fa = {};

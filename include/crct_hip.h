@@ -105,15 +105,21 @@ int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, v
                          uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                          void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream);
 
+/* Every amax "value" below and in CrctGemmArgs / CrctStepCfg / CrctFp8Shadow is CRCT_FP8_AMAX_LANES consecutive fp32 words
+ * (the kernels spread their atomic maxima over them; crct_fp8_update_scales takes the maximum of the words): an amax array
+ * for n tensors has n * CRCT_FP8_AMAX_LANES words and entry i starts at word i * CRCT_FP8_AMAX_LANES. */
+#define CRCT_FP8_AMAX_LANES 64
 /* fp8 (OCP e4m3, per-tensor delayed scaling) helpers.  All scales / amax values are device fp32.
  *  crct_fp8_quantize_bf16   q[i] = e4m3(x[i] * *scale), *amax = max(*amax, max |x|)            (n % 8 == 0)
- *  crct_fp8_update_scales   scale[i] = 448 / amax[i] where amax[i] > 0; amax[i] = 0            (once per step per table)
+ *  crct_fp8_update_scales   scale[i] = 448 / amax[i] where amax[i] > 0; reset != 0 also clears amax[i].  The amax values are
+ *                           RUNNING maxima: call it once per step with reset = 0 and every few hundred steps with reset = 1
+ *                           (a history window); clearing every step makes every wave of every producer issue an atomic
  *  crct_fp8_quantize_weights  exact per-tensor scaling of fp32 weights into the flat e4m3 shadow (same element offsets as
  *                           the fp32 buffer): tensors (seg_off, seg_len) with scale slot seg_slot[s] >= 0, chunk table
  *                           (blk_seg, blk_off) from crct_adamw_plan; writes scale[slot] = 448 / max |w|.  Used at start-up
  *                           and after a load_state_dict; the optimizer keeps the shadow current afterwards (CrctFp8Shadow). */
 int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* amax, int64_t n, crct_stream_t stream);
-int crct_fp8_update_scales(float* scale, float* amax, int n, crct_stream_t stream);
+int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, crct_stream_t stream);
 int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, const int64_t* seg_len, const int32_t* seg_slot,
                               const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk, float* scale, float* amax, int n_slots,
                               crct_stream_t stream);

@@ -384,11 +384,11 @@ def test_gemm_fp8_forward(M, N, K):
     q_out = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
     href = torch.nn.functional.gelu(ref)
     qs = torch.tensor([448.0 / float(href.abs().max()) * 0.9], device=DEV)
-    amax = torch.zeros(1, device=DEV)
+    amax = torch.zeros(L.FP8_AMAX_LANES, device=DEV)      # an amax value = LANES words, the kernels spread their atomics over them
     h = ops.gemm_fp8(xq, wq, sa_d, sb_d, M, N, K, bias=b, act="gelu", preact_out=pre, q_out=q_out, q_scale=qs, q_amax=amax)
     assert float((pre.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
     assert float((h.float() - href).abs().max()) <= 1e-2 * float(href.abs().max())
-    assert abs(float(amax) - float(href.abs().max())) <= 1e-2 * float(href.abs().max())
+    assert abs(float(amax.max()) - float(href.abs().max())) <= 1e-2 * float(href.abs().max())
     deq = q_out.view(torch.float8_e4m3fn).float() / float(qs)
     # e4m3 keeps 3 mantissa bits: relative error <= 2^-4 of the value (plus the subnormal step near zero)
     tol = 0.0625 * href.abs() + 0.002 / float(qs) + 1e-2 * float(href.abs().max())       # + the subnormal step, + the kernel's own bf16-level differences
@@ -400,22 +400,22 @@ def test_fp8_quantisers_and_layernorm_copy():
     # bf16 -> e4m3 pass
     x = (torch.randn(1600 * 768, device=DEV) * 2).to(torch.bfloat16)
     q = torch.zeros(x.numel(), device=DEV, dtype=torch.uint8)
-    sc, am = torch.tensor([17.0], device=DEV), torch.zeros(1, device=DEV)
+    sc, am = torch.tensor([17.0], device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV)
     L.check(lib.crct_fp8_quantize_bf16(x.data_ptr(), q.data_ptr(), sc.data_ptr(), am.data_ptr(), x.numel(), L.current_stream()))
     assert torch.equal(q.view(torch.float8_e4m3fn).float(), _q8(x, 17.0).float())
-    assert float(am) == float(x.float().abs().max())
-    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, L.current_stream()))
-    assert abs(float(sc) - 448.0 / float(x.float().abs().max())) < 1e-4 * float(sc) and float(am) == 0.0
+    assert float(am.max()) == float(x.float().abs().max())
+    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, L.current_stream()))
+    assert abs(float(sc) - 448.0 / float(x.float().abs().max())) < 1e-4 * float(sc) and float(am.abs().max()) == 0.0
     # LayerNorm with the e4m3 copy: the copy is the quantisation of the bf16 output the kernel stores
     xs = (torch.randn(1600, 768, device=DEV)).to(torch.bfloat16)
     gamma, beta = torch.rand(768, device=DEV) + 0.5, torch.randn(768, device=DEV) * 0.1
     y = torch.empty_like(xs)
     mean, rstd = torch.empty(1600, device=DEV), torch.empty(1600, device=DEV)
     yq = torch.zeros(1600, 768, device=DEV, dtype=torch.uint8)
-    sc2, am2 = torch.tensor([30.0], device=DEV), torch.zeros(1, device=DEV)
+    sc2, am2 = torch.tensor([30.0], device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV)
     L.check(lib.crct_layernorm_fwd_q(xs.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                      1600, 768, 1e-12, 0, 1.0, 0, 0, yq.data_ptr(), sc2.data_ptr(), am2.data_ptr(), L.current_stream()))
     y_plain, _, _ = ops.layernorm_fwd(xs, gamma, beta)
     assert torch.equal(y, y_plain)
     assert torch.equal(yq.view(torch.float8_e4m3fn).float(), _q8(y, 30.0).float())
-    assert float(am2) == float(y.float().abs().max())
+    assert float(am2.max()) == float(y.float().abs().max())

@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < maxel; ++i) { float f = (rand() / (float)RAND_MAX - 0.5f); unsigned u; memcpy(&u, &f, 4); h[i] = u >> 16; }
   hipMemcpy(B, h.data(), maxel * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float* scales; hipMalloc(&scales, 8); { float h2[2] = {1.f, 1.f}; hipMemcpy(scales, h2, 8, hipMemcpyHostToDevice); }
   const size_t pool_bytes = cold ? (size_t)640 << 20 : 0;
   char* poolB = nullptr; char* poolA = nullptr;
   if (cold) {
@@ -70,10 +71,15 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     if (f32) { hr.resize(nout); hipMemcpy(hr.data(), Cref, nout * 4, hipMemcpyDeviceToHost); }
     else { hrb.resize(nout); hipMemcpy(hrb.data(), Cref, nout * 2, hipMemcpyDeviceToHost); }
-    for (int tile = first_tile; tile < 64; ++tile) {
-      if (tile >= 16 && tile < 32) continue;
+    for (int tile = first_tile; tile < 22; ++tile) {
+      if (tile >= 16 && tile < 20) continue;
       if (only_tile >= 0 && tile != only_tile) continue;
       CrctGemmArgs g = make(tile, C);
+      const bool f8 = tile >= 20;          // fp8 forward kernel (2 / 3 stages): same byte buffers read as e4m3, timing only
+      if (f8) {
+        if (s.ta || s.tb || s.K % 128) continue;
+        g.fp8 = 1; g.scale_a = scales; g.scale_b = scales + 1; g.tile = tile; g.lda = s.K; g.ldb = s.K;
+      }
       hipMemset(C, 0xff, nout * (f32 ? 4 : 2));
       if (crct_gemm_bf16(&g, 0) != 0) { (void)hipGetLastError(); continue; }      // configuration not built for this mode
       if (hipDeviceSynchronize() != hipSuccess) { printf("tile %d: launch failed: %s\n", tile, hipGetErrorString(hipGetLastError())); return 1; }
@@ -93,7 +99,7 @@ int main(int argc, char** argv) {
       float ms; hipEventElapsedTime(&ms, e0, e1);
       double us = ms * 1e3 / iters, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
       printf("%s M=%5d N=%5d K=%5d tile=%2d  %8.2f us  %7.1f TF  maxdiff %.3g%s\n", s.name, s.M, s.N, s.K, tile, us, tf, maxd,
-             maxd > 0.26 ? "  <-- MISMATCH" : "");
+             (maxd > 0.26 && !f8) ? "  <-- MISMATCH" : "");
       fflush(stdout);
     }
   }
