@@ -293,6 +293,8 @@ def main():
                "bytes_per_step_per_gpu": int(sum(v.numel() * (feat_bytes if k == "image_feat" else v.element_size())
                                                  for k, v in host_pool[0].items()))}
         cur["feed"] = feed_of("resident")
+        prefetcher.close()                       # ends the worker thread (a suspended generator would keep it until exit)
+        prefetcher = None
 
     comm = None
     if world > 1:
@@ -335,6 +337,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(core, cfg, params, a.cpu_batch, a.tokens, a.vis, a.feat)
         print(json.dumps(out), flush=True)
+    if prefetcher is not None:
+        prefetcher.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -158,3 +158,4 @@ class DevicePrefetcher(object):
                 yield dev_batch
         finally:
             free.put(_END)
+            worker.join(timeout=10.0)          # the worker must be gone before the interpreter tears the HIP runtime down

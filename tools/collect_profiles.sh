@@ -17,4 +17,6 @@ python $R/tools/trace_timeline.py $(find /tmp/ks -name "*kernel_trace.csv" | hea
 cd $R
 python tools/step_phases.py > $O/${tag}_step_phases.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench_n1.err
+python bench.py --steps 20 --warmup 5 --dtype fp8 --no-cpu-baseline > $O/${tag}_bench_n1_fp8.json 2> $O/${tag}_bench_n1_fp8.err
+python bench.py --steps 20 --warmup 5 --batch 64 --vis 100 --tokens 40 --no-cpu-baseline > $O/${tag}_bench_n1_longctx.json 2> $O/${tag}_bench_n1_longctx.err
 tail -c 1500 $O/${tag}_bench_n1.json
