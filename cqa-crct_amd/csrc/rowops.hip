@@ -313,7 +313,7 @@ __device__ __forceinline__ void row_store_f32(const Row<NCH>& r, float* p, int H
 // table row: the 256 threads scan idx in a fixed strided order, compact the matching row numbers into LDS through a
 // block prefix sum (a fixed order: the result does not depend on timing), then every thread sums its 4 columns over
 // the listed rows.  M <= GATHER_MAX_ROWS.
-constexpr int GATHER_MAX_ROWS = 16384;
+constexpr int GATHER_MAX_ROWS = 15360;     // 4 bytes per row + the 1 KiB of counts stay under the default 64 KiB of dynamic LDS
 // Two tables in one launch: workgroups [0, n0) serve (idx, table), the rest (idx1, table1).
 __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
                                                          float* __restrict__ table, int n0, const int* __restrict__ idx1,
@@ -375,33 +375,103 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
 // different loss, round-2 tools/det_check.sh).
 // One workgroup of 4 waves serves 4 consecutive token rows (one wave each); the ids of ALL rows sit in LDS (int32, one
 // coalesced pass), so the scans are LDS reads.  A wave keeps its whole output row in registers (H / 64 columns per lane, 16-byte
-// pieces) and walks the matching rows ONCE.
+// pieces).  Light ids (<= WORD_HEAVY matches, nearly all of them) are summed by the owning wave alone.  A heavy id ([PAD]: a few
+// hundred rows) would leave one wave walking hundreds of dependent 3 KB loads while the chip idles (106 us in the round-2
+// timeline), so its workgroup shares it: the owner lists the matches in LDS, match e goes to wave (e / 4) % 4, accumulator e % 4
+// (four independent rows in flight per wave), and the 4 x 4 partial rows are folded in a fixed tree -- still bit-reproducible.
+constexpr int WORD_HEAVY = 8;
 template <int NCH>
 __global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
                                                            float* __restrict__ table) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sid = reinterpret_cast<int*>(smem);               // [M]
+  int* list = sid + M;                                   // [M]   matches of a heavy id
+  float* part = reinterpret_cast<float*>(sid + ((2 * M + 3) & ~3));      // [4][H] per-wave partial rows of a heavy id
+  __shared__ int s_cnt[ROWS_PER_BLOCK];
   for (int i = threadIdx.x; i < M; i += 256) sid[i] = (int)ids[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, r = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (r >= M) return;
-  const int id = sid[r];
-  bool earlier = false;
-  for (int i = lane; i < r; i += 64) earlier |= sid[i] == id;
-  if (__ballot(earlier) != 0ull) return;                 // an earlier row owns this table row
-  Row<NCH> acc;
-  row_zero(acc);
-  for (int base = r & ~63; base < M; base += 64) {
-    const int i = base + lane;
-    unsigned long long m = __ballot(i >= r && i < M && sid[i] == id);
-    while (m) {                                          // increasing row order: a fixed summation order
-      const int j = base + __builtin_ctzll(m);
-      m &= m - 1;
-      row_add_f32(acc, rows + (long)j * H, H, lane);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.x * ROWS_PER_BLOCK + w;
+  const int id = r < M ? sid[r] : -1;
+  bool earlier = r >= M;
+  for (int i = lane; i < r && i < M; i += 64) earlier |= sid[i] == id;
+  const bool own = __ballot(earlier) == 0ull;            // no earlier row carries this id: this wave owns the table row
+  int cnt = 0;
+  if (own)
+    for (int base = r & ~63; base < M; base += 64) {
+      const int i = base + lane;
+      cnt += __builtin_popcountll(__ballot(i >= r && i < M && sid[i] == id));
     }
+  if (lane == 0) s_cnt[w] = cnt;
+  __syncthreads();
+  if (own && cnt <= WORD_HEAVY) {
+    Row<NCH> acc;
+    row_zero(acc);
+    for (int base = r & ~63; base < M; base += 64) {
+      const int i = base + lane;
+      unsigned long long m = __ballot(i >= r && i < M && sid[i] == id);
+      while (m) {                                        // increasing row order: a fixed summation order
+        const int j = base + __builtin_ctzll(m);
+        m &= m - 1;
+        row_add_f32(acc, rows + (long)j * H, H, lane);
+      }
+    }
+    row_add_f32(acc, table + (long)id * H, H, lane);
+    row_store_f32(acc, table + (long)id * H, H, lane);
   }
-  row_add_f32(acc, table + (long)id * H, H, lane);
-  row_store_f32(acc, table + (long)id * H, H, lane);
+  for (int k = 0; k < ROWS_PER_BLOCK; ++k) {             // workgroup-uniform: s_cnt is shared
+    const int n = s_cnt[k];
+    if (n <= WORD_HEAVY) continue;
+    const int rk = blockIdx.x * ROWS_PER_BLOCK + k, idk = sid[rk];
+    if (w == k) {
+      int at = 0;
+      for (int base = rk & ~63; base < M; base += 64) {
+        const int i = base + lane;
+        const bool hit = i >= rk && i < M && sid[i] == idk;
+        const unsigned long long m = __ballot(hit);
+        if (hit) list[at + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        at += __builtin_popcountll(m);
+      }
+    }
+    __syncthreads();
+    Row<NCH> a0, a1, a2, a3;
+    row_zero(a0); row_zero(a1); row_zero(a2); row_zero(a3);
+    int e = w * 4;
+    for (; e + 3 < n; e += 16) {
+      const int j0 = list[e], j1 = list[e + 1], j2 = list[e + 2], j3 = list[e + 3];
+      row_add_f32(a0, rows + (long)j0 * H, H, lane);
+      row_add_f32(a1, rows + (long)j1 * H, H, lane);
+      row_add_f32(a2, rows + (long)j2 * H, H, lane);
+      row_add_f32(a3, rows + (long)j3 * H, H, lane);
+    }
+    if (e < n) row_add_f32(a0, rows + (long)list[e] * H, H, lane);
+    if (e + 1 < n) row_add_f32(a1, rows + (long)list[e + 1] * H, H, lane);
+    if (e + 2 < n) row_add_f32(a2, rows + (long)list[e + 2] * H, H, lane);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a0.v[i][j] = (a0.v[i][j] + a1.v[i][j]) + (a2.v[i][j] + a3.v[i][j]);
+    row_store_f32(a0, part + (long)w * H, H, lane);
+    __syncthreads();
+    if (w == k) {
+      Row<NCH> t, u;
+      row_load_f32(t, part, H, lane);
+      row_load_f32(u, part + H, H, lane);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.v[i][j] += u.v[i][j];
+      row_load_f32(u, part + 2 * (long)H, H, lane);
+      Row<NCH> v;
+      row_load_f32(v, part + 3 * (long)H, H, lane);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.v[i][j] += u.v[i][j] + v.v[i][j];
+      row_add_f32(t, table + (long)idk * H, H, lane);
+      row_store_f32(t, table + (long)idk * H, H, lane);
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------ LayerNorm fwd
@@ -1146,8 +1216,18 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
     hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s,
                        rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
     CRCT_CHECK_HIP(hipGetLastError());
-    DISPATCH_NCH(H, hipLaunchKernelGGL((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
-                                       (size_t)M * sizeof(int), s, (const float*)rows_scratch, ids, (int)M, H, d_word));
+    const size_t word_lds = (size_t)((2 * M + 3) & ~3L) * sizeof(int) + (size_t)ROWS_PER_BLOCK * H * sizeof(float);
+    CRCT_REQUIRE(word_lds <= 152 * 1024, "embed_text_bwd: B*T=%ld rows need %zu bytes of LDS for the word-gradient scan", M, word_lds);
+    DISPATCH_NCH(H, {
+      static bool big_lds = false;                         // ids + match list of every row: above 64 KiB from ~6 600 rows on
+      if (word_lds > 64 * 1024 && !big_lds) {
+        CRCT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&word_scatter_kernel<NCH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        big_lds = true;
+      }
+      hipLaunchKernelGGL((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
+                         (const float*)rows_scratch, ids, (int)M, H, d_word);
+    });
     CRCT_CHECK_HIP(hipGetLastError());
   }
   FinalizeArgs fa = {};

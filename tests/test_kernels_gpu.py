@@ -419,3 +419,56 @@ def test_fp8_quantisers_and_layernorm_copy():
     assert torch.equal(y, y_plain)
     assert torch.equal(yq.view(torch.float8_e4m3fn).float(), _q8(y, 30.0).float())
     assert float(am2.max()) == float(y.float().abs().max())
+
+
+# ------------------------------------------------------------------------------------------- word-gradient scan
+@pytest.mark.parametrize("B,T", [(80, 20), (7, 9), (64, 40)])
+def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T, gemm_path):
+    """crct_embed_text_bwd's word_embeddings gradient (index_add of the token-row gradients, vilbert.py:300 has no padding_idx, so
+    [PAD] collects every padded position): the fixed-order scan -- light ids by one wave, heavy ids shared by the workgroup --
+    against the same launcher's float-atomics fall-back (rows_scratch = NULL), and bit-identical when repeated."""
+    if gemm_path != "pipelined":
+        pytest.skip("no GEMM in this test")
+    lib = L.load()
+    H, V, n_pos, n_types = 768, 500, 64, 2
+    M = B * T
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + T)
+    ids = torch.randint(3, V, (B, T), generator=g)
+    ids[:, 0] = 1                                          # [CLS]-like: B matches
+    ids[:, T // 2:] = 0                                    # [PAD]-like: half of all rows -> the heavy path
+    ids[0, 1:4] = 2                                        # 3 matches -> the light path with repeats
+    ids = ids.to(DEV)
+    segs = torch.randint(0, n_types, (B, T), generator=g).to(DEV)
+    loc = torch.rand(B, T, 4, generator=g).to(DEV)
+    dy, saved = bf(rand(M, H, seed=1)), bf(rand(M, H, seed=2))
+    mean, rstd = rand(M, seed=3), rand(M, seed=4).abs() + 0.5
+    gamma = rand(H, seed=5)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(deterministic):
+        d_word = torch.zeros(V, H, device=DEV)
+        d_pos, d_type = torch.zeros(n_pos, H, device=DEV), torch.zeros(n_types, H, device=DEV)
+        d_wloc, d_bloc = torch.zeros(H, 4, device=DEV), torch.zeros(H, device=DEV)
+        d_g, d_b = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        partials = torch.zeros(10 * 4 * 256 * H, device=DEV)
+        rows = torch.zeros(M, H, device=DEV)
+        idx = torch.zeros(2 * M, dtype=torch.int32, device=DEV)
+        rc = lib.crct_embed_text_bwd(dy.data_ptr(), saved.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ids.data_ptr(),
+                                     segs.data_ptr(), loc.data_ptr(), gamma.data_ptr(), d_word.data_ptr(), d_pos.data_ptr(),
+                                     d_type.data_ptr(), d_wloc.data_ptr(), d_bloc.data_ptr(), d_g.data_ptr(), d_b.data_ptr(),
+                                     partials.data_ptr(), B, T, H, n_pos, 0, 1.0, 0, 0,
+                                     rows.data_ptr() if deterministic else None, idx.data_ptr(), n_types, stream)
+        L.check(rc, "embed_text_bwd")
+        torch.cuda.synchronize()
+        return d_word, d_pos, d_type
+
+    w_atomic, p_atomic, t_atomic = run(False)
+    w1, p1, t1 = run(True)
+    w2, p2, t2 = run(True)
+    assert torch.equal(w1, w2) and torch.equal(p1, p2) and torch.equal(t1, t2)
+    assert float(w1[0].abs().max()) > 0 and float(w1[V - 1].abs().max()) >= 0
+    for a, b in ((w1, w_atomic), (p1, p_atomic), (t1, t_atomic)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+    untouched = torch.ones(V, dtype=torch.bool, device=DEV)
+    untouched[ids.flatten()] = False
+    assert float(w1[untouched].abs().max()) == 0.0
