@@ -34,6 +34,26 @@ __device__ __forceinline__ void row_load_bf16(Row<NCH>& r, const bf16_t* p, int 
     r.v[i][6] = bf2f((bf16_t)(w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(w >> 16));
   }
 }
+// the two halves of row_load_bf16, for loops that keep the NEXT row's loads in flight while they work on the current one
+template <int NCH>
+struct RawRow { uint4 u[NCH]; };
+template <int NCH>
+__device__ __forceinline__ void row_fetch_bf16(RawRow<NCH>& raw, const bf16_t* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) raw.u[i] = *reinterpret_cast<const uint4*>(p + min((lane + 64 * i) * 8, H - 8));
+}
+template <int NCH>
+__device__ __forceinline__ void row_unpack_bf16(Row<NCH>& r, const RawRow<NCH>& raw, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const uint32_t m = (lane + 64 * i) * 8 < H ? 0xffffffffu : 0u;
+    const uint32_t x = raw.u[i].x & m, y = raw.u[i].y & m, z = raw.u[i].z & m, w = raw.u[i].w & m;
+    r.v[i][0] = bf2f((bf16_t)(x & 0xffff)); r.v[i][1] = bf2f((bf16_t)(x >> 16));
+    r.v[i][2] = bf2f((bf16_t)(y & 0xffff)); r.v[i][3] = bf2f((bf16_t)(y >> 16));
+    r.v[i][4] = bf2f((bf16_t)(z & 0xffff)); r.v[i][5] = bf2f((bf16_t)(z >> 16));
+    r.v[i][6] = bf2f((bf16_t)(w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(w >> 16));
+  }
+}
 template <int NCH>
 __device__ __forceinline__ void row_store_bf16(const Row<NCH>& r, bf16_t* p, int H, int lane) {
 #pragma unroll
@@ -518,11 +538,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   Row<NCH> adg, adb, adl, g;
   row_zero(adg); row_zero(adb); row_zero(adl);
   row_load_f32(g, gamma, H, lane);
-  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+  // M / (4 x grid) is 1.6 rows per wave at the CRCT sizes: the second row's loads are issued before the first row is worked on
+  const long stride = (long)gridDim.x * ROWS_PER_BLOCK;
+  long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+  RawRow<NCH> dy_n, x_n;
+  float mean_n = 0.f, rstd_n = 0.f;
+  if (row < M) {
+    row_fetch_bf16(dy_n, dy_p + row * H, H, lane);
+    row_fetch_bf16(x_n, x_p + row * H, H, lane);
+    mean_n = mean_p[row]; rstd_n = rstd_p[row];
+  }
+  for (; row < M; row += stride) {
     Row<NCH> dy, x;
-    const float mean = mean_p[row], rstd = rstd_p[row];
-    row_load_bf16(dy, dy_p + row * H, H, lane);
-    row_load_bf16(x, x_p + row * H, H, lane);
+    const float mean = mean_n, rstd = rstd_n;
+    row_unpack_bf16(dy, dy_n, H, lane);
+    row_unpack_bf16(x, x_n, H, lane);
+    if (row + stride < M) {
+      row_fetch_bf16(dy_n, dy_p + (row + stride) * H, H, lane);
+      row_fetch_bf16(x_n, x_p + (row + stride) * H, H, lane);
+      mean_n = mean_p[row + stride]; rstd_n = rstd_p[row + stride];
+    }
     row_apply_dropmask(dy, H, lane, row, post_thr, post_scale, post_site, seed);
     row_ln_bwd(dy, x, g, H, lane, mean, rstd, adg, adb);
     row_store_bf16(dy, dx_p + row * H, H, lane);
