@@ -63,6 +63,7 @@ class StepEngine(object):
         self.logits = self.out[self.NS + 5 * B:].view(B, 2)
         self._keep = None
         self._owned_key = None
+        self._staged, self._op_handle = None, None
 
     def __del__(self):
         try:
@@ -133,7 +134,27 @@ class StepEngine(object):
             self._owned_key = (tuple(off[:n]), tuple(num[:n]))
         return self._owned_key
 
+    # -- the two engine calls go through the registered torch ops (torch.ops.crct.step_forward / step_backward, crct/torch_ops.py);
+    #    the step configuration holds scalars, event handles and fp8 state, so it is staged here rather than passed as tensors
+    def staged_step(self):
+        return self._staged
+
     def forward(self, p32, p16, tensors, step):
+        from . import torch_ops as T
+        if self._op_handle is None:
+            self._op_handle = T.engine_handle(self)
+        self._staged = step
+        torch.ops.crct.step_forward(self._op_handle, p32, p16, T.pack_batch(tensors))
+        return self.outputs_of(self.out, tensors["tokens"].shape[0])
+
+    def backward(self, p32, p16, g32, tensors, step, seg=-1):
+        from . import torch_ops as T
+        if self._op_handle is None:
+            self._op_handle = T.engine_handle(self)
+        self._staged = step
+        torch.ops.crct.step_backward(self._op_handle, p32, p16, g32, T.pack_batch(tensors), int(seg))
+
+    def forward_native(self, p32, p16, tensors, step):
         B = tensors["tokens"].shape[0]
         b, c = self._batch(tensors), self._cfg(step)
         self._keep = (tensors, step)
@@ -151,7 +172,7 @@ class StepEngine(object):
         """The step outputs as tensors of their own (ONE copy kernel): the engine rewrites its buffer on the next call."""
         return self.outputs_of(self.out.clone(), B)
 
-    def backward(self, p32, p16, g32, tensors, step, seg=-1):
+    def backward_native(self, p32, p16, g32, tensors, step, seg=-1):
         b, c = self._batch(tensors), self._cfg(step)
         L.check(self.lib.crct_engine_backward(self.handle, p32.data_ptr(), p16.data_ptr(), C.byref(b), C.byref(c),
                                               self.workspace.data_ptr(), g32.data_ptr(), self.logits.data_ptr(),
