@@ -48,6 +48,18 @@ class Batch(C.Structure):
                 ("sep_indices", vp), ("hist_len", vp), ("image_mask", vp), ("sep_stride", c_i32), ("image_feat_bf16", c_i32)]
 
 
+class LnFwdArgs(C.Structure):
+    _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("mean", vp), ("rstd", vp), ("M", c_i32), ("H", c_i32),
+                ("eps", c_f32), ("drop_thr", c_u32), ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64),
+                ("q_out", vp), ("q_scale", vp), ("q_amax", vp)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("dy", vp), ("x", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("dx", vp), ("dx_lin", vp), ("partials", vp),
+                ("M", c_i32), ("H", c_i32), ("post_thr", c_u32), ("post_scale", c_f32), ("post_site", c_u32),
+                ("lin_thr", c_u32), ("lin_scale", c_f32), ("lin_site", c_u32), ("seed", c_u64)]
+
+
 class AmpState(C.Structure):
     _fields_ = [("grad_scale", vp), ("found_inf", vp), ("step", vp)]
 
@@ -87,6 +99,8 @@ PROTOTYPES = {
     "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_bf16_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_layernorm_fwd_q": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp, vp, vp, vp]),
+    "crct_layernorm_fwd_pair": (C.c_int, [C.POINTER(LnFwdArgs), C.POINTER(LnFwdArgs), vp]),
+    "crct_layernorm_bwd_rows_pair": (C.c_int, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), vp]),
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
     "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
@@ -111,6 +125,7 @@ PROTOTYPES = {
     "crct_engine_forward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp]),
     "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
     "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
+    "crct_engine_set_pairing": (C.c_int, [vp, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_engine_fp8_sites": (C.c_int, [vp]),
     "crct_engine_fp8_weights": (C.c_int, [vp, vp, vp, C.c_int]),

@@ -30,14 +30,12 @@ def _drop(p, site):
     return thr, (1.0 / (1.0 - p) if thr else 1.0), int(site)
 
 
-def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
-         preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
-         accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None):
-    lib = L.load()
+def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
+               preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
+               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None):
     _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    g = L.GemmArgs()
     g.A, g.B, g.C = L.ptr(A), L.ptr(B), L.ptr(out)
     g.bias, g.preact_out, g.dact_src, g.addend = L.ptr(bias), L.ptr(preact_out), L.ptr(dact_src), L.ptr(addend)
     g.lda = lda if lda is not None else (M if ta else K)
@@ -50,8 +48,24 @@ def gemm(A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=No
     g.drop_thr, g.drop_scale, g.drop_site = _drop(p_drop, site)
     g.seed = seed
     g.rowsum_out = L.ptr(rowsum_out)
-    L.check(lib.crct_gemm_bf16(C.byref(g), L.current_stream()), "gemm")
     return out
+
+
+def gemm(A, B, M, N, K, **kw):
+    """One GEMM with its fused epilogue (keyword arguments: see ``_gemm_args``)."""
+    g = L.GemmArgs()
+    out = _gemm_args(g, A, B, M, N, K, **kw)
+    L.check(L.load().crct_gemm_bf16(C.byref(g), L.current_stream()), "gemm")
+    return out
+
+
+def gemm_grouped(problems):
+    """``problems`` = [dict(A=, B=, M=, N=, K=, ...gemm keywords)] sharing (ta, tb): ONE grouped launch (crct_gemm_bf16_grouped),
+    every problem with its own epilogue.  Returns the outputs."""
+    arr = (L.GemmArgs * len(problems))()
+    outs = [_gemm_args(g, **prob) for g, prob in zip(arr, problems)]
+    L.check(L.load().crct_gemm_bf16_grouped(arr, len(problems), L.current_stream()), "gemm_grouped")
+    return outs
 
 
 def gemm_fp8(Aq, Bq, scale_a, scale_b, M, N, K, bias=None, act="none", preact_out=None, addend=None, p_drop=0.0, site=0, seed=0,

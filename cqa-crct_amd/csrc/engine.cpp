@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "crct_internal.h"
@@ -133,6 +134,12 @@ struct crct_engine {
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
+  // paired mode (off by default -- measured 1 ms per step slower in situ; CRCT_PAIR=1 or crct_engine_set_pairing(e, 1)
+  // turn it on): from the first co-attention layer on, the
+  // text and the visual side run on ONE stream as grouped / pair launches instead of two concurrent streams (Run::pair_flush);
+  // the bf16 step only -- the fp8 forward keeps the two-stream schedule
+  bool pair_mode = false, pair_forced = false;
+  int first_conn = -1;                  // schedule index of the first co-attention layer
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
   std::vector<hipEvent_t> evpool;
   size_t evnext = 0;
@@ -253,6 +260,15 @@ struct Run {
     }
     parity ^= 1;
   }
+  // ---- paired mode (crct_engine_set_pairing): the text and the visual Run share ONE data stream; inside the co-attention
+  // part of the schedule their launches are queued here instead of issued, and pair_flush() zips the two queues: GEMMs of
+  // the same kind leave as ONE grouped launch with both epilogues, LayerNorm passes as one pair launch, everything else
+  // back to back.  Q_SYNC marks the points where one side needs what the other has produced (the cross attention).
+  enum { Q_GEMM, Q_LNF, Q_LNB, Q_CALL, Q_SYNC };
+  struct QOp { int kind; CrctGemmArgs g; CrctLnFwdArgs lf; CrctLnBwdArgs lb; std::function<int(hipStream_t)> call; };
+  std::vector<QOp> q;
+  bool defer = false;
+  bool end_pending = false;            // a queued backward layer whose layer_end() has to follow the flush
   std::vector<CrctGemmArgs> pending;   // weight-gradient GEMMs of the current layer, launched as ONE grouped grid
   bool defer_wgrad = true;             // false: launch every weight gradient immediately on s (buffers are recycled)
   struct FinJob { const float* part; float* dg; float* db; float* dlb; int M, H; };
@@ -298,7 +314,15 @@ struct Run {
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
+    if (defer && st == s) { QOp op; op.kind = Q_GEMM; op.g = g; q.push_back(op); return; }
     fail(crct_gemm_bf16(&g, st));
+  }
+  void queue_call(std::function<int(hipStream_t)> f) { QOp op; op.kind = Q_CALL; op.call = std::move(f); q.push_back(op); }
+  // both sides reach this point before either goes on (immediate mode: order the two data streams against each other)
+  void cross_sync(Run& V) {
+    if (defer) { QOp op; op.kind = Q_SYNC; q.push_back(op); V.q.push_back(op); return; }
+    if (!rc) fail(order_streams(e, V.s, s));
+    if (!V.rc) V.fail(order_streams(e, s, V.s));
   }
   // y[M][out] = x W^T + b (+ epilogue)
   void lin_fwd(const void* x, int64_t ldx, const LinearP& l, int M, void* y, int64_t ldy, Opt o) {
@@ -321,6 +345,7 @@ struct Run {
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
     g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
     if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; }
+    if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
     fail(crct_gemm_bf16(&g, s));
   }
   // dW[out][in] += dy^T x
@@ -329,7 +354,12 @@ struct Run {
   void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M, bool with_bias = false) {
     if (rc) return;
     const bool fold = with_bias && M % 64 == 0 && l.in % 8 == 0 && l.out % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0;
-    if (with_bias && !fold) bias_grad(dy, lddy, l, M);
+    if (with_bias && !fold) {
+      if (defer) {                     // dy is not launched yet: the column sums follow it in the queue, on the data stream
+        float* db = G(l.b); float* part = F(colsum_part); const int N = l.out;
+        queue_call([dy, lddy, db, part, M, N](hipStream_t st) { return crct_colsum_bf16(dy, lddy, db, part, M, N, 1, st); });
+      } else bias_grad(dy, lddy, l, M);
+    }
     if (rc) return;
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -344,7 +374,7 @@ struct Run {
     // queued also without a side stream (sw == s): the same groups, hence the same kernels and summation orders,
     // in every stream mode -- results stay bit-identical across modes
     pending.push_back(g);
-    if (pending.size() == 8) flush_wgrads();
+    if (pending.size() == 8 && !defer) flush_wgrads();
   }
   // dx[M][in] = dy W (+ epilogue)
   void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, const Opt& o) {
@@ -358,8 +388,8 @@ struct Run {
     for (const FinJob& f : pending_fin)
       if (!rc) fail(crct_layernorm_bwd_finalize(f.part, f.dg, f.db, f.dlb, f.M, f.H, 1, sw));
     pending_fin.clear();
-    if (pending.empty()) return;
-    if (!rc) fail(crct_gemm_bf16_grouped(pending.data(), (int)pending.size(), sw));
+    for (size_t i = 0; i < pending.size() && !rc; i += 8)
+      fail(crct_gemm_bf16_grouped(pending.data() + i, (int)std::min<size_t>(8, pending.size() - i), sw));
     pending.clear();
   }
   void bias_grad(const void* dy, int64_t lddy, const LinearP& l, int M) {
@@ -370,9 +400,19 @@ struct Run {
   void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H, size_t yq, int site) {
     if (rc) return;
     ++tick;
-    if (f8()) fail(crct_layernorm_fwd_q(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed,
-                                        W<uint8_t>(yq), c->fp8_act_scale + site, c->fp8_act_amax + (int64_t)site * CRCT_FP8_AMAX_LANES, s));
-    else fail(crct_layernorm_fwd(A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, s));
+    CrctLnFwdArgs a = {A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, nullptr, nullptr, nullptr};
+    if (f8()) { a.q_out = W<uint8_t>(yq); a.q_scale = c->fp8_act_scale + site; a.q_amax = c->fp8_act_amax + (int64_t)site * CRCT_FP8_AMAX_LANES; }
+    if (defer) { QOp op; op.kind = Q_LNF; op.lf = a; q.push_back(op); return; }
+    fail(launch_ln_fwd(a, s));
+  }
+  static int launch_ln_fwd(const CrctLnFwdArgs& a, hipStream_t st) {
+    if (a.q_out) return crct_layernorm_fwd_q(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale,
+                                             a.drop_site, a.seed, a.q_out, a.q_scale, a.q_amax, st);
+    return crct_layernorm_fwd(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale, a.drop_site, a.seed, st);
+  }
+  static int launch_ln_bwd(const CrctLnBwdArgs& a, hipStream_t st) {
+    return crct_layernorm_bwd_rows(a.dy, a.x, a.mean, a.rstd, a.gamma, a.dx, a.dx_lin, a.partials, a.M, a.H, a.post_thr, a.post_scale,
+                                   a.post_site, a.lin_thr, a.lin_scale, a.lin_site, a.seed, st);
   }
   // returns the buffer that holds the gradient of the producing Linear's output
   size_t ln_bwd(size_t dy, size_t x, size_t mean, size_t rstd, const LnP& ln, const LinearP& lin, size_t dres, size_t dlin,
@@ -381,8 +421,10 @@ struct Run {
     // rows pass on the data stream; the column pass (dgamma, dbeta, bias gradient of the producing Linear) joins the
     // weight-gradient work on the side stream -- `part` belongs to this layer's scratch set
     ++tick;
-    fail(crct_layernorm_bwd_rows(A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
-                                 0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, s));
+    const CrctLnBwdArgs a = {A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
+                             0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed};
+    if (defer) { QOp op; op.kind = Q_LNB; op.lb = a; q.push_back(op); }
+    else fail(launch_ln_bwd(a, s));
     // the column pass is queued like the weight gradients: ONE ordering event per layer covers all of them
     if (defer_wgrad) pending_fin.push_back(FinJob{F(part), G(ln.g), G(ln.b), G(lin.b), M, H});
     else { wgrad_after_main(); if (!rc) fail(crct_layernorm_bwd_finalize(F(part), G(ln.g), G(ln.b), G(lin.b), M, H, 1, sw)); }
@@ -392,15 +434,23 @@ struct Run {
                 int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr) {
     if (rc) return;
     ++tick;
-    fail(crct_attention_fwd(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, c->seed, s));
+    const uint64_t seed = c->seed;
+    auto f = [=](hipStream_t st) { return crct_attention_fwd(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, seed, st); };
+    if (defer) queue_call(f);
+    else fail(f(s));
   }
   void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
                 const bf16_t* dctx, int64_t ldo, bf16_t* dq, int64_t lddq, bf16_t* dk, bf16_t* dv, int64_t lddk, int B,
                 int heads, int Tq, int Tk, int d, const Drop& dr) {
     if (rc) return;
     ++tick;
-    fail(crct_attention_bwd(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr,
-                            dr.scale, dr.site, c->seed, s));
+    const uint64_t seed = c->seed;
+    auto f = [=](hipStream_t st) {
+      return crct_attention_bwd(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr, dr.scale,
+                                dr.site, seed, st);
+    };
+    if (defer) queue_call(f);
+    else fail(f(s));
   }
 
   // ---------------------------------------------------------------- sub-blocks
@@ -450,6 +500,7 @@ struct Run {
     ffn_fwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, M, drop(p.p_hid, p.site + 2));
   }
   void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const uint8_t* km, int B, int T) {
+    // (paired mode: the launches are only queued here, so the layer's weight-gradient flush waits for pair_flush -- end_pending)
     const int M = B * T, H = p.H, d = H / p.heads;
     const StreamScratch& sc = layer_begin();
     ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
@@ -459,7 +510,8 @@ struct Run {
     lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M, true);
     Opt o; o.addend = A(sc.dres_b); o.ld_add = H;
     lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
-    layer_end();
+    if (defer) end_pending = true;
+    else layer_end();
   }
 
   // ---------------------------------------------------------------- connection layer (vilbert.py:774-788)
@@ -471,8 +523,7 @@ struct Run {
     else V.lin_fwd(V.A(xv), D.Hv, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
     if (f8_lin(p.qkv2)) lin_fwd_f8(xtq, site_t, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());
     else lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());            // query2/key2/value2  :673-675
-    if (!rc) fail(order_streams(e, V.s, s));          // text needs k1, v1
-    if (!V.rc) V.fail(order_streams(e, s, V.s));      // visual needs k2, v2
+    cross_sync(V);                                    // text needs k1, v1; visual needs k2, v2
     // text queries over visual keys/values -> ctx1 [B,T,Hb]  :684-701 (dropout1 = v_attention prob)
     attn_fwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(a.ctx1), Hb, B, D.b_heads,
              b->T, b->V, d, drop(D.p_v_attn, p.site));
@@ -496,8 +547,7 @@ struct Run {
     // each attention backward also writes into the OTHER stream's dqkv scratch, which that stream's previous
     // layer (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading: both data
     // streams have waited for their own wgrad stream above, so ordering them against each other closes the hazard
-    if (!rc) fail(order_streams(e, V.s, s));
-    if (!V.rc) V.fail(order_streams(e, s, V.s));
+    cross_sync(V);
     // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]            (text stream)
     attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
              3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site));
@@ -505,16 +555,67 @@ struct Run {
     V.attn_bwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(sv.dctx), Hb, A(sv.dqkv),
                3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1));
     // each stream's dqkv buffer has been written by BOTH attention backward kernels
-    if (!rc) fail(order_streams(e, V.s, s));
-    if (!V.rc) V.fail(order_streams(e, s, V.s));
+    cross_sync(V);
     V.lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv, true);
     Opt ov; ov.addend = A(sv.dres_b); ov.ld_add = D.Hv;
     V.lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
     lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt, true);
     Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
     lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
+    if (defer) { end_pending = true; V.end_pending = true; return; }
     V.layer_end();
     layer_end();
+  }
+
+  // ---------------------------------------------------------------- paired mode: issue the two queues
+  // Per-queue order is kept and nothing passes a Q_SYNC before BOTH sides have reached it; between two syncs the sides are
+  // independent, so heads of the queues that match in kind leave as one launch.  Same kernels, same per-element summation
+  // order as the unpaired schedule: results are bit-identical (test_internal_streams_do_not_change_results).
+  static int issue_one(const QOp& o, hipStream_t st) {
+    switch (o.kind) {
+      case Q_GEMM: return crct_gemm_bf16(&o.g, st);
+      case Q_LNF: return launch_ln_fwd(o.lf, st);
+      case Q_LNB: return launch_ln_bwd(o.lb, st);
+      case Q_CALL: return o.call(st);
+      default: return 0;
+    }
+  }
+  void pair_flush(Run& V) {
+    Run& T = *this;
+    size_t i = 0, j = 0;
+    const size_t n = T.q.size(), m = V.q.size();
+    hipStream_t st = T.s;
+    while ((i < n || j < m) && !T.rc && !V.rc) {
+      const QOp* a = i < n ? &T.q[i] : nullptr;
+      const QOp* b = j < m ? &V.q[j] : nullptr;
+      const bool sa = a && a->kind == Q_SYNC, sb = b && b->kind == Q_SYNC;
+      if ((sa || !a) && (sb || !b)) { if (a) ++i; if (b) ++j; continue; }       // both sides at the rendezvous (or one side done)
+      if (sa) a = nullptr;                                                     // the text side waits for the visual side
+      if (sb) b = nullptr;
+      if (a && b && a->kind == b->kind && a->kind != Q_CALL) {
+        int r = 0;
+        if (a->kind == Q_GEMM) {
+          if (a->g.ta == b->g.ta && a->g.tb == b->g.tb) { CrctGemmArgs pr[2] = {a->g, b->g}; r = crct_gemm_bf16_grouped(pr, 2, st); }
+          else { r = issue_one(*a, st); if (!r) r = issue_one(*b, st); }
+        } else if (a->kind == Q_LNF) r = crct_layernorm_fwd_pair(&a->lf, &b->lf, st);
+        else r = crct_layernorm_bwd_rows_pair(&a->lb, &b->lb, st);
+        T.fail(r);
+        ++i; ++j;
+        continue;
+      }
+      // kinds differ (or two attention calls): one launch from the side that is not holding a pairable GEMM, so that
+      // the queues fall back into step
+      if (a && b) {
+        const bool a_first = a->kind == Q_CALL || b->kind != Q_CALL;
+        if (a_first) { T.fail(issue_one(*a, st)); ++i; } else { V.fail(issue_one(*b, st)); ++j; }
+        continue;
+      }
+      if (a) { T.fail(issue_one(*a, st)); ++i; }
+      else { V.fail(issue_one(*b, st)); ++j; }
+    }
+    T.q.clear(); V.q.clear();
+    if (T.end_pending) { T.end_pending = false; T.layer_end(); }
+    if (V.end_pending) { V.end_pending = false; V.layer_end(); }
   }
 
   // ---------------------------------------------------------------- embeddings
@@ -728,6 +829,8 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     }
     for (int i = vs; i < D.Lv; ++i) e->sched.push_back({'v', i});
     for (int i = ts; i < D.L; ++i) e->sched.push_back({'t', i});
+    for (size_t i = 0; i < e->sched.size() && e->first_conn < 0; ++i)
+      if (e->sched[i].kind == 'c') e->first_conn = (int)i;
   }
   // ---- parameters
   char buf[256];
@@ -955,10 +1058,18 @@ int ensure_streams(crct_engine* e) {
   return 0;
 }
 
+bool pairing_on(crct_engine* e, const CrctStepCfg* cfg) {
+  static const char* env = getenv("CRCT_PAIR");
+  if (!e->pair_forced && env) e->pair_mode = env[0] != '0';
+  const bool f8 = cfg->fp8 && cfg->params_fp8 && cfg->fp8_w_scale && cfg->fp8_act_scale && cfg->fp8_act_amax;
+  return e->pair_mode && !f8 && e->first_conn >= 0;
+}
+
 // two drivers over one workspace: Rt = text stream on the caller's stream, Rv = visual stream
 void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, void* ws, hipStream_t main, const CrctBatch* batch,
                const CrctStepCfg* cfg, Run& Rt, Run& Rv) {
-  hipStream_t vis = e->use_vis_stream ? e->side[0] : main;
+  const bool paired = pairing_on(e, cfg);
+  hipStream_t vis = (e->use_vis_stream && !paired) ? e->side[0] : main;
   Rt = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, main, batch, cfg, e->use_wgrad_stream ? e->side[1] : main,
            e->partials[0], e->colsum_part[0], e->colsum_part[2]};
   Rv = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, vis, batch, cfg, e->use_wgrad_stream ? e->side[2] : vis,
@@ -1004,9 +1115,11 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   size_t xt = e->eta.y, xv = e->eva.y;
   size_t xtq = e->eta.yq, xvq = e->eva.yq;               // e4m3 copies of the running hidden states and their scale sites (fp8 forward)
   int site_t = e->eta.site, site_v = e->eva.site;
+  const bool paired = pairing_on(e, cfg);
   int step_i = 0;
   for (const Step& st : e->sched) {
     const int seg = (int)e->sched.size() - step_i;       // backward segment of this schedule step
+    Rt.defer = Rv.defer = paired && step_i >= e->first_conn;
     ++step_i;
     if (st.kind == 't') wait_params(Rt, seg);
     else if (st.kind == 'v') wait_params(Rv, seg);
@@ -1025,7 +1138,10 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
       xv = a.ffn_v.y; xvq = a.ffn_v.yq; site_v = a.ffn_v.site_y;
       xt = a.ffn_t.y; xtq = a.ffn_t.yq; site_t = a.ffn_t.site_y;
     }
+    // paired mode: a co-attention layer is issued at once; a visual layer waits for the text layer the schedule runs beside it
+    if (Rt.defer && (st.kind != 'v' || step_i == (int)e->sched.size() || e->sched[step_i].kind != 't')) Rt.pair_flush(Rv);
   }
+  Rt.defer = Rv.defer = false;
   wait_params(Rt, 0);
   wait_params(Rv, 0);
   Rt.heads_branch_fwd(false, xt);
@@ -1067,7 +1183,12 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   }
   // fork: every internal stream starts after the caller's prior work (previous segment, optimizer, ...)
   Rv.fail(order_streams(e, Rt.s, Rv.s));
+  const bool paired = pairing_on(e, cfg);
+  int ev_from = s0;                                      // segments enqueued completely but not yet marked for the data-parallel caller
   for (int sgi = s0; sgi < s1 && !Rt.rc && !Rv.rc; ++sgi) {
+    const bool in_sched = sgi != 0 && sgi != nseg - 1;
+    const size_t si = in_sched ? e->sched.size() - (size_t)sgi : 0;
+    Rt.defer = Rv.defer = paired && in_sched && (int)si >= e->first_conn;
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
       Rt.heads_bwd(Rv, e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
@@ -1088,17 +1209,29 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
         e->cur_t ^= 1; e->cur_v ^= 1;
       }
     }
+    if (Rt.defer) {
+      // paired mode: a text layer waits for the visual layer that follows it in backward order (the pair the forward ran side
+      // by side); everything else is issued at the end of its segment
+      const bool hold = in_sched && e->sched[si].kind == 't' && sgi + 1 < s1 && sgi + 1 < nseg - 1 && e->sched[si - 1].kind == 'v' &&
+                        (int)(si - 1) >= e->first_conn;
+      if (hold) continue;
+      Rt.pair_flush(Rv);
+    }
     if (seg < 0 && cfg->seg_done_events && !Rt.rc && !Rv.rc) {
-      // segment sgi is completely enqueued: mark that point on every internal stream for the data-parallel caller
+      // segments ev_from .. sgi are completely enqueued: mark that point on every internal stream for the data-parallel caller
       Rt.flush_wgrads();
       Rv.flush_wgrads();
       hipStream_t ss[4] = {Rt.s, Rt.sw, Rv.s, Rv.sw};
-      for (int k = 0; k < 4; ++k) {
-        hipEvent_t ev = (hipEvent_t)cfg->seg_done_events[4 * sgi + k];
-        if (ev && hipEventRecord(ev, ss[k]) != hipSuccess) { crct_set_error("engine_backward: cannot record a segment event"); Rt.rc = 1; }
-      }
+      for (int sg = ev_from; sg <= sgi; ++sg)
+        for (int k = 0; k < 4; ++k) {
+          hipEvent_t ev = (hipEvent_t)cfg->seg_done_events[4 * sg + k];
+          if (ev && hipEventRecord(ev, ss[k]) != hipSuccess) { crct_set_error("engine_backward: cannot record a segment event"); Rt.rc = 1; }
+        }
     }
+    ev_from = sgi + 1;
   }
+  if (!Rt.q.empty() || !Rv.q.empty()) Rt.pair_flush(Rv);
+  Rt.defer = Rv.defer = false;
   // join: everything this call enqueued anywhere is ordered before later work on the caller's stream
   Rt.main_after_wgrad();
   Rv.main_after_wgrad();
@@ -1145,6 +1278,13 @@ extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, 
   e->use_vis_stream = use_visual_stream != 0;
   e->use_wgrad_stream = use_wgrad_streams != 0;
   e->streams_forced = true;
+  return 0;
+}
+
+extern "C" int crct_engine_set_pairing(crct_engine_t* e, int on) {
+  if (!e) return 1;
+  e->pair_mode = on != 0;
+  e->pair_forced = true;
   return 0;
 }
 

@@ -918,7 +918,7 @@ struct GroupArgs {
   int n;
   int tile_begin[GROUP_MAX + 1];       // first block of every problem (multiples of 8: a problem starts on XCD 0)
   TileMap map[GROUP_MAX];              // per-problem XCD-aware block -> tile map, as for single launches
-  struct P { const void* A; const void* B; void* C; float* rowsum; long lda, ldb, ldc; int M, N, K, c_is_f32, accumulate; } p[GROUP_MAX];
+  CrctGemmArgs p[GROUP_MAX];           // the problems with their full epilogues (ta / tb are the kernel's template arguments)
 };
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
@@ -930,11 +930,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
     if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
   int tm, tn;
   if (!map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) return;
-  CrctGemmArgs g = {};
-  g.A = ga.p[pi].A; g.B = ga.p[pi].B; g.C = ga.p[pi].C;
-  g.lda = ga.p[pi].lda; g.ldb = ga.p[pi].ldb; g.ldc = ga.p[pi].ldc;
-  g.M = ga.p[pi].M; g.N = ga.p[pi].N; g.K = ga.p[pi].K; g.ta = TA; g.tb = TB;
-  g.c_is_f32 = ga.p[pi].c_is_f32; g.accumulate = ga.p[pi].accumulate; g.alpha = 1.0f; g.rowsum_out = ga.p[pi].rowsum;
+  CrctGemmArgs g = ga.p[pi];
+  g.ta = TA; g.tb = TB;
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
 }
 
@@ -951,7 +948,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
     ga.map[i] = make_tile_map(g.M, g.N, BM, BN, &grid);
     ga.map[i].dbg = 0;
     total += grid;
-    ga.p[i] = {g.A, g.B, g.C, g.rowsum_out, g.lda, g.ldb, g.ldc, g.M, g.N, g.K, g.c_is_f32, g.accumulate};
+    ga.p[i] = g;
   }
   ga.tile_begin[n] = total;
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
@@ -1196,14 +1193,15 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
   return e;
 }
 
-// Grouped launch of n <= 8 plain GEMMs (no epilogue extras besides fp32 / bf16 output and accumulate) that share
-// (ta, tb) and satisfy the LDS-DMA kernel's requirements; anything else is launched one by one.
+// Grouped launch of n <= 8 bf16 GEMMs with their full epilogues that share (ta, tb) and satisfy the LDS-DMA kernel's
+// requirements; anything else is launched one by one.  Two uses: the weight gradients of a layer (ta = tb = 1), and the
+// forward / data-gradient GEMMs of the text and the visual side of a co-attention layer or of two independent layers
+// (n = 2): one grid, one ramp, the tiles of both problems packed over the CUs.
 hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s) {
   bool ok = n >= 2 && n <= GROUP_MAX && !g_force_generic;
   for (int i = 0; ok && i < n; ++i) {
     const CrctGemmArgs& g = gs[i];
-    ok = pipe_ok(g) && g.ta == gs[0].ta && g.tb == gs[0].tb && !g.bias && !g.preact_out && !g.dact_src && !g.addend && !g.drop_thr &&
-         g.act == ACT_NONE && g.alpha == 1.0f && g.M > 96;
+    ok = pipe_ok(g) && g.ta == gs[0].ta && g.tb == gs[0].tb && !g.fp8 && !g.q_out && g.M > 96 && (g.ta || !g.rowsum_out);
   }
   if (!ok) {
     for (int i = 0; i < n; ++i) {
@@ -1212,7 +1210,9 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
     }
     return hipSuccess;
   }
-  static const int cfg = getenv("CRCT_GEMM_GROUP") ? atoi(getenv("CRCT_GEMM_GROUP")) : 4;   // 128x128, 8 waves, 3 stages
+  static const int cfg_w = getenv("CRCT_GEMM_GROUP") ? atoi(getenv("CRCT_GEMM_GROUP")) : 4;   // weight gradients: 128x128, 8 waves, 3 stages
+  static const int cfg_p = getenv("CRCT_GEMM_PAIR") ? atoi(getenv("CRCT_GEMM_PAIR")) : 9;     // forward / dgrad pairs: 128x128, 8 waves, 2 stages
+  const int cfg = gs[0].ta ? cfg_w : cfg_p;
   ProfSlot* slot = nullptr;
   if (g_prof.on) {                     // one timed slot for the whole group, FLOPs summed
     if (g_prof.used == g_prof.slots.size()) {

@@ -495,52 +495,69 @@ __global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------ LayerNorm fwd
+// One problem of a LayerNorm launch (the pair kernels below carry two: the text and the visual side of a layer pair).
+struct LnFwdP {
+  const bf16_t* x; const float* gamma; const float* beta; bf16_t* y; float* mean_o; float* rstd_o; int M, H; float eps;
+  uint32_t thr; float scale; uint32_t site; uint64_t seed; uint8_t* q_out; const float* q_scale; float* q_amax;
+};
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H, float eps,
-                                                     uint32_t thr, float scale, uint32_t site, uint64_t seed,
-                                                     uint8_t* __restrict__ q_out, const float* __restrict__ q_scale, float* __restrict__ q_amax) {
+__device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, const int nblk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int M = a.M, H = a.H;
   Row<NCH> g, b;
-  row_load_f32(g, gamma, H, lane);
-  row_load_f32(b, beta, H, lane);
-  const float qs = q_out ? q_scale[0] : 0.f;
+  row_load_f32(g, a.gamma, H, lane);
+  row_load_f32(b, a.beta, H, lane);
+  const float qs = a.q_out ? a.q_scale[0] : 0.f;
   float amax = 0.f;
-  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+  for (long row = (long)blk * ROWS_PER_BLOCK + wave; row < M; row += (long)nblk * ROWS_PER_BLOCK) {
     Row<NCH> r;
-    row_load_bf16(r, x + row * H, H, lane);
+    row_load_bf16(r, a.x + row * H, H, lane);
     float mean, rstd;
-    row_stats(r, H, lane, eps, mean, rstd);
-    row_normalize(r, g, b, H, lane, mean, rstd, row, thr, scale, site, seed);
-    row_store_bf16(r, y + row * H, H, lane);
-    if (q_out) amax = fmaxf(amax, row_store_fp8(r, q_out + row * H, H, lane, qs));     // the fp8 GEMMs' operand (BASELINE configs[4])
-    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    row_stats(r, H, lane, a.eps, mean, rstd);
+    row_normalize(r, g, b, H, lane, mean, rstd, row, a.thr, a.scale, a.site, a.seed);
+    row_store_bf16(r, a.y + row * H, H, lane);
+    if (a.q_out) amax = fmaxf(amax, row_store_fp8(r, a.q_out + row * H, H, lane, qs));     // the fp8 GEMMs' operand (BASELINE configs[4])
+    if (lane == 0) { a.mean_o[row] = mean; a.rstd_o[row] = rstd; }
   }
-  if (q_out && q_amax) {
+  if (a.q_out && a.q_amax) {
     amax = wave_max(amax);
-    if (lane == 0) amax_update(q_amax, amax);
+    if (lane == 0) amax_update(a.q_amax, amax);
   }
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdP a) { ln_fwd_body<NCH>(a, blockIdx.x, gridDim.x); }
+// workgroups [0, nb0) serve problem a, the rest problem b: same arithmetic per row as two single launches
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const LnFwdP a, const LnFwdP b, const int nb0) {
+  if ((int)blockIdx.x < nb0) ln_fwd_body<NCH>(a, blockIdx.x, nb0);
+  else ln_fwd_body<NCH>(b, blockIdx.x - nb0, gridDim.x - nb0);
 }
 
 // ------------------------------------------------------------------------------ LayerNorm bwd
 // COMBINE: the four waves of a workgroup add their column partials through LDS and store ONE partial row set per
 // workgroup ([3][gridDim.x][H], a quarter of the per-wave traffic for the kernel and for the finalize pass); without it
 // (rows too long for 64 KB of LDS) every wave stores its own ([3][4 * gridDim.x][H]).
+struct LnBwdP {
+  const bf16_t* dy; const bf16_t* x; const float* mean; const float* rstd; const float* gamma; bf16_t* dx; bf16_t* dxl;
+  float* partials; int M, H; uint32_t post_thr; float post_scale; uint32_t post_site; uint32_t lin_thr; float lin_scale;
+  uint32_t lin_site; uint64_t seed;
+};
 template <int NCH, bool COMBINE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy_p, const bf16_t* __restrict__ x_p,
-                                                     const float* __restrict__ mean_p, const float* __restrict__ rstd_p,
-                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dx_p,
-                                                     bf16_t* __restrict__ dxl_p, float* __restrict__ partials, int M, int H,
-                                                     uint32_t post_thr, float post_scale, uint32_t post_site,
-                                                     uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed) {
+__device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, const int nblk) {
+  const bf16_t* __restrict__ dy_p = a.dy; const bf16_t* __restrict__ x_p = a.x;
+  const float* __restrict__ mean_p = a.mean; const float* __restrict__ rstd_p = a.rstd; const float* __restrict__ gamma = a.gamma;
+  bf16_t* __restrict__ dx_p = a.dx; bf16_t* __restrict__ dxl_p = a.dxl; float* __restrict__ partials = a.partials;
+  const int M = a.M, H = a.H;
+  const uint32_t post_thr = a.post_thr, post_site = a.post_site, lin_thr = a.lin_thr, lin_site = a.lin_site;
+  const float post_scale = a.post_scale, lin_scale = a.lin_scale;
+  const uint64_t seed = a.seed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   Row<NCH> adg, adb, adl, g;
   row_zero(adg); row_zero(adb); row_zero(adl);
   row_load_f32(g, gamma, H, lane);
   // M / (4 x grid) is 1.6 rows per wave at the CRCT sizes: the second row's loads are issued before the first row is worked on
-  const long stride = (long)gridDim.x * ROWS_PER_BLOCK;
-  long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+  const long stride = (long)nblk * ROWS_PER_BLOCK;
+  long row = (long)blk * ROWS_PER_BLOCK + wave;
   RawRow<NCH> dy_n, x_n;
   float mean_n = 0.f, rstd_n = 0.f;
   if (row < M) {
@@ -579,15 +596,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       const float* src = ln_lds + (long)q * ROWS_PER_BLOCK * H + c;
       const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + H);
       const float4 d = *reinterpret_cast<const float4*>(src + 2 * H), e = *reinterpret_cast<const float4*>(src + 3 * H);
-      *reinterpret_cast<float4*>(partials + ((long)q * gridDim.x + blockIdx.x) * H + c) =
+      *reinterpret_cast<float4*>(partials + ((long)q * nblk + blk) * H + c) =
           make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
     }
   } else {
-    const long nr = (long)gridDim.x * ROWS_PER_BLOCK, pr = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+    const long nr = (long)nblk * ROWS_PER_BLOCK, pr = (long)blk * ROWS_PER_BLOCK + wave;
     row_store_f32(adg, partials + (0 * nr + pr) * H, H, lane);
     row_store_f32(adb, partials + (1 * nr + pr) * H, H, lane);
     row_store_f32(adl, partials + (2 * nr + pr) * H, H, lane);
   }
+}
+
+template <int NCH, bool COMBINE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP a) { ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, gridDim.x); }
+// workgroups [0, nb0) serve problem a, the rest problem b; each problem keeps its own partial-row geometry ([3][nblk][H])
+template <int NCH, bool COMBINE>
+__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(const LnBwdP a, const LnBwdP b, const int nb0) {
+  if ((int)blockIdx.x < nb0) ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, nb0);
+  else ln_bwd_body<NCH, COMBINE>(b, blockIdx.x - nb0, gridDim.x - nb0);
 }
 
 // out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
@@ -940,29 +966,53 @@ int launch_finalize(const FinalizeArgs& fa, hipStream_t s) {
 
 extern "C" {
 
+static LnFwdP ln_fwd_problem(const CrctLnFwdArgs& a) {
+  return LnFwdP{(const bf16_t*)a.x, a.gamma, a.beta, (bf16_t*)a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale,
+                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax};
+}
+static int ln_fwd_check(const CrctLnFwdArgs& a) {
+  CRCT_REQUIRE(a.H % 8 == 0 && a.H > 0, "layernorm: H=%d must be a positive multiple of 8", a.H);
+  CRCT_REQUIRE(!a.q_out || a.q_scale, "layernorm_fwd: q_out needs q_scale");
+  return 0;
+}
+static int ln_fwd_launch(const CrctLnFwdArgs& a, hipStream_t s) {
+  if (int r = ln_fwd_check(a)) return r;
+  if (a.M <= 0) return 0;
+  const LnFwdP p = ln_fwd_problem(a);
+  DISPATCH_NCH(a.H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(a.M, 2048)), dim3(256), 0, s, p));
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int M, int H, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site,
                        uint64_t seed, crct_stream_t stream) {
-  CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm: H=%d must be a positive multiple of 8", H);
-  if (M <= 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
-                                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr,
-                                     drop_scale, drop_site, seed, (uint8_t*)nullptr, (const float*)nullptr, (float*)nullptr));
-  CRCT_CHECK_HIP(hipGetLastError());
-  return 0;
+  const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, nullptr, nullptr, nullptr};
+  return ln_fwd_launch(a, (hipStream_t)stream);
 }
 
 int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int M, int H, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site,
                          uint64_t seed, void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream) {
-  CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm: H=%d must be a positive multiple of 8", H);
   CRCT_REQUIRE(q_out && q_scale, "layernorm_fwd_q: q_out and q_scale are required");
-  if (M <= 0) return 0;
+  const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, q_out, q_scale, q_amax};
+  return ln_fwd_launch(a, (hipStream_t)stream);
+}
+
+// Two independent LayerNorms (the text and the visual side of a layer pair) in ONE launch; rows of different widths are fine
+// as long as both take the same number of 512-column register chunks, otherwise two launches.
+int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct_stream_t stream) {
+  CRCT_REQUIRE(a && b, "layernorm_fwd_pair: null argument");
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
-                                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr,
-                                     drop_scale, drop_site, seed, (uint8_t*)q_out, q_scale, q_amax));
+  if (int r = ln_fwd_check(*a)) return r;
+  if (int r = ln_fwd_check(*b)) return r;
+  if (a->M <= 0 || b->M <= 0 || nch_for(a->H) != nch_for(b->H)) {
+    if (int r = ln_fwd_launch(*a, s)) return r;
+    return ln_fwd_launch(*b, s);
+  }
+  const LnFwdP pa = ln_fwd_problem(*a), pb = ln_fwd_problem(*b);
+  const int nb0 = row_grid(a->M, 2048), nb1 = row_grid(b->M, 2048);
+  DISPATCH_NCH(a->H, hipLaunchKernelGGL((ln_fwd_pair_kernel<NCH>), dim3(nb0 + nb1), dim3(256), 0, s, pa, pb, nb0));
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -991,22 +1041,50 @@ static bool ln_bwd_combines(int H) {
   static const bool off = getenv("CRCT_LN_BWD_NO_COMBINE") != nullptr;      // developer A/B switch
   return !off && (size_t)3 * ROWS_PER_BLOCK * H * 4 <= 64 * 1024;
 }
+static LnBwdP ln_bwd_problem(const CrctLnBwdArgs& a) {
+  return LnBwdP{(const bf16_t*)a.dy, (const bf16_t*)a.x, a.mean, a.rstd, a.gamma, (bf16_t*)a.dx, (bf16_t*)a.dx_lin, a.partials,
+                a.M, a.H, a.post_thr, a.post_scale, a.post_site, a.lin_thr, a.lin_scale, a.lin_site, a.seed};
+}
+static int ln_bwd_launch(const CrctLnBwdArgs& a, hipStream_t s) {
+  CRCT_REQUIRE(a.H % 8 == 0 && a.H > 0, "layernorm_bwd: H=%d must be a positive multiple of 8", a.H);
+  if (a.M <= 0) return 0;
+  const int nb = crct_layernorm_bwd_blocks(a.M);
+  const LnBwdP p = ln_bwd_problem(a);
+  if (ln_bwd_combines(a.H)) {
+    DISPATCH_NCH(a.H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, p));
+  } else {
+    DISPATCH_NCH(a.H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, p));
+  }
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                             void* dx, void* dx_lin, float* partials, int M, int H, uint32_t post_thr, float post_scale,
                             uint32_t post_site, uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
                             crct_stream_t stream) {
-  CRCT_REQUIRE(H % 8 == 0 && H > 0, "layernorm_bwd: H=%d must be a positive multiple of 8", H);
-  if (M <= 0) return 0;
+  const CrctLnBwdArgs a = {dy, x, mean, rstd, gamma, dx, dx_lin, partials, M, H, post_thr, post_scale, post_site, lin_thr, lin_scale,
+                           lin_site, seed};
+  return ln_bwd_launch(a, (hipStream_t)stream);
+}
+// The rows passes of two independent LayerNorm backwards in ONE launch (see crct_layernorm_fwd_pair); every problem keeps
+// the partial-row geometry of its own single launch, so crct_layernorm_bwd_finalize is unchanged.
+int crct_layernorm_bwd_rows_pair(const CrctLnBwdArgs* a, const CrctLnBwdArgs* b, crct_stream_t stream) {
+  CRCT_REQUIRE(a && b, "layernorm_bwd_rows_pair: null argument");
   hipStream_t s = (hipStream_t)stream;
-  const int nb = crct_layernorm_bwd_blocks(M);
-  if (ln_bwd_combines(H)) {
-    DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * H * 4, s,
-                                       (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin,
-                                       partials, M, H, post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
+  const bool same = a->M > 0 && b->M > 0 && a->H % 8 == 0 && b->H % 8 == 0 && a->H > 0 && b->H > 0 && nch_for(a->H) == nch_for(b->H) &&
+                    ln_bwd_combines(a->H) == ln_bwd_combines(b->H);
+  if (!same) {
+    if (int r = ln_bwd_launch(*a, s)) return r;
+    return ln_bwd_launch(*b, s);
+  }
+  const LnBwdP pa = ln_bwd_problem(*a), pb = ln_bwd_problem(*b);
+  const int nb0 = crct_layernorm_bwd_blocks(a->M), nb1 = crct_layernorm_bwd_blocks(b->M);
+  const int Hmax = a->H > b->H ? a->H : b->H;
+  if (ln_bwd_combines(a->H)) {
+    DISPATCH_NCH(a->H, hipLaunchKernelGGL((ln_bwd_pair_kernel<NCH, true>), dim3(nb0 + nb1), dim3(256),
+                                          (size_t)3 * ROWS_PER_BLOCK * Hmax * 4, s, pa, pb, nb0));
   } else {
-    DISPATCH_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
-                                       (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_lin, partials, M, H,
-                                       post_thr, post_scale, post_site, lin_thr, lin_scale, lin_site, seed));
+    DISPATCH_NCH(a->H, hipLaunchKernelGGL((ln_bwd_pair_kernel<NCH, false>), dim3(nb0 + nb1), dim3(256), 0, s, pa, pb, nb0));
   }
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -105,6 +105,15 @@ int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, v
                          uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                          void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream);
 
+/* Two independent LayerNorms in ONE launch (the text and the visual side of a co-attention layer, or of two layers the schedule
+ * runs side by side): same arithmetic per row as two crct_layernorm_fwd[_q] calls.  q_out == NULL: no e4m3 copy. */
+typedef struct CrctLnFwdArgs {
+  const void* x; const float* gamma; const float* beta; void* y; float* mean; float* rstd;
+  int32_t M, H; float eps; uint32_t drop_thr; float drop_scale; uint32_t drop_site; uint64_t seed;
+  void* q_out; const float* q_scale; float* q_amax;
+} CrctLnFwdArgs;
+int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct_stream_t stream);
+
 /* Every amax "value" below and in CrctGemmArgs / CrctStepCfg / CrctFp8Shadow is CRCT_FP8_AMAX_LANES consecutive fp32 words
  * (the kernels spread their atomic maxima over them; crct_fp8_update_scales takes the maximum of the words): an amax array
  * for n tensors has n * CRCT_FP8_AMAX_LANES words and entry i starts at word i * CRCT_FP8_AMAX_LANES. */
@@ -150,6 +159,14 @@ int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, co
                             uint32_t post_thr, float post_scale, uint32_t post_site,
                             uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
                             crct_stream_t stream);
+/* The rows passes of two independent LayerNorm backwards in ONE launch; arguments as crct_layernorm_bwd_rows, partial rows in
+ * each problem's own buffer and geometry (crct_layernorm_bwd_finalize per problem afterwards). */
+typedef struct CrctLnBwdArgs {
+  const void* dy; const void* x; const float* mean; const float* rstd; const float* gamma; void* dx; void* dx_lin; float* partials;
+  int32_t M, H; uint32_t post_thr; float post_scale; uint32_t post_site; uint32_t lin_thr; float lin_scale; uint32_t lin_site;
+  uint64_t seed;
+} CrctLnBwdArgs;
+int crct_layernorm_bwd_rows_pair(const CrctLnBwdArgs* a, const CrctLnBwdArgs* b, crct_stream_t stream);
 int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin,
                                 int M, int H, int accumulate, crct_stream_t stream);
 
@@ -410,6 +427,12 @@ int crct_engine_backward(crct_engine_t*, const float* params_f32, const void* pa
 /* Internal concurrency (default: both on): the visual stream's layers run on a second HIP stream and all
  * weight-gradient GEMMs / bias column sums on two more, forked from and joined to `stream` inside every call.
  * Results do not depend on the setting (tests compare them bit for bit). */
+int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
+/* Paired mode (default OFF: measured slower in the step; CRCT_PAIR=1 turns it on for A/B runs): from the first co-attention layer
+ * on, the text and the visual side of the schedule share ONE stream and leave as grouped GEMM / pair LayerNorm launches
+ * (crct_gemm_bf16_grouped with n = 2, crct_layernorm_*_pair) instead of running on two concurrent streams.  Results are
+ * bit-identical in both modes.  The fp8 forward always uses the two-stream schedule. */
+int crct_engine_set_pairing(crct_engine_t*, int on);
 /* The weight gradients (flat offsets / element counts into grads_f32, sorted by offset) that exactly one weight-gradient
  * GEMM per backward pass produces and nothing else adds to: every Linear weight of the encoder layers, the image embedding,
  * the poolers and the regressor pipes.  The set is fixed by the schedule at crct_engine_create (it does not depend on the
@@ -419,7 +442,6 @@ int crct_engine_wgrad_owned(crct_engine_t*, int64_t* offsets, int64_t* numels, i
  * over len): the gradients that stay accumulate-only under wgrad_overwrite.  Non-temporal stores. */
 int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
                    int64_t n_blk, crct_stream_t stream);
-int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
 /* fp8 forward: number of activation scale sites, and the (flat offset, element count) of every weight that has an e4m3 shadow
  * (index = its slot in CrctStepCfg.fp8_w_scale).  Both are fixed at crct_engine_create. */
 int crct_engine_fp8_sites(const crct_engine_t*);

@@ -472,3 +472,35 @@ def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T,
     untouched = torch.ones(V, dtype=torch.bool, device=DEV)
     untouched[ids.flatten()] = False
     assert float(w1[untouched].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- grouped forward / dgrad pairs
+@pytest.mark.parametrize("mode", ["fwd", "dgrad"])
+def test_grouped_pair_with_epilogues_equals_single_launches(mode, gemm_path):
+    """crct_gemm_bf16_grouped with n = 2 and full epilogues (the text / visual pair of a co-attention layer in ONE grid): every
+    problem must come out bit-identical to its own single launch -- same K order per output element, whatever the tile."""
+    if gemm_path != "pipelined":
+        pytest.skip("grouped launches exist for the LDS-DMA kernel only")
+    Mt, Mv = 1600, 2880
+    if mode == "fwd":       # text FFN-up (bias, GELU, pre-activation kept) || visual FFN-down (bias, dropout, residual add)
+        xt, wt, bt = bf(rand(Mt, 768, seed=1)), bf(rand(3072, 768, scale=0.05, seed=2)), rand(3072, seed=3)
+        xv, wv, bv = bf(rand(Mv, 1024, seed=4)), bf(rand(1024, 1024, scale=0.05, seed=5)), rand(1024, seed=6)
+        res = bf(rand(Mv, 1024, seed=7))
+        pre1, pre2 = (torch.empty(Mt, 3072, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+        single = [ops.gemm(xt, wt, Mt, 3072, 768, bias=bt, act="gelu", preact_out=pre1),
+                  ops.gemm(xv, wv, Mv, 1024, 1024, bias=bv, addend=res, p_drop=0.1, site=7, seed=11)]
+        grouped = ops.gemm_grouped([dict(A=xt, B=wt, M=Mt, N=3072, K=768, bias=bt, act="gelu", preact_out=pre2),
+                                    dict(A=xv, B=wv, M=Mv, N=1024, K=1024, bias=bv, addend=res, p_drop=0.1, site=7, seed=11)])
+        assert torch.equal(pre1, pre2)
+    else:                   # text FFN-down dgrad (x gelu'(u)) || visual QKV dgrad (+ residual gradient)
+        dyt, wt = bf(rand(Mt, 768, seed=1)), bf(rand(768, 3072, scale=0.05, seed=2))
+        u = bf(rand(Mt, 3072, seed=3))
+        dyv, wv = bf(rand(Mv, 3072, seed=4)), bf(rand(3072, 1024, scale=0.05, seed=5))
+        res = bf(rand(Mv, 1024, seed=6))
+        single = [ops.gemm(dyt, wt, Mt, 3072, 768, tb=True, dact_src=u, dact="gelu"),
+                  ops.gemm(dyv, wv, Mv, 1024, 3072, tb=True, addend=res)]
+        grouped = ops.gemm_grouped([dict(A=dyt, B=wt, M=Mt, N=3072, K=768, tb=True, dact_src=u, dact="gelu"),
+                                    dict(A=dyv, B=wv, M=Mv, N=1024, K=3072, tb=True, addend=res)])
+    for a, b in zip(single, grouped):
+        assert torch.equal(a, b)
+        assert float(a.float().abs().max()) > 0
