@@ -538,16 +538,22 @@ struct Run {
   }
   void conn_bwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
     const CrctModelDims& D = e->d;
+    hipEvent_t free_v = V.set_free[V.parity], free_t = set_free[parity];      // "the last readers of this scratch set are done"
     const StreamScratch& sv = V.layer_begin(); const StreamScratch& st = layer_begin();
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
     V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
     V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
     proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3));       // dctx1 [Mt,Hb]
-    // each attention backward also writes into the OTHER stream's dqkv scratch, which that stream's previous
-    // layer (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading: both data
-    // streams have waited for their own wgrad stream above, so ordering them against each other closes the hazard
-    cross_sync(V);
+    // each attention backward also writes into the OTHER stream's dqkv scratch, which the layer that used this scratch set
+    // last (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading.  With side streams that
+    // layer's end is marked by the set's free event (recorded on the side stream behind everything the layer enqueued):
+    // each data stream also waits for the OTHER side's event -- long signalled, so the wait is free, where a fresh
+    // two-way hand-off costs 10+ us on the critical stream (tools/handoff_lab.cpp).  Without side streams: a full ordering.
+    if (!defer && sw != s && V.sw != V.s) {
+      if (free_v && !rc && hipStreamWaitEvent(s, free_v, 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); rc = 1; }
+      if (free_t && !V.rc && hipStreamWaitEvent(V.s, free_t, 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); V.rc = 1; }
+    } else cross_sync(V);
     // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]            (text stream)
     attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
              3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site));
