@@ -125,6 +125,12 @@ PROTOTYPES = {
     "crct_engine_forward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp]),
     "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
     "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
+    "crct_event_create": (vp, []),
+    "crct_event_destroy": (None, [vp]),
+    "crct_event_record": (C.c_int, [vp, vp]),
+    "crct_stream_wait_event": (C.c_int, [vp, vp]),
+    "crct_event_synchronize": (C.c_int, [vp]),
+    "crct_event_query": (C.c_int, [vp]),
     "crct_engine_set_pairing": (C.c_int, [vp, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_engine_fp8_sites": (C.c_int, [vp]),

@@ -357,9 +357,8 @@ class CrctModel(nn.Module):
     def segment_done_events(self):
         """4 events per backward segment, recorded by the engine on its internal streams when the segment is enqueued."""
         if self._seg_done is None:
-            self._seg_done = [torch.cuda.Event() for _ in range(4 * self._engine.n_segments)]
-            for ev in self._seg_done:                 # torch creates the hipEvent lazily, at the first record
-                ev.record()
+            from .events import DeviceEvent
+            self._seg_done = [DeviceEvent() for _ in range(4 * self._engine.n_segments)]
         return self._seg_done
 
     def take_segment_done_events(self):
@@ -370,7 +369,8 @@ class CrctModel(nn.Module):
 
     def _run_backward(self, tensors, step):
         if self._opt_stream is not None:             # overlapped optimizer update / gradient memset of the previous step
-            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            from .events import order_streams
+            order_streams(self._opt_stream, torch.cuda.current_stream())
         self._ensure_grad_views()
         self._grads_dirty = True                     # gradients are being accumulated again (optimizer bookkeeping)
         eng = self._engine
@@ -386,7 +386,7 @@ class CrctModel(nn.Module):
             evs = self.segment_done_events()
             step = dict(step, seg_done_events=evs)
             eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, -1)
-            self._grad_waits = [[(lambda st, ev=ev: st.wait_event(ev)) for ev in evs[4 * i:4 * i + 4]] for i in range(eng.n_segments)]
+            self._grad_waits = [[(lambda st, ev=ev: ev.wait(st)) for ev in evs[4 * i:4 * i + 4]] for i in range(eng.n_segments)]
             return
         if self._ddp is None:
             if os.environ.get("CRCT_FORCE_SEGMENTED"):     # developer switch: the DDP call pattern without the collectives

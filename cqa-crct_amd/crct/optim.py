@@ -18,6 +18,7 @@ from torch.optim.lr_scheduler import _LRScheduler
 
 from . import lib as L
 from . import ops
+from .events import order_streams
 from .layout import NO_DECAY, is_language_weight
 
 
@@ -214,7 +215,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if covered != len(blk_seg):
             raise RuntimeError("optimizer overlap plan does not cover every block (%d of %d)" % (covered, len(blk_seg)))
         self._opt_stream = torch.cuda.Stream(device=self.core.flat_params.device)
-        self._events = [torch.cuda.Event() for _ in eng.segments]
+        from .events import DeviceEvent
+        self._events = [DeviceEvent() for _ in eng.segments]
         return True
 
     @torch.no_grad()
@@ -230,7 +232,7 @@ class FusedAdamW(torch.optim.Optimizer):
             n = len(self._seg_blocks)
             if done is None:
                 self._upload_hyper()
-                self._opt_stream.wait_stream(cur)             # gradients (and the hyper-parameter upload) are final
+                order_streams(cur, self._opt_stream)          # gradients (and the hyper-parameter upload) are final
                 order = range(n - 1, -1, -1)                  # first-use order: embeddings ... heads
             else:
                 self._upload_hyper(self._opt_stream)          # not behind the backward pass that `cur` still runs
@@ -245,7 +247,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, self.overlap_workgroups)
                 self._events[sgi].record(self._opt_stream)
             if done is not None:
-                self._opt_stream.wait_stream(cur)             # the gradient memset that follows must not pass backward's tail
+                order_streams(cur, self._opt_stream)          # the gradient memset that follows must not pass backward's tail
             core._param_events = self._events                # the next forward waits segment by segment
             core._opt_stream = self._opt_stream               # ... and the next backward for the whole stream
         else:
@@ -261,7 +263,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def synchronize(self):
         """Order the current stream after an in-flight overlapped update (before reading weights outside forward)."""
         if self._opt_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            order_streams(self._opt_stream, torch.cuda.current_stream())
 
     def zero_grad(self, set_to_none=True):
         # one memset; .grad views stay attached (set_to_none would only force a re-attach next step)

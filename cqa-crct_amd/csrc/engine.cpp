@@ -215,7 +215,10 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
 hipEvent_t ev_new(crct_engine* e) {
   if (e->evnext == e->evpool.size()) {
     hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    // ordering between streams of ONE device: no system-scope fence (host / peer visibility) at the record -- the hand-off
+    // is 2.5-4 us shorter (tools/handoff_lab.cpp); CRCT_EVENT_SYSFENCE=1 restores the default flags for A/B runs
+    static const unsigned flags = getenv("CRCT_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+    if (hipEventCreateWithFlags(&ev, flags) != hipSuccess) return nullptr;
     e->evpool.push_back(ev);
   }
   return e->evpool[e->evnext++];
@@ -1284,6 +1287,40 @@ extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, 
   e->use_vis_stream = use_visual_stream != 0;
   e->use_wgrad_stream = use_wgrad_streams != 0;
   e->streams_forced = true;
+  return 0;
+}
+
+// ---- device-scope ordering events for the host-side glue (optimizer overlap, data-parallel buckets): hipEventDisableTiming |
+// hipEventDisableSystemFence, like the engine's internal ones.  A stock torch.cuda.Event carries a system-scope fence (host /
+// peer visibility) in every record, which these same-device stream orderings do not need.
+extern "C" void* crct_event_create(void) {
+  hipEvent_t ev = nullptr;
+  static const unsigned flags = getenv("CRCT_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+  if (hipEventCreateWithFlags(&ev, flags) != hipSuccess) { crct_set_error("event_create: hipEventCreateWithFlags failed"); return nullptr; }
+  return ev;
+}
+extern "C" void crct_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int crct_event_record(void* ev, crct_stream_t stream) {
+  CRCT_REQUIRE(ev, "event_record: null event");
+  CRCT_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int crct_stream_wait_event(crct_stream_t stream, void* ev) {
+  CRCT_REQUIRE(ev, "stream_wait_event: null event");
+  CRCT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+  return 0;
+}
+extern "C" int crct_event_query(void* ev) {          // 1: everything before the last record has finished, 0: not yet, < 0: error
+  if (!ev) return -1;
+  const hipError_t r = hipEventQuery((hipEvent_t)ev);
+  if (r == hipSuccess) return 1;
+  if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  crct_set_error("event_query: %s", hipGetErrorString(r));
+  return -1;
+}
+extern "C" int crct_event_synchronize(void* ev) {
+  CRCT_REQUIRE(ev, "event_synchronize: null event");
+  CRCT_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev));
   return 0;
 }
 

@@ -446,6 +446,17 @@ int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const in
  * (index = its slot in CrctStepCfg.fp8_w_scale).  Both are fixed at crct_engine_create. */
 int crct_engine_fp8_sites(const crct_engine_t*);
 int crct_engine_fp8_weights(const crct_engine_t*, int64_t* offsets, int64_t* numels, int cap);
+/* Ordering events for same-device stream dependencies of the host-side glue (optimizer overlap, data-parallel buckets, the
+ * CrctStepCfg event arrays): created without timing and without the system-scope fence a default HIP / torch event carries in
+ * every record (a same-device hand-off is ~3 us shorter, the following kernels keep their L2 contents).  NOT for data the
+ * host or a peer device reads. */
+void* crct_event_create(void);
+void crct_event_destroy(void* ev);
+int crct_event_record(void* ev, crct_stream_t stream);
+int crct_stream_wait_event(crct_stream_t stream, void* ev);
+int crct_event_synchronize(void* ev);
+int crct_event_query(void* ev);      /* 1 = complete, 0 = not yet, < 0 = error */
+
 /* Debug taps: copy a named bf16 activation ("emb.t", "t3.t", "c0.v", "seq_t" ...) of the last
  * forward (batch B, T, V) into `out` (device, bf16); returns the element count or -1. */
 int64_t crct_engine_tap(crct_engine_t*, const void* workspace, const char* name, int B, int T, int V,

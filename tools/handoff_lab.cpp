@@ -2,17 +2,21 @@
 //   hipcc -O2 --offload-arch=gfx950 tools/handoff_lab.cpp -o tools/handoff_lab.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 __global__ void spin(long cycles, int* sink) {
   const long t0 = clock64();
   while (clock64() - t0 < cycles) {}
   if (sink && threadIdx.x == 9999) *sink = 1;
 }
-int main() {
+int main(int argc, char** argv) {
   hipStream_t s0, s1; hipStreamCreateWithFlags(&s0, hipStreamNonBlocking); hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
   const int N = 400;
   std::vector<hipEvent_t> ev(2 * N);
-  for (auto& e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  const unsigned flags = argc > 1 ? (unsigned)strtoul(argv[1], nullptr, 0) : (unsigned)hipEventDisableTiming;
+  printf("event flags 0x%x (DisableTiming 0x%x, DisableSystemFence 0x%x, ReleaseToDevice 0x%x)\n", flags, hipEventDisableTiming,
+         hipEventDisableSystemFence, hipEventReleaseToDevice);
+  for (auto& e : ev) if (hipEventCreateWithFlags(&e, flags) != hipSuccess) { printf("event flags rejected\n"); return 1; }
   hipEvent_t t0, t1; hipEventCreate(&t0); hipEventCreate(&t1);
   for (long cyc : {2000L, 20000L}) {          // ~1 us and ~10 us kernels (100 MHz counter? measured below)
     float ms_chain, ms_pp, ms_pp2;
