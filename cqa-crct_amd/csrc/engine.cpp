@@ -357,12 +357,7 @@ struct Run {
   void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M, bool with_bias = false) {
     if (rc) return;
     const bool fold = with_bias && M % 64 == 0 && l.in % 8 == 0 && l.out % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0;
-    if (with_bias && !fold) {
-      if (defer) {                     // dy is not launched yet: the column sums follow it in the queue, on the data stream
-        float* db = G(l.b); float* part = F(colsum_part); const int N = l.out;
-        queue_call([dy, lddy, db, part, M, N](hipStream_t st) { return crct_colsum_bf16(dy, lddy, db, part, M, N, 1, st); });
-      } else bias_grad(dy, lddy, l, M);
-    }
+    if (with_bias && !fold) bias_grad(dy, lddy, l, M);
     if (rc) return;
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -385,9 +380,12 @@ struct Run {
   }
   // launch the queued weight-gradient GEMMs on the side stream, ordered after everything enqueued on s so far
   void flush_wgrads() {
-    if (rc || (pending.empty() && pending_fin.empty())) return;
+    if (rc || (pending.empty() && pending_fin.empty() && pending_bias.empty())) return;
     if (sw == s) ++tick;
     wgrad_after_main();
+    for (const BiasJob& j : pending_bias)
+      if (!rc) fail(crct_colsum_bf16(j.dy, j.lddy, j.db, F(sw != s ? colsum_part_w : colsum_part), j.M, j.N, 1, sw));
+    pending_bias.clear();
     for (const FinJob& f : pending_fin)
       if (!rc) fail(crct_layernorm_bwd_finalize(f.part, f.dg, f.db, f.dlb, f.M, f.H, 1, sw));
     pending_fin.clear();
@@ -395,7 +393,13 @@ struct Run {
       fail(crct_gemm_bf16_grouped(pending.data() + i, (int)std::min<size_t>(8, pending.size() - i), sw));
     pending.clear();
   }
+  // db[out] += column sums of dy: queued like the weight gradients (dy stays valid until the layer's flush), so the data
+  // stream carries no ordering event per call -- the head chain alone had 13 of them between its 13 small data-gradient GEMMs
+  struct BiasJob { const void* dy; int64_t lddy; float* db; int M, N; };
+  std::vector<BiasJob> pending_bias;
   void bias_grad(const void* dy, int64_t lddy, const LinearP& l, int M) {
+    if (rc) return;
+    if (defer_wgrad) { pending_bias.push_back(BiasJob{dy, lddy, G(l.b), M, l.out}); return; }
     wgrad_after_main();
     if (rc) return;
     fail(crct_colsum_bf16(dy, lddy, G(l.b), F(sw != s ? colsum_part_w : colsum_part), M, l.out, 1, sw));

@@ -1,6 +1,7 @@
 // Developer microbenchmark: cost of a cross-stream dependency (event record on one stream, wait on the other) on this stack.
 //   hipcc -O2 --offload-arch=gfx950 tools/handoff_lab.cpp -o tools/handoff_lab.bin
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -57,6 +58,21 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 2 * N; ++i) { hipStreamWaitEvent(s0, ev[0], 0); hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s0, cyc, (int*)nullptr); }
       hipEventRecord(t1, s0); hipEventSynchronize(t1); hipEventElapsedTime(&ms_old, t0, t1);
     }
+    // (f) one chain with an event RECORD after every kernel (nobody waits): what a record costs the recording stream;
+    // (g) the same with the event attached to the kernel's own dispatch packet (hipExtLaunchKernelGGL stop event)
+    float ms_rec, ms_ext;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(t0, s0);
+      for (int i = 0; i < 2 * N; ++i) { hipLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s0, cyc, (int*)nullptr); hipEventRecord(ev[i], s0); }
+      hipEventRecord(t1, s0); hipEventSynchronize(t1); hipEventElapsedTime(&ms_rec, t0, t1);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(t0, s0);
+      for (int i = 0; i < 2 * N; ++i) hipExtLaunchKernelGGL(spin, dim3(256), dim3(64), 0, s0, nullptr, ev[i], 0, cyc, (int*)nullptr);
+      hipEventRecord(t1, s0); hipEventSynchronize(t1); hipEventElapsedTime(&ms_ext, t0, t1);
+    }
+    printf("          event record after every kernel: %.2f us/kernel (+%.2f us) | as the kernel's stop event: %.2f us/kernel (+%.2f us)\n",
+           ms_rec * 1e3 / (2 * N), (ms_rec - ms_chain) * 1e3 / (2 * N), ms_ext * 1e3 / (2 * N), (ms_ext - ms_chain) * 1e3 / (2 * N));
     // (e) ping-pong through stream memory operations (write a counter after the kernel, the other stream waits for it)
     float ms_val = -1.f;
     {
