@@ -69,7 +69,7 @@ def reduce_behind_events(flat_grads, buckets, seg_events, comm_stream, group=Non
     with torch.cuda.stream(comm_stream):
         for last, lo, hi in buckets:
             for ev in seg_events[4 * last:4 * last + 4]:
-                ev.wait(comm_stream)
+                comm_stream.wait_event(ev)
             works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
     for w in works:
         w.wait()
@@ -118,8 +118,12 @@ class FlatGradDDP(object):
             # events and the collectives queue up behind them on a communication stream
             if self._events is None:
                 self._comm = torch.cuda.Stream(device=core.flat_grads.device)
-                from .events import DeviceEvent             # same-device ordering: no system-scope fence per record
-                self._events = [DeviceEvent() for _ in range(4 * len(eng.segments))]
+                # stock torch events (system-scope release at every record): what follows them is a collective whose peers
+                # read and write across GPUs -- unlike the engine-internal and optimizer events (crct/events.py), which order
+                # streams of one device only
+                self._events = [torch.cuda.Event() for _ in range(4 * len(eng.segments))]
+                for ev in self._events:          # torch creates the hipEvent lazily, at the first record
+                    ev.record()
             step["seg_done_events"] = self._events
             eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
             reduce_behind_events(core.flat_grads, self._buckets, self._events, self._comm, self.group)
