@@ -54,10 +54,15 @@ _pool = []
 _next = [0]
 
 
-def order_streams(src, dst):
+def order_streams(src, dst, system=False):
     """Everything enqueued on ``src`` so far happens before whatever is enqueued on ``dst`` from now on (``dst.wait_stream(src)``
-    without the system-scope fence).  Events come from a small ring: an event is re-recorded only long after its waiters ran."""
+    without the system-scope fence).  Events come from a small ring: an event is re-recorded only long after its waiters ran.
+    ``system=True``: the stock torch ordering (system-scope release / acquire) -- for consumers of data that a PEER device
+    has written into local memory (gradients after an all-reduce)."""
     if src.cuda_stream == dst.cuda_stream:
+        return
+    if system:
+        dst.wait_stream(src)
         return
     if len(_pool) < 64:
         _pool.append(DeviceEvent())

@@ -232,7 +232,10 @@ class FusedAdamW(torch.optim.Optimizer):
             n = len(self._seg_blocks)
             if done is None:
                 self._upload_hyper()
-                order_streams(cur, self._opt_stream)          # gradients (and the hyper-parameter upload) are final
+                # gradients (and the hyper-parameter upload) are final; after an all-reduce across GPUs they were written by
+                # peer devices: system-scope ordering then
+                ddp = getattr(core, "_ddp", None)
+                order_streams(cur, self._opt_stream, system=ddp is not None and getattr(ddp, "world", 1) > 1)
                 order = range(n - 1, -1, -1)                  # first-use order: embeddings ... heads
             else:
                 self._upload_hyper(self._opt_stream)          # not behind the backward pass that `cur` still runs
