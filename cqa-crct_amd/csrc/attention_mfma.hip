@@ -281,14 +281,21 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
   }
   wave_sync();
   const float ds = a.thr ? a.dscale : 1.0f;
-  f4_t dq[ND][NQ];
+  // Large tile counts (7 x 3 and up: the 100-element sequences of the long-context configuration) would keep K fragments,
+  // V fragments, every dq tile and every dS tile live at once -- 380 registers for 7 x 7 x 64, 848 bytes per lane of scratch
+  // with the plain code.  LOWREG re-reads the K fragments from their LDS image per query tile and stores each dq tile to
+  // global memory as soon as it is complete (8 bytes per lane) instead of holding all of them for a staged row store.
+  constexpr bool LOWREG = NQ * NK >= 21;
+  f4_t dq[LOWREG ? 1 : ND][LOWREG ? 1 : NQ];
   s4_t dsb[NQ][NK];                     // dS^T tiles (bf16): B operand of dq now, written to the image for dk later
   {
-    s4_t kf[NK][ND];
+    s4_t kf[LOWREG ? 1 : NK][LOWREG ? 1 : ND];
+    if constexpr (!LOWREG) {
 #pragma unroll
-    for (int jt = 0; jt < NK; ++jt)
+      for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
-      for (int ks = 0; ks < ND; ++ks) kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
+        for (int ks = 0; ks < ND; ++ks) kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
+    }
 #pragma unroll
     for (int it = 0; it < NQ; ++it) {
       s4_t qf[ND], of[ND];
@@ -304,7 +311,10 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
         gp[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < ND; ++ks) {
-          p[jt] = mma16(kf[jt][ks], qf[ks], p[jt]);        // S^T[j][i]
+          s4_t kfr;
+          if constexpr (LOWREG) kfr = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
+          else kfr = kf[jt][ks];
+          p[jt] = mma16(kfr, qf[ks], p[jt]);               // S^T[j][i]
           gp[jt] = mma16(vf[jt][ks], of[ks], gp[jt]);      // (dO v^T)^T[j][i]
         }
       }
@@ -333,19 +343,29 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
       // dq^T[c][i] = sum_j k[j][c] dS^T[j][i]
 #pragma unroll
       for (int ct = 0; ct < ND; ++ct) {
-        dq[ct][it] = f4_t{0.f, 0.f, 0.f, 0.f};
+        f4_t t = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jt = 0; jt < NK; ++jt) dq[ct][it] = mma16(frag_cols(Ks, STB, 16 * jt, 16 * ct, lane), dsb[it][jt], dq[ct][it]);
+        for (int jt = 0; jt < NK; ++jt) t = mma16(frag_cols(Ks, STB, 16 * jt, 16 * ct, lane), dsb[it][jt], t);
+        if constexpr (LOWREG) {           // element r = column 16 ct + 4 (lane >> 4) + r of query 16 it + n
+          const int i = 16 * it + n;
+          if (i < a.Tq) {
+            t = t * a.scale;
+            *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Tq + i) * a.lddq + h * d + 16 * ct + 4 * (lane >> 4)) =
+                make_uint2(pack2bf(t[0], t[1]), pack2bf(t[2], t[3]));
+          }
+        } else dq[ct][it] = t;
       }
     }
   }
   wave_sync();                          // K is consumed (its image becomes the staging tile); the P image is complete
+  if constexpr (!LOWREG) {
 #pragma unroll
-  for (int it = 0; it < NQ; ++it)
+    for (int it = 0; it < NQ; ++it)
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * it, 16 * ct, dq[ct][it] * a.scale, lane);
-  wave_sync();
-  store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane);
+      for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * it, 16 * ct, dq[ct][it] * a.scale, lane);
+    wave_sync();
+    store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane);
+  }
   // dv^T[c][j] = sum_i dO[i][c] Pd[i][j]
   f4_t acc[ND][NK];
 #pragma unroll

@@ -1250,7 +1250,7 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   Rv.main_after_wgrad();
   Rt.fail(order_streams(e, Rv.s, Rt.s));
   static const bool dbg_ev = getenv("CRCT_DEBUG_EVENTS") != nullptr;
-  if (dbg_ev) fprintf(stderr, "[crct] backward: %d ordering events\n", e->evnext);
+  if (dbg_ev) fprintf(stderr, "[crct] backward: %d ordering events\n", (int)e->evnext);
   return Rt.rc ? Rt.rc : Rv.rc;
 }
 
