@@ -504,3 +504,30 @@ def test_grouped_pair_with_epilogues_equals_single_launches(mode, gemm_path):
     for a, b in zip(single, grouped):
         assert torch.equal(a, b)
         assert float(a.float().abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------- device-scope ordering events
+def test_device_events_order_streams_without_the_system_fence(gemm_path):
+    """crct/events.py (crct_event_*): record on one stream, wait on another, query / synchronize from the host; the consumer
+    stream must see the producer's kernel results (same-device visibility is all these events promise)."""
+    if gemm_path != "pipelined":
+        pytest.skip("no GEMM in this test")
+    from crct.events import DeviceEvent, order_streams
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 22, device=DEV)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    ev = DeviceEvent()
+    for it in range(20):
+        with torch.cuda.stream(s1):
+            x.add_(1.0)                               # producer
+            ev.record(s1)
+        ev.wait(s2)
+        with torch.cuda.stream(s2):
+            y.copy_(x)                                # consumer on another stream
+        order_streams(s2, s1)                         # the next producer pass must not overtake the copy
+    ev2 = DeviceEvent()
+    ev2.record(s2)
+    ev2.synchronize()
+    assert ev2.query() and ev.query()
+    assert float(y.min()) == 20.0 and float(y.max()) == 20.0
