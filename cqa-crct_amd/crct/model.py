@@ -21,7 +21,7 @@ from . import lib as L
 from . import ops
 from .config import BertConfig
 from .engine import StepEngine
-from .layout import parameter_table, used_span
+from .layout import parameter_table
 
 
 class _Node(nn.Module):
