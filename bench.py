@@ -248,7 +248,9 @@ def main():
         batch = next(cur["feed"])
         loss = step_forward(model, batch, params)[0]
         if world > 1:
-            all_reduce_stats(core.last_stats[8:17], world)       # the reference's per-iteration stats exchange (train.py:181-189)
+            # the reference's per-iteration stats exchange (train.py:181-189) on a COPY, as the reference builds a new tensor: the
+            # loss autograd returns is a view of the same output buffer and must not be modified in place before backward
+            all_reduce_stats(core.last_stats[8:17].clone(), world)
         loss.backward()
         opt.step()
         opt.zero_grad()

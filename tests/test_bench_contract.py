@@ -52,3 +52,27 @@ def test_cpu_baseline_object(line):
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == line["unit"]
     assert c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str) and c["sample"]
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_runs_end_to_end():
+    """The N > 1 path of bench.py as the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 ...`), on this one-GPU box with both ranks on cuda:0 and gloo between them (CRCT_BENCH_SHARE_GPU: a developer
+    switch that changes the process group only): FlatGradDDP in event mode, the stats all-reduce inside the step, the
+    overlapped optimizer, max-over-ranks timing, ONE JSON line from rank 0.  (Round 2 shipped for a while with an in-place
+    all-reduce on the buffer the loss is a view of -- every N > 1 run died in backward; this test is the guard.)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, CRCT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--profile-steps", "0", "--no-h2d-leg"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    rows = [r for r in res.stdout.strip().split("\n") if r.startswith("{")]
+    assert len(rows) == 1, rows
+    line = json.loads(rows[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 2 * 80 and line["value"] > 0
