@@ -1048,7 +1048,7 @@ static int env_cfg(const char* name) { const char* v = getenv(name); return v ? 
 //   tnl  text rows, narrow output, long K (> 1024)                FFN-down forward, FFN-up / QKV data gradient
 //   vw   visual rows (M > 2000), wide output                      visual / co-attention QKV forward
 //   vm   visual rows, N <= 1024, K <= 1024                        visual projections and FFN, both directions
-//   vml  visual rows, N <= 1024, long K                           QKV data gradient, image-embedding forward
+//   vml  visual rows, N <= 1024, long K                           QKV data gradient, image-embedding forward (128 x 128 tiles: id 4)
 // Round 2 tried a tile-flexible variant of the LDS-DMA kernel (160 x 128, 96 x 64, 192 x 192 ... tiles that cover M = 1600 /
 // 2880 in ONE round of workgroups, 4 or 8 waves, 3-4 stages, in-place inline-asm MFMAs, half-tile register double buffering;
 // commit 11e1801).  Stand-alone with cold weights it won 10-17 % on several shapes (profiles/r2_gemm_lab_cold.txt), in the
@@ -1056,7 +1056,7 @@ static int env_cfg(const char* name) { const char* v = getenv(name); return v ? 
 // so the kernels of the other internal streams can no longer share the CUs.  The 48-72 KB configurations below stay.
 enum { CLS_TW, CLS_TN, CLS_TNL, CLS_VW, CLS_VM, CLS_VML, CLS_COUNT };
 static const int* class_table() {
-  static int tab[CLS_COUNT] = {12, 12, 15, 12, 12, 15};
+  static int tab[CLS_COUNT] = {12, 12, 15, 12, 12, 4};      // vml: 128x128, 3 stages (long context 12.33 -> 12.19 ms, configs[1] 7.61 -> 7.56)
   static bool init = false;
   if (!init) {
     init = true;
