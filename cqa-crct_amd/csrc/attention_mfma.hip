@@ -1,4 +1,4 @@
-// MFMA attention for the short CRCT sequences: ONE WAVE per (batch, head), sequences up to 112 queries x
+// MFMA attention for the short CRCT sequences: one, two or four waves per (batch, head) (see launch()), sequences up to 112 queries x
 // 112 keys (1-4 or 7 tiles of 16 per side), head size 32 / 48 / 64.  Same math and the same dropout stream as attention.hip (which stays
 // the path for longer sequences):
 //   P = softmax(q k^T / sqrt(d) + (1 - keymask) * -10000) ; ctx = dropout(P) v
@@ -24,10 +24,11 @@
 #include "attention_args.h"
 
 //
-// A workgroup holds W = 1, 2 or 4 independent waves (consecutive (batch, head) pairs), each with its own slice
-// of the dynamic LDS allocation; W is chosen per launch so that a CU's 160 KB hold as many waves as possible.
-// The waves never exchange data, so phases are separated by wave-level fences only (LDS operations of one wave
-// execute in issue order) and a wave past the end of the grid simply exits.
+// A workgroup holds W = 1, 2 or 4 independent (batch, head) pairs, each with its own slice of the dynamic LDS allocation
+// (W is chosen per launch so that a CU's 160 KB hold as many pairs as possible) and SP = 1, 2 or 4 waves per pair.
+// With SP = 1 the waves never exchange data: phases are separated by wave-level fences only (LDS operations of one wave
+// execute in issue order) and a wave past the end of the grid simply exits; with SP > 1 the waves of a pair split the
+// query tiles (scores, softmax, dS, dq) and the key tiles (dv, dk) and meet at workgroup barriers between the phases.
 namespace {
 
 typedef s4_t __attribute__((address_space(3))) * lds_s4_ptr;
@@ -37,6 +38,14 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// SP == 1: one wave owns a (batch, head) -- a wave-level fence separates its phases; SP > 1: the SP waves that share
+// the (batch, head)'s LDS images meet at a workgroup barrier (every wave of the workgroup takes the same path)
+template <int SP>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (SP == 1) wave_sync();
+  else __syncthreads();
+}
+
 __device__ __forceinline__ f4_t mma16(s4_t a, s4_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
 // rows [T][16*ND] bf16 (row stride ld) -> LDS image of 16*NT rows (rows >= T are zero), in two phases so that the global
@@ -44,32 +53,33 @@ __device__ __forceinline__ f4_t mma16(s4_t a, s4_t b, f4_t c) { return __builtin
 // matrix unconditionally (rows past T re-read row 0 and are zeroed afterwards: no branch, no wait between loads),
 // put() stores the registers to the image.  (A plain load -> store loop costs one memory round trip per 64 chunks and
 // matrix: 6-14 serial round trips in front of 2-3 us of arithmetic.)
-template <int ND, int NT>
+template <int ND, int NT, int SP = 1>
 struct RowTile {
-  static constexpr int CPR = 2 * ND, STB = 32 * ND + 16, CHUNKS = 16 * NT * CPR, ITER = (CHUNKS + 63) / 64;
+  // SP cooperating waves share the chunks of the matrix round-robin (chunk c belongs to wave (c / 64) % SP)
+  static constexpr int CPR = 2 * ND, STB = 32 * ND + 16, CHUNKS = 16 * NT * CPR, ITER = (CHUNKS + 64 * SP - 1) / (64 * SP);
   uint4 reg[ITER];
-  __device__ __forceinline__ void fetch(const bf16_t* __restrict__ src, long ld, int T, int lane) {
+  __device__ __forceinline__ void fetch(const bf16_t* __restrict__ src, long ld, int T, int lane, int part = 0) {
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-      const int c = lane + 64 * i, r = c / CPR, cc = (c - r * CPR) << 3;
+      const int c = lane + 64 * (part + SP * i), r = c / CPR, cc = (c - r * CPR) << 3;
       const int rr = min(r, T - 1);                            // c >= CHUNKS implies r >= 16 * NT >= T
       const uint32_t m = r < T ? 0xffffffffu : 0u;             // mask, not a select: the load must stay unconditional
       const uint4 u = *reinterpret_cast<const uint4*>(src + (long)rr * ld + cc);
       reg[i] = make_uint4(u.x & m, u.y & m, u.z & m, u.w & m);
     }
   }
-  __device__ __forceinline__ void put(char* img, int lane) const {
+  __device__ __forceinline__ void put(char* img, int lane, int part = 0) const {
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-      const int c = lane + 64 * i, r = c / CPR, cc = (c - r * CPR) << 3;
-      if (CHUNKS % 64 == 0 || c < CHUNKS) *reinterpret_cast<uint4*>(img + r * STB + cc * 2) = reg[i];
+      const int c = lane + 64 * (part + SP * i), r = c / CPR, cc = (c - r * CPR) << 3;
+      if (c < CHUNKS) *reinterpret_cast<uint4*>(img + r * STB + cc * 2) = reg[i];
     }
   }
 };
-template <int ND>
-__device__ __forceinline__ void store_rows(bf16_t* dst, long ld, const char* img, int T, int lane) {
+template <int ND, int SP = 1>
+__device__ __forceinline__ void store_rows(bf16_t* dst, long ld, const char* img, int T, int lane, int part = 0) {
   constexpr int CPR = 2 * ND, STB = 32 * ND + 16;
-  for (int c = lane; c < T * CPR; c += 64) {
+  for (int c = lane + 64 * part; c < T * CPR; c += 64 * SP) {
     const int r = c / CPR, cc = (c - r * CPR) << 3;
     *reinterpret_cast<uint4*>(dst + (long)r * ld + cc) = *reinterpret_cast<const uint4*>(img + r * STB + cc * 2);
   }
@@ -183,80 +193,98 @@ template <int NQ, int NK, int ND> struct BwdLds {
   static constexpr int BYTES = 16 * (2 * NQ + NX) * STB + 16 * NQ * PSB;
 };
 
-template <int NQ, int NK, int ND, int W>
-__global__ __launch_bounds__(64 * W) void attn_fwd_mfma(const AttnArgs a) {
+// W independent (batch, head) pairs per workgroup, SP cooperating waves per pair (query tiles it = part, part + SP, ...):
+// the arithmetic per tile is the same for every SP, so are the results bit for bit.
+template <int NQ, int NK, int ND, int W, int SP>
+__global__ __launch_bounds__(64 * W * SP) void attn_fwd_mfma(const AttnArgs a) {
   constexpr int STB = FwdLds<NQ, NK, ND>::STB;
+  constexpr int NQL = (NQ + SP - 1) / SP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, n = lane & 15;
-  const long bh = (long)blockIdx.x * W + (threadIdx.x >> 6);
-  if (bh >= (long)a.B * a.heads) return;
-  char* Qs = smem + (threadIdx.x >> 6) * FwdLds<NQ, NK, ND>::BYTES;
+  const int wv = threadIdx.x >> 6, grp = wv / SP, part = wv % SP;
+  const long total = (long)a.B * a.heads;
+  long bh = (long)blockIdx.x * W + grp;
+  const bool live = bh < total;
+  if constexpr (SP == 1) { if (!live) return; }
+  else if (!live) bh = total - 1;       // a surplus group of the last workgroup recomputes the last pair and stores nothing
+  char* Qs = smem + grp * FwdLds<NQ, NK, ND>::BYTES;
   char* Ks = Qs + 16 * NQ * STB;
   char* Vs = Ks + 16 * NK * STB;
   const int b = (int)(bh / a.heads), h = (int)(bh % a.heads), d = 16 * ND;
   uint32_t attend, valid;
   {
-    RowTile<ND, NQ> tq;
-    RowTile<ND, NK> tk, tv;
-    tq.fetch(a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, lane);
-    tk.fetch(a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, lane);
-    tv.fetch(a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, lane);
+    RowTile<ND, NQ, SP> tq;
+    RowTile<ND, NK, SP> tk, tv;
+    tq.fetch(a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, lane, part);
+    tk.fetch(a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, lane, part);
+    tv.fetch(a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, lane, part);
     key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
-    tq.put(Qs, lane);
-    tk.put(Ks, lane);
-    tv.put(Vs, lane);
+    tq.put(Qs, lane, part);
+    tk.put(Ks, lane, part);
+    tv.put(Vs, lane, part);
   }
-  wave_sync();
+  group_sync<SP>();
   s4_t kf[NK][ND];
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
     for (int ks = 0; ks < ND; ++ks) kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
 #pragma unroll
-  for (int it = 0; it < NQ; ++it) {
-    s4_t qf[ND];
+  for (int li = 0; li < NQL; ++li) {
+    const int it = part + SP * li;
+    if (it < NQ) {
+      s4_t qf[ND];
 #pragma unroll
-    for (int ks = 0; ks < ND; ++ks) qf[ks] = frag_rows(Qs, STB, 16 * it, 16 * ks, lane);
-    f4_t s[NK];
+      for (int ks = 0; ks < ND; ++ks) qf[ks] = frag_rows(Qs, STB, 16 * it, 16 * ks, lane);
+      f4_t s[NK];
 #pragma unroll
-    for (int jt = 0; jt < NK; ++jt) {
-      s[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
+      for (int jt = 0; jt < NK; ++jt) {
+        s[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < ND; ++ks) s[jt] = mma16(kf[jt][ks], qf[ks], s[jt]);      // S^T[j][i]
-    }
-    uint32_t keep;
-    softmax_cols<NK>(s, keep, attend, valid, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
-    const float ds = a.thr ? a.dscale : 1.0f;
-    s4_t pb[NK];
+        for (int ks = 0; ks < ND; ++ks) s[jt] = mma16(kf[jt][ks], qf[ks], s[jt]);      // S^T[j][i]
+      }
+      uint32_t keep;
+      softmax_cols<NK>(s, keep, attend, valid, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
+      const float ds = a.thr ? a.dscale : 1.0f;
+      s4_t pb[NK];
 #pragma unroll
-    for (int jt = 0; jt < NK; ++jt) {
-      f4_t p;
+      for (int jt = 0; jt < NK; ++jt) {
+        f4_t p;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = ((keep >> (4 * jt + r)) & 1u) ? s[jt][r] * ds : 0.f;
-      pb[jt] = pack4(p);
-    }
-    // the 16 query rows of this block have been read into qf: their slot in the Q image takes the output tile
+        for (int r = 0; r < 4; ++r) p[r] = ((keep >> (4 * jt + r)) & 1u) ? s[jt][r] * ds : 0.f;
+        pb[jt] = pack4(p);
+      }
+      // the 16 query rows of this block have been read into qf: their slot in the Q image takes the output tile
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) {
-      f4_t o = f4_t{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < ND; ++ct) {
+        f4_t o = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jt = 0; jt < NK; ++jt) o = mma16(frag_cols(Vs, STB, 16 * jt, 16 * ct, lane), pb[jt], o);   // ctx^T[c][i]
-      put_tile_t(Qs, STB, 16 * it, 16 * ct, o, lane);
+        for (int jt = 0; jt < NK; ++jt) o = mma16(frag_cols(Vs, STB, 16 * jt, 16 * ct, lane), pb[jt], o);   // ctx^T[c][i]
+        put_tile_t(Qs, STB, 16 * it, 16 * ct, o, lane);
+      }
     }
   }
-  wave_sync();
-  store_rows<ND>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq, lane);
+  group_sync<SP>();
+  if (live) store_rows<ND, SP>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq, lane, part);
 }
 
-template <int NQ, int NK, int ND, int W>
-__global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
+// SP cooperating waves per (batch, head): phase 1 (scores, softmax, dS, dq) by QUERY tiles it = part, part + SP, ...; the two
+// products that contract over the queries (dv, dk) by KEY tiles jt = part, part + SP, ... from the P / dS image all waves
+// have filled.  Every tile is computed exactly as with one wave, in the same summation order: bit-identical results.
+template <int NQ, int NK, int ND, int W, int SP>
+__global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
   typedef BwdLds<NQ, NK, ND> G;
   constexpr int STB = G::STB, PSB = G::PSB;
+  constexpr int NQL = (NQ + SP - 1) / SP, NKL = (NK + SP - 1) / SP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, n = lane & 15;
-  const long bh = (long)blockIdx.x * W + (threadIdx.x >> 6);
-  if (bh >= (long)a.B * a.heads) return;
-  char* Qs = smem + (threadIdx.x >> 6) * G::BYTES;
+  const int wv = threadIdx.x >> 6, grp = wv / SP, part = wv % SP;
+  const long total = (long)a.B * a.heads;
+  long bh = (long)blockIdx.x * W + grp;
+  const bool live = bh < total;
+  if constexpr (SP == 1) { if (!live) return; }
+  else if (!live) bh = total - 1;       // a surplus group of the last workgroup recomputes the last pair and stores nothing
+  char* Qs = smem + grp * G::BYTES;
   char* Os = Qs + 16 * NQ * STB;        // dO
   char* Ks = Os + 16 * NQ * STB;        // K (16 * max(NQ, NK) rows: later the staging tile of dq / dv / dk)
   char* Pi = Ks + 16 * G::NX * STB;     // dropout(P) [i][j], then dS [i][j]
@@ -265,29 +293,31 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
   s4_t vf[NK][ND];                      // V is only ever contracted along its columns: fragments straight from global
   uint32_t attend, valid;
   {
-    RowTile<ND, NQ> tq, to;
-    RowTile<ND, NK> tk;
-    tq.fetch(a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, lane);
-    to.fetch(a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, lane);
-    tk.fetch(a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, lane);
+    RowTile<ND, NQ, SP> tq, to;
+    RowTile<ND, NK, SP> tk;
+    tq.fetch(a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, lane, part);
+    to.fetch(a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, lane, part);
+    tk.fetch(a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, lane, part);
 #pragma unroll
     for (int jt = 0; jt < NK; ++jt)
 #pragma unroll
       for (int ks = 0; ks < ND; ++ks) vf[jt][ks] = frag_rows_global(vg, a.ldv, a.Tk, 16 * jt, 16 * ks, lane);
     key_bits<NK>(a.keymask + (long)b * a.Tk, a.Tk, lane, attend, valid);
-    tq.put(Qs, lane);
-    to.put(Os, lane);
-    tk.put(Ks, lane);
+    tq.put(Qs, lane, part);
+    to.put(Os, lane, part);
+    tk.put(Ks, lane, part);
   }
-  wave_sync();
+  group_sync<SP>();
   const float ds = a.thr ? a.dscale : 1.0f;
   // Large tile counts (7 x 3 and up: the 100-element sequences of the long-context configuration) would keep K fragments,
   // V fragments, every dq tile and every dS tile live at once -- 380 registers for 7 x 7 x 64, 848 bytes per lane of scratch
-  // with the plain code.  LOWREG re-reads the K fragments from their LDS image per query tile and stores each dq tile to
-  // global memory as soon as it is complete (8 bytes per lane) instead of holding all of them for a staged row store.
+  // with the plain code.  LOWREG re-reads the K fragments from their LDS image per query tile; DQ_DIRECT stores each dq tile
+  // to global memory as soon as it is complete (8 bytes per lane) instead of holding all of them for a staged row store
+  // (also with cooperating waves: the K image, which is the staging tile, is still being read by the other wave).
   constexpr bool LOWREG = NQ * NK >= 21;
-  f4_t dq[LOWREG ? 1 : ND][LOWREG ? 1 : NQ];
-  s4_t dsb[NQ][NK];                     // dS^T tiles (bf16): B operand of dq now, written to the image for dk later
+  constexpr bool DQ_DIRECT = LOWREG || SP > 1;
+  f4_t dq[DQ_DIRECT ? 1 : ND][DQ_DIRECT ? 1 : NQ];
+  s4_t dsb[NQL][NK];                    // dS^T tiles (bf16) of this wave's query tiles: B operand of dq now, written to the image for dk later
   {
     s4_t kf[LOWREG ? 1 : NK][LOWREG ? 1 : ND];
     if constexpr (!LOWREG) {
@@ -297,68 +327,71 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
         for (int ks = 0; ks < ND; ++ks) kf[jt][ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
     }
 #pragma unroll
-    for (int it = 0; it < NQ; ++it) {
-      s4_t qf[ND], of[ND];
-#pragma unroll
-      for (int ks = 0; ks < ND; ++ks) {
-        qf[ks] = frag_rows(Qs, STB, 16 * it, 16 * ks, lane);
-        of[ks] = frag_rows(Os, STB, 16 * it, 16 * ks, lane);
-      }
-      f4_t p[NK], gp[NK];
-#pragma unroll
-      for (int jt = 0; jt < NK; ++jt) {
-        p[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
-        gp[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int li = 0; li < NQL; ++li) {
+      const int it = part + SP * li;
+      if (it < NQ) {
+        s4_t qf[ND], of[ND];
 #pragma unroll
         for (int ks = 0; ks < ND; ++ks) {
-          s4_t kfr;
-          if constexpr (LOWREG) kfr = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
-          else kfr = kf[jt][ks];
-          p[jt] = mma16(kfr, qf[ks], p[jt]);               // S^T[j][i]
-          gp[jt] = mma16(vf[jt][ks], of[ks], gp[jt]);      // (dO v^T)^T[j][i]
+          qf[ks] = frag_rows(Qs, STB, 16 * it, 16 * ks, lane);
+          of[ks] = frag_rows(Os, STB, 16 * it, 16 * ks, lane);
         }
-      }
-      uint32_t keep;
-      softmax_cols<NK>(p, keep, attend, valid, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
-      float part = 0.f;
+        f4_t p[NK], gp[NK];
 #pragma unroll
-      for (int jt = 0; jt < NK; ++jt)
+        for (int jt = 0; jt < NK; ++jt) {
+          p[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
+          gp[jt] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gp[jt][r] = ((keep >> (4 * jt + r)) & 1u) ? gp[jt][r] * ds : 0.f;        // gradient w.r.t. P (through dropout)
-          part += gp[jt][r] * p[jt][r];
-        }
-      const float delta = xsum2(part);
-#pragma unroll
-      for (int jt = 0; jt < NK; ++jt) {
-        f4_t dsv, pd;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dsv[r] = p[jt][r] * (gp[jt][r] - delta);
-          pd[r] = ((keep >> (4 * jt + r)) & 1u) ? p[jt][r] * ds : 0.f;
-        }
-        dsb[it][jt] = pack4(dsv);
-        put_tile_t(Pi, PSB, 16 * it, 16 * jt, pd, lane);
-      }
-      // dq^T[c][i] = sum_j k[j][c] dS^T[j][i]
-#pragma unroll
-      for (int ct = 0; ct < ND; ++ct) {
-        f4_t t = f4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jt = 0; jt < NK; ++jt) t = mma16(frag_cols(Ks, STB, 16 * jt, 16 * ct, lane), dsb[it][jt], t);
-        if constexpr (LOWREG) {           // element r = column 16 ct + 4 (lane >> 4) + r of query 16 it + n
-          const int i = 16 * it + n;
-          if (i < a.Tq) {
-            t = t * a.scale;
-            *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Tq + i) * a.lddq + h * d + 16 * ct + 4 * (lane >> 4)) =
-                make_uint2(pack2bf(t[0], t[1]), pack2bf(t[2], t[3]));
+          for (int ks = 0; ks < ND; ++ks) {
+            s4_t kfr;
+            if constexpr (LOWREG) kfr = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
+            else kfr = kf[jt][ks];
+            p[jt] = mma16(kfr, qf[ks], p[jt]);               // S^T[j][i]
+            gp[jt] = mma16(vf[jt][ks], of[ks], gp[jt]);      // (dO v^T)^T[j][i]
           }
-        } else dq[ct][it] = t;
+        }
+        uint32_t keep;
+        softmax_cols<NK>(p, keep, attend, valid, a.Tk, a.Tq, 16 * it + n, bh, a, lane);
+        float psum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NK; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gp[jt][r] = ((keep >> (4 * jt + r)) & 1u) ? gp[jt][r] * ds : 0.f;        // gradient w.r.t. P (through dropout)
+            psum += gp[jt][r] * p[jt][r];
+          }
+        const float delta = xsum2(psum);
+#pragma unroll
+        for (int jt = 0; jt < NK; ++jt) {
+          f4_t dsv, pd;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dsv[r] = p[jt][r] * (gp[jt][r] - delta);
+            pd[r] = ((keep >> (4 * jt + r)) & 1u) ? p[jt][r] * ds : 0.f;
+          }
+          dsb[li][jt] = pack4(dsv);
+          put_tile_t(Pi, PSB, 16 * it, 16 * jt, pd, lane);
+        }
+        // dq^T[c][i] = sum_j k[j][c] dS^T[j][i]
+#pragma unroll
+        for (int ct = 0; ct < ND; ++ct) {
+          f4_t t = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jt = 0; jt < NK; ++jt) t = mma16(frag_cols(Ks, STB, 16 * jt, 16 * ct, lane), dsb[li][jt], t);
+          if constexpr (DQ_DIRECT) {        // element r = column 16 ct + 4 (lane >> 4) + r of query 16 it + n
+            const int i = 16 * it + n;
+            if (live && i < a.Tq) {
+              t = t * a.scale;
+              *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Tq + i) * a.lddq + h * d + 16 * ct + 4 * (lane >> 4)) =
+                  make_uint2(pack2bf(t[0], t[1]), pack2bf(t[2], t[3]));
+            }
+          } else dq[ct][it] = t;
+        }
       }
     }
   }
-  wave_sync();                          // K is consumed (its image becomes the staging tile); the P image is complete
-  if constexpr (!LOWREG) {
+  group_sync<SP>();                     // K is consumed (its image becomes the staging tile); the P image is complete
+  if constexpr (!DQ_DIRECT) {
 #pragma unroll
     for (int it = 0; it < NQ; ++it)
 #pragma unroll
@@ -366,52 +399,70 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_mfma(const AttnArgs a) {
     wave_sync();
     store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane);
   }
-  // dv^T[c][j] = sum_i dO[i][c] Pd[i][j]
-  f4_t acc[ND][NK];
+  // dv^T[c][j] = sum_i dO[i][c] Pd[i][j]     (this wave's key tiles)
+  f4_t acc[ND][NKL];
 #pragma unroll
-  for (int jt = 0; jt < NK; ++jt) {
-    s4_t pf[NQ];
+  for (int lj = 0; lj < NKL; ++lj) {
+    const int jt = part + SP * lj;
+    if (jt < NK) {
+      s4_t pf[NQ];
 #pragma unroll
-    for (int it = 0; it < NQ; ++it) pf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
+      for (int it = 0; it < NQ; ++it) pf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) {
-      acc[ct][jt] = f4_t{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < ND; ++ct) {
+        acc[ct][lj] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int it = 0; it < NQ; ++it) acc[ct][jt] = mma16(frag_cols(Os, STB, 16 * it, 16 * ct, lane), pf[it], acc[ct][jt]);
+        for (int it = 0; it < NQ; ++it) acc[ct][lj] = mma16(frag_cols(Os, STB, 16 * it, 16 * ct, lane), pf[it], acc[ct][lj]);
+      }
     }
   }
-  wave_sync();                          // dq has left the staging tile, P has been read: the image now takes dS
+  group_sync<SP>();                     // dq has left the staging tile, P has been read by every wave: the image now takes dS
 #pragma unroll
-  for (int it = 0; it < NQ; ++it)
+  for (int li = 0; li < NQL; ++li) {
+    const int it = part + SP * li;
+    if (it < NQ) {
 #pragma unroll
-    for (int jt = 0; jt < NK; ++jt)
-      *reinterpret_cast<s4_t*>(Pi + (16 * it + n) * PSB + (16 * jt + 4 * (lane >> 4)) * 2) = dsb[it][jt];
-#pragma unroll
-  for (int jt = 0; jt < NK; ++jt)
-#pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * jt, 16 * ct, acc[ct][jt], lane);
-  wave_sync();
-  store_rows<ND>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, Ks, a.Tk, lane);
-  // dk^T[c][j] = sum_i q[i][c] dS[i][j]
-#pragma unroll
-  for (int jt = 0; jt < NK; ++jt) {
-    s4_t sf[NQ];
-#pragma unroll
-    for (int it = 0; it < NQ; ++it) sf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
-#pragma unroll
-    for (int ct = 0; ct < ND; ++ct) {
-      acc[ct][jt] = f4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int it = 0; it < NQ; ++it) acc[ct][jt] = mma16(frag_cols(Qs, STB, 16 * it, 16 * ct, lane), sf[it], acc[ct][jt]);
+      for (int jt = 0; jt < NK; ++jt)
+        *reinterpret_cast<s4_t*>(Pi + (16 * it + n) * PSB + (16 * jt + 4 * (lane >> 4)) * 2) = dsb[li][jt];
     }
   }
-  wave_sync();                          // dv has left the staging tile
 #pragma unroll
-  for (int jt = 0; jt < NK; ++jt)
+  for (int lj = 0; lj < NKL; ++lj) {
+    const int jt = part + SP * lj;
+    if (jt < NK) {
 #pragma unroll
-    for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * jt, 16 * ct, acc[ct][jt] * a.scale, lane);
-  wave_sync();
-  store_rows<ND>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, Ks, a.Tk, lane);
+      for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * jt, 16 * ct, acc[ct][lj], lane);
+    }
+  }
+  group_sync<SP>();
+  if (live) store_rows<ND, SP>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, Ks, a.Tk, lane, part);
+  // dk^T[c][j] = sum_i q[i][c] dS[i][j]      (this wave's key tiles)
+#pragma unroll
+  for (int lj = 0; lj < NKL; ++lj) {
+    const int jt = part + SP * lj;
+    if (jt < NK) {
+      s4_t sf[NQ];
+#pragma unroll
+      for (int it = 0; it < NQ; ++it) sf[it] = frag_cols(Pi, PSB, 16 * it, 16 * jt, lane);
+#pragma unroll
+      for (int ct = 0; ct < ND; ++ct) {
+        acc[ct][lj] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) acc[ct][lj] = mma16(frag_cols(Qs, STB, 16 * it, 16 * ct, lane), sf[it], acc[ct][lj]);
+      }
+    }
+  }
+  group_sync<SP>();                     // dv has left the staging tile
+#pragma unroll
+  for (int lj = 0; lj < NKL; ++lj) {
+    const int jt = part + SP * lj;
+    if (jt < NK) {
+#pragma unroll
+      for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * jt, 16 * ct, acc[ct][lj] * a.scale, lane);
+    }
+  }
+  group_sync<SP>();
+  if (live) store_rows<ND, SP>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, Ks, a.Tk, lane, part);
 }
 
 // waves per workgroup: the largest of 4 / 2 / 1 that does not lower the number of waves a CU's LDS can hold
@@ -421,12 +472,13 @@ constexpr int waves_per_group(int bytes_per_wave) {
   return (w4 >= w1 && w4 >= w2) ? 4 : (w2 >= w1 ? 2 : 1);
 }
 
-template <bool BWD, int NQ, int NK, int ND>
-hipError_t launch(const AttnArgs& a, hipStream_t s) {
+template <bool BWD, int NQ, int NK, int ND, int SP>
+hipError_t launch_sp(const AttnArgs& a, hipStream_t s) {
   constexpr int BYTES = BWD ? BwdLds<NQ, NK, ND>::BYTES : FwdLds<NQ, NK, ND>::BYTES;
-  constexpr int W = waves_per_group(BYTES);
+  constexpr int W0 = waves_per_group(BYTES);
+  constexpr int W = W0 * SP > 8 ? 8 / SP : W0;        // at most 512 threads per workgroup
   static_assert(BYTES % 16 == 0 && BYTES * W <= 160 * 1024, "LDS slice");
-  auto kern = BWD ? attn_bwd_mfma<NQ, NK, ND, W> : attn_fwd_mfma<NQ, NK, ND, W>;
+  auto kern = BWD ? attn_bwd_mfma<NQ, NK, ND, W, SP> : attn_fwd_mfma<NQ, NK, ND, W, SP>;
   static bool raised = false;           // first call is eager (outside any stream capture)
   if (BYTES * W > 64 * 1024 && !raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES * W);
@@ -434,8 +486,24 @@ hipError_t launch(const AttnArgs& a, hipStream_t s) {
     raised = true;
   }
   const int total = a.B * a.heads;
-  hipLaunchKernelGGL(kern, dim3((total + W - 1) / W), dim3(64 * W), BYTES * W, s, a);
+  hipLaunchKernelGGL(kern, dim3((total + W - 1) / W), dim3(64 * W * SP), BYTES * W, s, a);
   return hipGetLastError();
+}
+// Waves per (batch, head): 4 when both sides have at least four tiles, 2 with at least two (each wave then owns whole query
+// tiles in the first phase and whole key tiles in the second), else 1.  Long context (B = 64, V = 100, T = 40): 12.28 ms per
+// step with one wave, 11.90 with two, 11.83 with four for the 7 x 7-tile launches; configs[1] (2-3 tiles): unchanged.
+// CRCT_ATTN_SPLIT=1 / 2 / 4 forces a count (developer A/B: every count gives the same bits).
+template <bool BWD, int NQ, int NK, int ND>
+hipError_t launch(const AttnArgs& a, hipStream_t s) {
+  static const int forced = [] { const char* e = getenv("CRCT_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+  constexpr bool can2 = NQ >= 2 && NK >= 2, can4 = NQ >= 4 && NK >= 4;
+  if constexpr (can4) {
+    if (forced == 4 || forced == 0) return launch_sp<BWD, NQ, NK, ND, 4>(a, s);
+  }
+  if constexpr (can2) {
+    if (forced != 1) return launch_sp<BWD, NQ, NK, ND, 2>(a, s);
+  }
+  return launch_sp<BWD, NQ, NK, ND, 1>(a, s);
 }
 template <bool BWD, int NQ, int NK>
 hipError_t pick_d(const AttnArgs& a, hipStream_t s) {

@@ -531,3 +531,49 @@ def test_device_events_order_streams_without_the_system_fence(gemm_path):
     ev2.synchronize()
     assert ev2.query() and ev.query()
     assert float(y.min()) == 20.0 and float(y.max()) == 20.0
+
+
+# ------------------------------------------------------------------------------------------- attention: waves per (batch, head)
+_ATTN_SPLIT_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from crct import ops
+out = {}
+for name, B, h, Tq, Tk, d in (("self100", 3, 16, 100, 100, 64), ("co40x100", 3, 32, 40, 100, 32), ("self36", 5, 16, 36, 36, 64),
+                              ("self20", 5, 16, 20, 20, 48), ("self64", 2, 16, 64, 50, 48)):
+    g = torch.Generator().manual_seed(Tq * 1000 + Tk)
+    q = torch.randn(B, Tq, h * d, generator=g).cuda().bfloat16(); k = torch.randn(B, Tk, h * d, generator=g).cuda().bfloat16()
+    v = torch.randn(B, Tk, h * d, generator=g).cuda().bfloat16(); do = torch.randn(B, Tq, h * d, generator=g).cuda().bfloat16()
+    km = torch.ones(B, Tk, dtype=torch.uint8, device="cuda"); km[:, Tk - 3:] = 0
+    out[name + ".ctx"] = ops.attention_fwd(q, k, v, km, h, d, p_drop=0.1, site=3, seed=9).cpu()
+    dq, dk, dv = ops.attention_bwd(q, k, v, km, do, h, d, p_drop=0.1, site=3, seed=9)
+    out[name + ".dq"], out[name + ".dk"], out[name + ".dv"] = dq.cpu(), dk.cpu(), dv.cpu()
+torch.cuda.synchronize()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_attention_gives_the_same_bits_for_every_wave_count(gemm_path, tmp_path):
+    """attention_mfma.hip splits one (batch, head) over 1, 2 or 4 waves (query tiles, then key tiles); every tile is computed the
+    same way in the same summation order, so CRCT_ATTN_SPLIT=1 (one wave, the round-1 kernel) and the default must agree bit
+    for bit -- forward, dq, dk, dv, with dropout, at 7 x 7, 3 x 7, 4 x 4, 3 x 3 and 2 x 2 tiles."""
+    if gemm_path != "pipelined":
+        pytest.skip("no GEMM in this test")
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cqa-crct_amd")
+    res = {}
+    for split in ("1", "0"):
+        path = str(tmp_path / ("attn_%s.pt" % split))
+        env = dict(os.environ)
+        env.pop("CRCT_ATTN_SPLIT", None)
+        if split != "0":
+            env["CRCT_ATTN_SPLIT"] = split
+        r = subprocess.run([sys.executable, "-c", _ATTN_SPLIT_SCRIPT, pkg, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[split] = torch.load(path)
+    assert set(res["1"]) == set(res["0"]) and len(res["0"]) == 20
+    for key in res["0"]:
+        assert torch.equal(res["0"][key], res["1"][key]), key
+        assert float(res["0"][key].float().abs().max()) > 0
