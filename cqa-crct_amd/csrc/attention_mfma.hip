@@ -476,7 +476,10 @@ template <bool BWD, int NQ, int NK, int ND, int SP>
 hipError_t launch_sp(const AttnArgs& a, hipStream_t s) {
   constexpr int BYTES = BWD ? BwdLds<NQ, NK, ND>::BYTES : FwdLds<NQ, NK, ND>::BYTES;
   constexpr int W0 = waves_per_group(BYTES);
-  constexpr int W = W0 * SP > 8 ? 8 / SP : W0;        // at most 512 threads per workgroup
+  // at most 512 threads per workgroup; a pair that needs more than 48 KB gets a workgroup of its own: a 150 KB workgroup can
+  // only start on a CU whose LDS is empty, i.e. after the other streams' GEMM workgroups have left it (long context: 11.83 ->
+  // 11.75 ms per step)
+  constexpr int W = BYTES > 48 * 1024 ? 1 : (W0 * SP > 8 ? 8 / SP : W0);
   static_assert(BYTES % 16 == 0 && BYTES * W <= 160 * 1024, "LDS slice");
   auto kern = BWD ? attn_bwd_mfma<NQ, NK, ND, W, SP> : attn_fwd_mfma<NQ, NK, ND, W, SP>;
   static bool raised = false;           // first call is eager (outside any stream capture)
