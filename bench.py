@@ -14,12 +14,16 @@ Prints ONE JSON line on rank 0:
   config.h2d_inclusive : the same step fed from PAGEABLE HOST batches through crct.input_pipeline.DevicePrefetcher (one
                  pinned staging buffer and ONE async copy per batch on a copy stream, double-buffered; features shipped
                  as bf16 unless --host-feat fp32), measured in the same run -- the PCIe-inclusive rate.
-  roofline     : the GEMM variant with the largest share of step time; achieved = algorithmic FLOPs per launch / average
-                 kernel duration measured live: during --profile-steps extra steps every GEMM kernel is dispatched with a
-                 start / stop event pair (hipExtLaunchKernelGGL), i.e. the begin / end stamps of the kernel itself -- the
-                 quantity ``rocprofv3 --kernel-trace --stats`` averages (profiles/r2_rocprof_kernel_stats_bench.csv);
-                 peak = 2.5 PFLOP/s dense bf16 MFMA.  traffic = fabric-side bytes per launch from the committed PMC passes
-                 (profiles/r2_pmc_traffic.json), used only while the kernel sources still hash to what was measured.
+  roofline     : the FFN GEMM group the north star names: text / visual FFN-up and FFN-down, forward and
+                 data gradient (each its own kernel launch).  achieved = sum of their algorithmic FLOPs / sum of their kernel
+                 durations, measured live IN the step: during --profile-steps extra steps every GEMM kernel is dispatched with
+                 a start / stop event pair (hipExtLaunchKernelGGL), i.e. the begin / end stamps of the kernel itself -- the
+                 quantity ``rocprofv3 --kernel-trace --stats`` averages -- and the engine tags every launch with its model site
+                 (CrctGemmArgs.site).  roofline.ffn lists the per-site figures (``*_wgrad``: the layer's weight gradients are
+                 ONE grouped kernel, its duration is apportioned by FLOP share); config.gemm_sites has every site of the step,
+                 config.gemm_variants the kernel configurations.  peak = 2.5 PFLOP/s dense bf16 MFMA (also for the non-scaled
+                 fp8 MFMA, which runs at the bf16 rate).  traffic = fabric-side bytes per launch of the group from the
+                 committed PMC passes (profiles/r*_pmc_sites.json), used only while the kernel sources hash to what was measured.
   cpu_baseline : the CPU oracle (fp32 PyTorch restatement, ``kind: port``) doing forward+backward of the same batch
                  shape on this node's host cores (rank 0, N = 1 only, bounded sample).
 """
@@ -78,6 +82,10 @@ def parse():
     ap.add_argument("--adamw-wgs", type=int, default=-1, help="workgroups per overlapped AdamW launch (0 = full width; default: the optimizer's)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
+    ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
+                    "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
+    ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
+                    "(tools/pmc_sites.py matches it against a rocprofv3 counter collection)")
     ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
                     help="bf16: the headline (BASELINE configs[1]).  fp8: BASELINE configs[4] -- the QKV / FFN GEMMs of the forward pass on "
                          "OCP e4m3 operands with per-tensor delayed scaling and fp32 accumulation, backward and everything else bf16")
@@ -89,7 +97,8 @@ def stage(batch, dev):
 
 
 def gemm_profile(run_step, n_steps):
-    """Begin / end stamps of every GEMM kernel over `n_steps` extra steps (same process, every internal stream)."""
+    """Begin / end stamps of every GEMM kernel over `n_steps` extra steps (same process, every internal stream): rows per kernel
+    configuration and rows per model site (CRCT_SITE_* x forward / dgrad / wgrad)."""
     lib = L.load()
     lib.crct_prof_reset()
     lib.crct_prof_enable(1)
@@ -97,16 +106,49 @@ def gemm_profile(run_step, n_steps):
         run_step()
     torch.cuda.synchronize()
     lib.crct_prof_enable(0)
-    rows = []
+    rows, sites = [], []
+
+    def row(label, cnt, fl, ms, **extra):
+        return dict(kernel=label, launches_per_step=cnt / n_steps, gflop_per_launch=fl / cnt / 1e9, us_per_launch=ms * 1e3 / cnt,
+                    ms_per_step=ms / n_steps, tflops=fl / (ms * 1e-3) / 1e12, frac_of_bf16_peak=fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, **extra)
+
     for v in range(72):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue
-        rows.append(dict(kernel="gemm<%s,%s>" % (TILE_NAMES.get(v // 3, "?"), VARIANT_NAMES[v % 3]), launches_per_step=cnt.value / n_steps,
-                         gflop_per_launch=fl.value / cnt.value / 1e9, us_per_launch=ms.value * 1e3 / cnt.value,
-                         ms_per_step=ms.value / n_steps, tflops=fl.value / (ms.value * 1e-3) / 1e12))
+        rows.append(row("gemm<%s,%s>" % (TILE_NAMES.get(v // 3, "?"), VARIANT_NAMES[v % 3]), cnt.value, fl.value, ms.value))
+    for s in range(1, len(L.SITE_NAMES)):
+        for k in range(3):
+            cnt, fl, ms, app = C.c_long(), C.c_double(), C.c_double(), C.c_int()
+            if lib.crct_prof_read_site(s, k, C.byref(cnt), C.byref(fl), C.byref(ms), C.byref(app)) != 0 or cnt.value == 0 or ms.value <= 0:
+                continue
+            sites.append(row("%s.%s" % (L.SITE_NAMES[s], L.KIND_NAMES[k]), cnt.value, fl.value, ms.value, apportioned=bool(app.value)))
     lib.crct_prof_reset()
-    return rows
+    return rows, sites
+
+
+FFN_SITES = ("t.ffn_up", "t.ffn_down", "v.ffn_up", "v.ffn_down")
+
+
+def ffn_roofline(sites, n_profiled):
+    """fraction of the FFN-GEMM roofline = sum of FFN GEMM FLOPs / sum of their kernel time / peak."""
+    by = {r["kernel"]: r for r in sites}
+
+    def group(kinds):
+        sel = [by["%s.%s" % (s, k)] for s in FFN_SITES for k in kinds if "%s.%s" % (s, k) in by]
+        if not sel:
+            return None
+        fl = sum(r["gflop_per_launch"] * r["launches_per_step"] for r in sel)        # GFLOP per step
+        ms = sum(r["ms_per_step"] for r in sel)
+        n = sum(r["launches_per_step"] for r in sel)
+        return dict(gflop_per_step=fl, ms_per_step=ms, launches_per_step=n, tflops=fl / ms, frac=fl / ms / PEAK_BF16_TFLOPS)
+    out = dict(fwd_dgrad=group(("fwd", "dgrad")), with_wgrad_apportioned=group(("fwd", "dgrad", "wgrad")))
+    for s in FFN_SITES:
+        for k in ("fwd", "dgrad", "wgrad"):
+            r = by.get("%s.%s" % (s, k))
+            if r:
+                out["%s.%s" % (s, k)] = dict(gflop=r["gflop_per_launch"], us=r["us_per_launch"], frac=r["frac_of_bf16_peak"])
+    return out
 
 
 def source_hash():
@@ -117,22 +159,23 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_label):
-    """Fabric-side bytes per launch of a GEMM variant from the committed PMC passes of this same command
-    (profiles/r*_pmc_traffic.json, made by tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
-    doubled per MI355X_MICROARCH.md).  A table is used only if it is stamped with the hash of the kernel sources as they are
-    now (``source_hash``): a measurement of other code is not reported.  None otherwise."""
+def pmc_traffic(site_labels, workload):
+    """Fabric-side bytes per launch (average over the launches of `site_labels`, e.g. 't.ffn_up.fwd') from the committed PMC
+    passes of this same command (profiles/r*_pmc_sites*.json, made by tools/pmc_sites.py: separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs, FETCH_SIZE doubled per MI355X_MICROARCH.md, dispatches matched to the engine's launch log).  A table is used only if
+    it is stamped with the hash of the kernel sources as they are now (``source_hash``) and with this workload: a measurement
+    of other code is not reported.  None otherwise."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sites*.json"))):
         try:
             with open(path) as f:
                 table = json.load(f)
         except (OSError, ValueError):
             continue
-        if table.get("_source_hash", {}).get("value") != source_hash():
+        if table.get("_source_hash") != source_hash() or table.get("_workload") != list(workload):
             continue
-        cand = [v for k, v in table.items() if not k.startswith("_") and v.get("bench_label") == kernel_label]
+        cand = [table["sites"][k] for k in site_labels if k in table.get("sites", {}) and table["sites"][k].get("bytes_per_launch")]
         if cand:
             tot = sum(v["launches"] for v in cand)
             best = sum(v["bytes_per_launch"] * v["launches"] for v in cand) / max(tot, 1)
@@ -187,6 +230,11 @@ def main():
         raise SystemExit("bench.py --gpus %d must equal WORLD_SIZE=%d (launch N > 1 with torch.distributed.run, one rank per GPU)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # nothing in the environment may change what the measured step launches: the library reads no CRCT_* variable any more, and
+    # a stray one (an old A/B script) is an error rather than a silent no-op
+    stray = sorted(k for k in os.environ if k.startswith("CRCT_") and k != "CRCT_BENCH_SHARE_GPU")
+    if stray:
+        raise SystemExit("bench.py: unset %s -- developer switches are command-line options (--site-policy ...), not environment variables" % ", ".join(stray))
     if os.environ.get("CRCT_BENCH_SHARE_GPU"):       # developer check of the N > 1 code path on a 1-GPU box (gloo, every rank on cuda:0)
         local = 0
     torch.cuda.set_device(local)
@@ -209,6 +257,11 @@ def main():
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
+    site_policy = []
+    for item in filter(None, a.site_policy.split(",")):
+        s, k, ph, c, sk = item.split(":")
+        site_policy.append(dict(site=s, kind=k, phase=int(ph), cfg=int(c), split_k=int(sk)))
+    core.site_policy = site_policy
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1
@@ -278,7 +331,20 @@ def main():
 
     for _ in range(a.warmup):
         run_step()
+    if a.launch_log:
+        L.load().crct_launch_log_enable(1)
     dt, loss = timed(a.steps)
+    if a.launch_log:
+        lib = L.load()
+        lib.crct_launch_log_enable(0)               # stop recording; the records stay readable
+        recs = []
+        for i in range(lib.crct_launch_log_count()):
+            r = L.LaunchRec()
+            lib.crct_launch_log_read(i, C.byref(r))
+            recs.append(dict(site=L.SITE_NAMES[r.site] if r.site >= 0 else "group", kind=L.KIND_NAMES[r.kind], M=r.M, N=r.N, K=r.K, cfg=r.cfg,
+                             split_k=r.split_k, n_problems=r.n_problems, flops=r.flops))
+        with open(a.launch_log, "w") as f:
+            json.dump(dict(steps=a.steps, source_hash=source_hash(), workload=[a.batch, a.vis, a.tokens, a.feat], launches=recs), f)
     final_loss = float(loss.detach())
     qa_per_s = a.batch * world * a.steps / dt
 
@@ -316,7 +382,7 @@ def main():
                 "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9}
 
     # profiled steps run on EVERY rank (they contain the collectives of a normal step); only rank 0 reads the stamps
-    rows = gemm_profile(run_step, a.profile_steps) if a.profile_steps > 0 else []
+    rows, sites = gemm_profile(run_step, a.profile_steps) if a.profile_steps > 0 else ([], [])
     if rank == 0:
         flop_qa = FLOP_PER_QA.get((a.vis, a.tokens, a.feat))
         out = {"metric": "QA-pairs/sec training step (whole node)", "value": qa_per_s, "unit": "QA-pairs/s", "n_gpus": world,
@@ -326,16 +392,24 @@ def main():
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
                                       "; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.dtype == "fp8" else ""),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input,
-                          "h2d_inclusive": h2d, "gradient_allreduce": comm, "gemm_variants": rows}}
+                          "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None,
+                          "gemm_sites": sites, "gemm_variants": rows}}
         if flop_qa:
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
-        if rows:
+        if sites:
+            ffn = ffn_roofline(sites, a.profile_steps)
+            grp = ffn["fwd_dgrad"]
             dom = max(rows, key=lambda r: r["ms_per_step"])
-            traffic = pmc_traffic(dom["kernel"]) if (a.batch, a.vis, a.tokens, a.feat) == (80, 36, 20, 2048) else None
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
-                               "gflop_per_launch": dom["gflop_per_launch"], "us_per_launch": dom["us_per_launch"],
-                               "timing": "kernel begin / end stamps (hipExtLaunchKernelGGL start / stop events), %d profiled steps" % a.profile_steps}
+            traffic = pmc_traffic(["%s.%s" % (s, k) for s in FFN_SITES for k in ("fwd", "dgrad")], (a.batch, a.vis, a.tokens, a.feat))
+            out["roofline"] = {"bound": "mfma", "kernel": "FFN GEMMs: text / visual FFN-up + FFN-down, forward + data gradient (%d launches per step)"
+                                                             % round(grp["launches_per_step"]),
+                               "achieved": grp["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": grp["frac"], "traffic": traffic,
+                               "gflop_per_launch": grp["gflop_per_step"] / grp["launches_per_step"],
+                               "us_per_launch": grp["ms_per_step"] * 1e3 / grp["launches_per_step"], "ffn": ffn,
+                               "largest_kernel_class": {"kernel": dom["kernel"], "tflops": dom["tflops"], "frac": dom["tflops"] / PEAK_BF16_TFLOPS,
+                                                        "ms_per_step": dom["ms_per_step"]},
+                               "timing": "kernel begin / end stamps (hipExtLaunchKernelGGL start / stop events), %d profiled steps, in the step "
+                                         "(other streams' kernels run beside each launch)" % a.profile_steps}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(core, cfg, params, a.cpu_batch, a.tokens, a.vis, a.feat)
         print(json.dumps(out), flush=True)

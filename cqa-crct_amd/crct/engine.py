@@ -112,6 +112,13 @@ class StepEngine(object):
             c.seg_done_events = C.cast(arr, C.c_void_p)
         return c
 
+    def set_site_policy(self, site, kind, cfg=-1, split_k=0, phase=-1):
+        """Launch policy of one GEMM site (crct_engine_set_site_policy): ``site`` / ``kind`` by name (crct.lib.SITE_NAMES /
+        KIND_NAMES) or number, ``phase`` 0 = text-only part of the schedule, 1 = beside the visual stream, -1 = both."""
+        s = L.SITE_NAMES.index(site) if isinstance(site, str) else int(site)
+        k = L.KIND_NAMES.index(kind) if isinstance(kind, str) else int(kind)
+        L.check(self.lib.crct_engine_set_site_policy(self.handle, s, k, int(phase), int(cfg), int(split_k)), "set_site_policy")
+
     def fp8_layout(self):
         """(number of activation scale sites, [(flat offset, numel)] of the weights with an e4m3 shadow; index = scale slot)."""
         n = self.lib.crct_engine_fp8_weights(self.handle, None, None, 0)

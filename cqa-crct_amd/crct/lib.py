@@ -20,7 +20,18 @@ class GemmArgs(C.Structure):
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ta", c_i32), ("tb", c_i32), ("act", c_i32), ("dact", c_i32),
                 ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
                 ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp),
-                ("fp8", c_i32), ("scale_a", vp), ("scale_b", vp), ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("ld_q", c_i64)]
+                ("fp8", c_i32), ("scale_a", vp), ("scale_b", vp), ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("ld_q", c_i64),
+                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp)]
+
+
+class LaunchRec(C.Structure):
+    _fields_ = [("site", c_i32), ("kind", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("cfg", c_i32), ("split_k", c_i32),
+                ("grid", c_i32), ("n_problems", c_i32), ("flops", C.c_double)]
+
+
+SITE_NAMES = ["none", "t.qkv", "t.out", "t.ffn_up", "t.ffn_down", "v.qkv", "v.out", "v.ffn_up", "v.ffn_down",
+              "c.qkv_t", "c.qkv_v", "c.out_t", "c.out_v", "img_emb", "head"]      # CRCT_SITE_* of include/crct_hip.h
+KIND_NAMES = ["fwd", "dgrad", "wgrad"]
 
 
 class HeadArgs(C.Structure):
@@ -88,6 +99,13 @@ PROTOTYPES = {
     "crct_prof_enable": (C.c_int, [C.c_int]),
     "crct_prof_reset": (C.c_int, []),
     "crct_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "crct_prof_read_site": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "crct_launch_log_enable": (C.c_int, [C.c_int]),
+    "crct_launch_log_count": (C.c_int, []),
+    "crct_launch_log_read": (C.c_int, [C.c_int, C.POINTER(LaunchRec)]),
+    "crct_gemm_splitk_ws_elems": (c_i64, [C.c_int, C.c_int, C.c_int]),
+    "crct_gemm_splitk_tickets": (C.c_int, [C.c_int, C.c_int]),
+    "crct_engine_set_site_policy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crct_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp]),
     "crct_layernorm_bwd_blocks": (C.c_int, [C.c_int]),
     "crct_layernorm_bwd": (C.c_int, [vp] * 11 + [C.c_int, C.c_int, C.c_int, c_u32, c_f32, c_u32, c_u32, c_f32, c_u32, c_u64, vp]),
@@ -102,12 +120,13 @@ PROTOTYPES = {
     "crct_layernorm_fwd_pair": (C.c_int, [C.POINTER(LnFwdArgs), C.POINTER(LnFwdArgs), vp]),
     "crct_layernorm_bwd_rows_pair": (C.c_int, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), vp]),
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
-    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
     "crct_attention_force_valu": (None, [C.c_int]),
+    "crct_attention_force_split": (None, [C.c_int]),
     "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),
     "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp, vp, C.c_int, vp]),
     "crct_embed_image_fwd": (C.c_int, [vp] * 12 + [C.c_int] * 2 + [c_f32] + _u8 + [vp]),

@@ -45,7 +45,9 @@ class _StepFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         logits, reg_all, stats = model._engine.snapshot(tensors["tokens"].shape[0])    # one copy; the engine reuses its buffer
         ctx.mark_non_differentiable(logits, reg_all, stats)
-        return stats[0], stats[1:2], reg_all[1], logits, reg_all, stats       # views of the snapshot: no further copies
+        # the differentiable scalar is a tensor of its own (4 bytes): the reference loop modifies it in place
+        # (train.py:204-205 ``loss /= params['batch_multiply']``), which autograd forbids on a view output of a multi-output node
+        return stats[0].clone(), stats[1:2], reg_all[1], logits, reg_all, stats     # the rest: views of the snapshot, no copies
 
     @staticmethod
     def backward(ctx, g_loss, g_nsp, g_reg, _gl, _gr, _gs):
@@ -228,7 +230,7 @@ class CrctModel(nn.Module):
         st = self._fp8
         st["updates"] = st.get("updates", 0) + 1
         L.check(L.load().crct_fp8_update_scales(st["a_scale"].data_ptr(), st["a_amax"].data_ptr(), st["n_sites"],
-                                                int(st["updates"] % self.FP8_AMAX_WINDOW == 0), L.current_stream()), "fp8_update_scales")
+                                                int(st["updates"] % self.FP8_AMAX_WINDOW == 0), None, L.current_stream()), "fp8_update_scales")
 
     def _apply(self, fn, recurse=True):
         probe = fn(torch.zeros(1, device=self._flat_p.device))
@@ -240,6 +242,14 @@ class CrctModel(nn.Module):
             self._flat_p, self._flat_g, self._flat_b16 = fn(self._flat_p), fn(self._flat_g), self._flat_b16.to(probe.device)
             self._anchor = torch.zeros(1, device=probe.device, requires_grad=True)
             self._engine = None
+            # everything bound to the old device goes with the engine: fp8 shadow / scales / chunk tables, segment events, the
+            # lazy-clear plan, constants (the fused optimizer drops its own device state when it sees the new buffers)
+            self._fp8 = None
+            self._seg_done = None
+            self._lazy_plan_key, self._lazy_plan = None, None
+            self._const_zeros = None
+            self._param_events = None
+            self._opt_stream = None
             self._rebind()
         return self
 
@@ -352,6 +362,8 @@ class CrctModel(nn.Module):
             mt = max(T, eng.max[1] if eng else 0)
             mv = max(V, eng.max[2] if eng else 0)
             self._engine = StepEngine(self.config, self.params, mb, mt, mv, self._flat_p.device, self.cls_dropout)
+            for pol in getattr(self, "site_policy", ()):          # developer / test overrides of the per-site launch policy
+                self._engine.set_site_policy(**pol)
         return self._engine
 
     def segment_done_events(self):
@@ -389,7 +401,7 @@ class CrctModel(nn.Module):
             self._grad_waits = [[(lambda st, ev=ev: ev.wait(st)) for ev in evs[4 * i:4 * i + 4]] for i in range(eng.n_segments)]
             return
         if self._ddp is None:
-            if os.environ.get("CRCT_FORCE_SEGMENTED"):     # developer switch: the DDP call pattern without the collectives
+            if getattr(self, "force_segmented", False):    # developer switch: the DDP call pattern without the collectives
                 for i in range(eng.n_segments):
                     eng.backward(self._flat_p, self._flat_b16, self._flat_g, tensors, step, i)
                 return

@@ -32,7 +32,7 @@ def _drop(p, site):
 
 def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
                preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
-               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None):
+               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0):
     _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
@@ -48,7 +48,26 @@ def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=Non
     g.drop_thr, g.drop_scale, g.drop_site = _drop(p_drop, site)
     g.seed = seed
     g.rowsum_out = L.ptr(rowsum_out)
+    g.site = int(model_site)
+    if split_k and split_k > 1:       # K-partitioned launch: slab space + ticket words (zero before the first use) per device
+        ws, cnt = _splitk_space(A.device, M, N, split_k)
+        g.split_k, g.splitk_ws, g.splitk_cnt = int(split_k), L.ptr(ws), L.ptr(cnt)
+        g._keep = (ws, cnt)
     return out
+
+
+_SPLITK = {}
+
+
+def _splitk_space(dev, M, N, S):
+    lib = L.load()
+    need, tickets = lib.crct_gemm_splitk_ws_elems(M, N, S), lib.crct_gemm_splitk_tickets(M, N)
+    ws, cnt = _SPLITK.get(dev, (None, None))
+    if ws is None or ws.numel() < need or cnt.numel() < tickets:
+        ws = torch.empty(max(need, ws.numel() if ws is not None else 0), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(max(tickets, 4096), dtype=torch.int32, device=dev)
+        _SPLITK[dev] = (ws, cnt)
+    return ws, cnt
 
 
 def gemm(A, B, M, N, K, **kw):

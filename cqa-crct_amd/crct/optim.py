@@ -191,8 +191,13 @@ class FusedAdamW(torch.optim.Optimizer):
         """Delayed scaling of the weight shadow: the scales this update quantises with come from the amax the previous update saw."""
         if self._fp8_arg() is not None:
             st = self.core._fp8
+            # the window is counted on the host per CALL (under GradScaler the host step counter is frozen: the device counter
+            # takes over), and a step the scaler skips leaves shadow AND scales alone
+            st["w_updates"] = st.get("w_updates", 0) + 1
+            found = self._amp_keep[1] if (self._amp_arg is not None and self._amp_keep is not None) else None
             L.check(L.load().crct_fp8_update_scales(st["w_scale"].data_ptr(), st["w_amax"].data_ptr(), len(st["weights"]),
-                                                    int(self._step % self.core.FP8_AMAX_WINDOW == 0), stream), "fp8_update_scales")
+                                                    int(st["w_updates"] % self.core.FP8_AMAX_WINDOW == 0), L.ptr(found), stream),
+                    "fp8_update_scales")
 
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
@@ -219,10 +224,30 @@ class FusedAdamW(torch.optim.Optimizer):
         self._events = [DeviceEvent() for _ in eng.segments]
         return True
 
+    def _follow_device(self):
+        """The model was moved (``model.to('cuda:1')`` after the optimizer was built): the moments and tables follow, and
+        everything bound to the old device -- update stream, segment events, fp8 shadow descriptor -- is made again."""
+        dev = self.core.flat_params.device
+        if self._m.device == dev:
+            return
+        old_m, old_v = self._m, self._v
+        self._m, self._v = old_m.to(dev), old_v.to(dev)
+        for e in self._segs:
+            st = self.state[self._byname[e.name]]
+            st["exp_avg"] = self._m[e.offset:e.offset + e.numel].view(e.shape)
+            st["exp_avg_sq"] = self._v[e.offset:e.offset + e.numel].view(e.shape)
+        for k in ("_seg_off", "_seg_len", "_blk_seg", "_blk_off", "_lr_dev", "_wd_dev"):
+            setattr(self, k, getattr(self, k).to(dev))
+        self._last = None
+        self._upload_done = None
+        self._fp8_keep = self._events = self._opt_stream = self._seg_blocks = None
+        self._step_dev = self._step_dev.to(dev) if self._step_dev is not None else None
+
     @torch.no_grad()
     def step(self, closure=None, inv_scale=None):
         loss = closure() if closure is not None else None
         core = self.core
+        self._follow_device()
         amp = self._amp_begin()
         if not amp:
             self._step += 1
@@ -258,7 +283,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._fp8_before_update(L.current_stream())
             self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
         core.note_params_updated_natively()
-        self._grads_cleared = bool(self.fuse_zero_grad)
+        # under GradScaler the kernel returns at once on a skipped step and zeroes nothing: only without it the clear is certain
+        self._grads_cleared = bool(self.fuse_zero_grad) and not amp
         if self._grads_cleared:
             core._grads_dirty = False                         # until the next backward pass
         return loss

@@ -393,13 +393,10 @@ int check_args(int Tq, int Tk, int d) {
   return 0;
 }
 
-// MFMA path (attention_mfma.hip) for the lengths / head sizes it covers; CRCT_ATTN_VALU=1 or
-// crct_attention_force_valu(1) keep everything on the fp32 kernels of this file
-int g_force_valu = -1;
-bool use_mfma(int Tq, int Tk, int d) {
-  if (g_force_valu < 0) g_force_valu = getenv("CRCT_ATTN_VALU") ? atoi(getenv("CRCT_ATTN_VALU")) : 0;
-  return !g_force_valu && crct_attention_mfma_ok(Tq, Tk, d);
-}
+// MFMA path (attention_mfma.hip) for the lengths / head sizes it covers; crct_attention_force_valu(1) (test hook) keeps
+// everything on the fp32 kernels of this file
+int g_force_valu = 0;
+bool use_mfma(int Tq, int Tk, int d) { return !g_force_valu && crct_attention_mfma_ok(Tq, Tk, d); }
 
 }  // namespace
 

@@ -29,6 +29,9 @@
 // With SP = 1 the waves never exchange data: phases are separated by wave-level fences only (LDS operations of one wave
 // execute in issue order) and a wave past the end of the grid simply exits; with SP > 1 the waves of a pair split the
 // query tiles (scores, softmax, dS, dq) and the key tiles (dv, dk) and meet at workgroup barriers between the phases.
+static int g_attn_force_split = 0;      // test hook (crct_attention_force_split): 0 = by tile count, 1 / 2 / 4 = that many waves per pair
+extern "C" void crct_attention_force_split(int n) { g_attn_force_split = (n == 1 || n == 2 || n == 4) ? n : 0; }
+
 namespace {
 
 typedef s4_t __attribute__((address_space(3))) * lds_s4_ptr;
@@ -495,10 +498,10 @@ hipError_t launch_sp(const AttnArgs& a, hipStream_t s) {
 // Waves per (batch, head): 4 when both sides have at least four tiles, 2 with at least two (each wave then owns whole query
 // tiles in the first phase and whole key tiles in the second), else 1.  Long context (B = 64, V = 100, T = 40): 12.28 ms per
 // step with one wave, 11.90 with two, 11.83 with four for the 7 x 7-tile launches; configs[1] (2-3 tiles): unchanged.
-// CRCT_ATTN_SPLIT=1 / 2 / 4 forces a count (developer A/B: every count gives the same bits).
+// crct_attention_force_split(1 / 2 / 4) forces a count (test hook: every count gives the same bits).
 template <bool BWD, int NQ, int NK, int ND>
 hipError_t launch(const AttnArgs& a, hipStream_t s) {
-  static const int forced = [] { const char* e = getenv("CRCT_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+  const int forced = g_attn_force_split;
   constexpr bool can2 = NQ >= 2 && NK >= 2, can4 = NQ >= 4 && NK >= 4;
   if constexpr (can4) {
     if (forced == 4 || forced == 0) return launch_sp<BWD, NQ, NK, ND, 4>(a, s);

@@ -41,7 +41,7 @@ void crct_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crct_last_error(void) { return g_err; }
-extern "C" int crct_abi_version(void) { return 2; }
+extern "C" int crct_abi_version(void) { return 3; }
 
 extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a != nullptr, "gemm: null args");
@@ -87,7 +87,7 @@ struct Arena {
 struct Drop { uint32_t thr = 0; float scale = 1.f; uint32_t site = 0; };
 
 // ---- parameter offsets (elements into the flat buffers)
-struct LinearP { int64_t w = -1, b = -1; int in = 0, out = 0; };
+struct LinearP { int64_t w = -1, b = -1; int in = 0, out = 0; int site = 0; };
 struct LnP { int64_t g = -1, b = -1; };
 struct FfnP { LinearP up, down; LnP ln; };
 struct ProjP { LinearP dense; LnP ln; };      // LN(dropout(dense(ctx)) + residual)
@@ -126,6 +126,12 @@ struct crct_engine {
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
   size_t embed_rows[2], embed_idx[2];   // embedding backward: fp32 row gradients + table indices for the gather-sum pass
   size_t km_t = 0, km_v = 0;
+  // per-site launch policy of the forward / data-gradient GEMMs (crct_engine_set_site_policy): [site][kind][phase]
+  struct SitePolicy { int cfg = -1, split_k = 0; };
+  SitePolicy policy[CRCT_SITE_COUNT][2][2];
+  size_t sk_ws[2] = {0, 0}, sk_cnt[2] = {0, 0};   // split-K slab space / ticket words per data stream [text, visual]
+  size_t sk_ws_elems[2] = {0, 0};
+  int sk_tickets = 0;
   // fp8 forward (BASELINE configs[4]): scale slot of every Linear weight that has an e4m3 shadow, number of activation scale sites
   std::unordered_map<int64_t, int> wq_slot;
   std::vector<std::pair<int64_t, int64_t>> wq_list;      // slot -> (flat offset, numel)
@@ -164,17 +170,17 @@ struct crct_engine {
 
 namespace {
 
-LinearP linear_p(crct_engine* e, const std::string& name, int in, int out) {
+LinearP linear_p(crct_engine* e, const std::string& name, int in, int out, int site = CRCT_SITE_HEAD) {
   LinearP l;
-  l.w = e->P(name + ".weight"); l.b = e->P(name + ".bias"); l.in = in; l.out = out;
+  l.w = e->P(name + ".weight"); l.b = e->P(name + ".bias"); l.in = in; l.out = out; l.site = site;
   return l;
 }
 LnP ln_p(crct_engine* e, const std::string& name) {
   LnP l; l.g = e->P(name + ".weight"); l.b = e->P(name + ".bias"); return l;
 }
 // three Linear(in, out) stored back to back -> one Linear(in, 3*out)
-LinearP fused3(crct_engine* e, const std::string& a, const std::string& b, const std::string& c, int in, int out) {
-  LinearP l = linear_p(e, a, in, 3 * out);
+LinearP fused3(crct_engine* e, const std::string& a, const std::string& b, const std::string& c, int in, int out, int site) {
+  LinearP l = linear_p(e, a, in, 3 * out, site);
   const int64_t wsz = (int64_t)in * out;
   if (e->P(b + ".weight") != l.w + wsz || e->P(c + ".weight") != l.w + 2 * wsz || e->P(b + ".bias") != l.b + out ||
       e->P(c + ".bias") != l.b + 2 * out) {
@@ -216,8 +222,8 @@ hipEvent_t ev_new(crct_engine* e) {
   if (e->evnext == e->evpool.size()) {
     hipEvent_t ev = nullptr;
     // ordering between streams of ONE device: no system-scope fence (host / peer visibility) at the record -- the hand-off
-    // is 2.5-4 us shorter (tools/handoff_lab.cpp); CRCT_EVENT_SYSFENCE=1 restores the default flags for A/B runs
-    static const unsigned flags = getenv("CRCT_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+    // is 2.5-4 us shorter (tools/handoff_lab.cpp)
+    const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
     if (hipEventCreateWithFlags(&ev, flags) != hipSuccess) return nullptr;
     e->evpool.push_back(ev);
   }
@@ -240,6 +246,8 @@ struct Run {
   const CrctBatch* b; const CrctStepCfg* c;
   hipStream_t sw;                      // stream of this data stream's weight-gradient GEMMs (== s when disabled)
   size_t partials, colsum_part, colsum_part_w;
+  int which = 0;                       // 0 = text stream, 1 = visual stream (owner of split-K workspace `which`)
+  int phase = 1;                       // 0: text-only part of the schedule, 1: beside the visual stream (site policy)
   int rc = 0;
   bool sw_dirty = false;               // sw has work that s has not been ordered after yet (no empty forks / joins)
   // scratch double-buffering: layer n of this data stream uses scratch set (n & 1); before reusing a set the
@@ -305,6 +313,7 @@ struct Run {
   struct Opt {
     const float* bias = nullptr; void* preact = nullptr; const void* dact_src = nullptr; int dact = 0; int act = 0;
     const void* addend = nullptr; int64_t ld_aux = 0, ld_add = 0; Drop drop; bool f32 = false; bool acc = false;
+    int site = 0;
   };
   void gemm(const void* Ap, int64_t lda, bool ta, const void* Bp, int64_t ldb, bool tb, void* C, int64_t ldc, int M, int N,
             int K, const Opt& o, hipStream_t st = nullptr) {
@@ -317,6 +326,15 @@ struct Run {
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
+    g.site = o.site;
+    if (!ta && st == s && o.site > 0 && o.site < CRCT_SITE_COUNT) {      // forward / data gradient on the data stream: the site's policy
+      const crct_engine::SitePolicy& pol = e->policy[o.site][tb ? 1 : 0][phase];
+      if (pol.cfg >= 0) g.tile = pol.cfg;
+      if (pol.split_k > 1 && !defer && crct_gemm_splitk_ws_elems(M, N, pol.split_k) <= (int64_t)e->sk_ws_elems[which] &&
+          crct_gemm_splitk_tickets(M, N) <= e->sk_tickets) {
+        g.split_k = pol.split_k; g.splitk_ws = F(e->sk_ws[which]); g.splitk_cnt = W<uint32_t>(e->sk_cnt[which]);
+      }
+    }
     if (defer && st == s) { QOp op; op.kind = Q_GEMM; op.g = g; q.push_back(op); return; }
     fail(crct_gemm_bf16(&g, st));
   }
@@ -329,7 +347,7 @@ struct Run {
   }
   // y[M][out] = x W^T + b (+ epilogue)
   void lin_fwd(const void* x, int64_t ldx, const LinearP& l, int M, void* y, int64_t ldy, Opt o) {
-    o.bias = P(l.b);
+    o.bias = P(l.b); o.site = l.site;
     gemm(x, ldx, false, PB(l.w), l.in, false, y, ldy, M, l.out, l.in, o);
   }
   // ---- fp8 forward (CrctStepCfg.fp8): the same Linear from the e4m3 copies of its input (scale site `site_in`) and of its
@@ -346,7 +364,7 @@ struct Run {
     g.lda = l.in; g.ldb = l.in; g.ldc = ldy; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
     g.M = M; g.N = l.out; g.K = l.in; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
-    g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
+    g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w); g.site = l.site;
     if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; }
     if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
     fail(crct_gemm_bf16(&g, s));
@@ -362,7 +380,7 @@ struct Run {
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = x; g.C = G(l.w); g.lda = lddy; g.ldb = ldx; g.ldc = l.in; g.M = l.out; g.N = l.in; g.K = M;
-    g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f;
+    g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f; g.site = l.site;
     if (c->wgrad_overwrite && e->wgrad_owned.count(l.w)) {
       if (++e->wgrad_pass[l.w] > 1) { rc = 1; crct_set_error("engine_backward: weight gradient at offset %lld is produced twice in one pass but is listed as owned", (long long)l.w); return; }
       g.accumulate = 0;               // the only producer of this gradient: write it, whatever the buffer held
@@ -375,7 +393,8 @@ struct Run {
     if (pending.size() == 8 && !defer) flush_wgrads();
   }
   // dx[M][in] = dy W (+ epilogue)
-  void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, const Opt& o) {
+  void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, Opt o) {
+    o.site = l.site;
     gemm(dy, lddy, false, PB(l.w), l.in, true, dx, lddx, M, l.in, l.out, o);
   }
   // launch the queued weight-gradient GEMMs on the side stream, ordered after everything enqueued on s so far
@@ -853,11 +872,11 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     std::string p(buf);
     SelfLayerP l;
     l.H = D.H; l.heads = D.heads; l.p_attn = D.p_attn; l.p_hid = D.p_hidden; l.site = site; site += 4;
-    l.qkv = fused3(e, p + "attention.self.query", p + "attention.self.key", p + "attention.self.value", D.H, D.H);
-    l.proj.dense = linear_p(e, p + "attention.output.dense", D.H, D.H);
+    l.qkv = fused3(e, p + "attention.self.query", p + "attention.self.key", p + "attention.self.value", D.H, D.H, CRCT_SITE_T_QKV);
+    l.proj.dense = linear_p(e, p + "attention.output.dense", D.H, D.H, CRCT_SITE_T_OUT);
     l.proj.ln = ln_p(e, p + "attention.output.LayerNorm");
-    l.ffn.up = linear_p(e, p + "intermediate.dense", D.H, D.I);
-    l.ffn.down = linear_p(e, p + "output.dense", D.I, D.H);
+    l.ffn.up = linear_p(e, p + "intermediate.dense", D.H, D.I, CRCT_SITE_T_FFN_UP);
+    l.ffn.down = linear_p(e, p + "output.dense", D.I, D.H, CRCT_SITE_T_FFN_DN);
     l.ffn.ln = ln_p(e, p + "output.LayerNorm");
     e->tl.push_back(l);
   }
@@ -866,11 +885,11 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     std::string p(buf);
     SelfLayerP l;
     l.H = D.Hv; l.heads = D.v_heads; l.p_attn = D.p_v_attn; l.p_hid = D.p_v_hidden; l.site = site; site += 4;
-    l.qkv = fused3(e, p + "attention.self.query", p + "attention.self.key", p + "attention.self.value", D.Hv, D.Hv);
-    l.proj.dense = linear_p(e, p + "attention.output.dense", D.Hv, D.Hv);
+    l.qkv = fused3(e, p + "attention.self.query", p + "attention.self.key", p + "attention.self.value", D.Hv, D.Hv, CRCT_SITE_V_QKV);
+    l.proj.dense = linear_p(e, p + "attention.output.dense", D.Hv, D.Hv, CRCT_SITE_V_OUT);
     l.proj.ln = ln_p(e, p + "attention.output.LayerNorm");
-    l.ffn.up = linear_p(e, p + "intermediate.dense", D.Hv, D.Iv);
-    l.ffn.down = linear_p(e, p + "output.dense", D.Iv, D.Hv);
+    l.ffn.up = linear_p(e, p + "intermediate.dense", D.Hv, D.Iv, CRCT_SITE_V_FFN_UP);
+    l.ffn.down = linear_p(e, p + "output.dense", D.Iv, D.Hv, CRCT_SITE_V_FFN_DN);
     l.ffn.ln = ln_p(e, p + "output.LayerNorm");
     e->vl.push_back(l);
   }
@@ -879,14 +898,14 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     std::string p(buf);
     ConnLayerP l;
     l.site = site; site += 8;
-    l.qkv1 = fused3(e, p + "biattention.query1", p + "biattention.key1", p + "biattention.value1", D.Hv, D.Hb);
-    l.qkv2 = fused3(e, p + "biattention.query2", p + "biattention.key2", p + "biattention.value2", D.H, D.Hb);
-    l.proj_v.dense = linear_p(e, p + "biOutput.dense1", D.Hb, D.Hv); l.proj_v.ln = ln_p(e, p + "biOutput.LayerNorm1");
-    l.proj_t.dense = linear_p(e, p + "biOutput.dense2", D.Hb, D.H); l.proj_t.ln = ln_p(e, p + "biOutput.LayerNorm2");
-    l.ffn_v.up = linear_p(e, p + "v_intermediate.dense", D.Hv, D.Iv);
-    l.ffn_v.down = linear_p(e, p + "v_output.dense", D.Iv, D.Hv); l.ffn_v.ln = ln_p(e, p + "v_output.LayerNorm");
-    l.ffn_t.up = linear_p(e, p + "t_intermediate.dense", D.H, D.I);
-    l.ffn_t.down = linear_p(e, p + "t_output.dense", D.I, D.H); l.ffn_t.ln = ln_p(e, p + "t_output.LayerNorm");
+    l.qkv1 = fused3(e, p + "biattention.query1", p + "biattention.key1", p + "biattention.value1", D.Hv, D.Hb, CRCT_SITE_C_QKV_V);
+    l.qkv2 = fused3(e, p + "biattention.query2", p + "biattention.key2", p + "biattention.value2", D.H, D.Hb, CRCT_SITE_C_QKV_T);
+    l.proj_v.dense = linear_p(e, p + "biOutput.dense1", D.Hb, D.Hv, CRCT_SITE_C_OUT_V); l.proj_v.ln = ln_p(e, p + "biOutput.LayerNorm1");
+    l.proj_t.dense = linear_p(e, p + "biOutput.dense2", D.Hb, D.H, CRCT_SITE_C_OUT_T); l.proj_t.ln = ln_p(e, p + "biOutput.LayerNorm2");
+    l.ffn_v.up = linear_p(e, p + "v_intermediate.dense", D.Hv, D.Iv, CRCT_SITE_V_FFN_UP);
+    l.ffn_v.down = linear_p(e, p + "v_output.dense", D.Iv, D.Hv, CRCT_SITE_V_FFN_DN); l.ffn_v.ln = ln_p(e, p + "v_output.LayerNorm");
+    l.ffn_t.up = linear_p(e, p + "t_intermediate.dense", D.H, D.I, CRCT_SITE_T_FFN_UP);
+    l.ffn_t.down = linear_p(e, p + "t_output.dense", D.I, D.H, CRCT_SITE_T_FFN_DN); l.ffn_t.ln = ln_p(e, p + "t_output.LayerNorm");
     e->cl.push_back(l);
   }
   e->et.word = e->P("bert.embeddings.word_embeddings.weight");
@@ -895,7 +914,7 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->et.wloc = e->P("bert.embeddings.txt_location_embeddings.weight");
   e->et.bloc = e->P("bert.embeddings.txt_location_embeddings.bias");
   e->et.ln = ln_p(e, "bert.embeddings.LayerNorm");
-  e->ev.img = linear_p(e, "bert.v_embeddings.new_image_embeddings", D.Fv, D.Hv);
+  e->ev.img = linear_p(e, "bert.v_embeddings.new_image_embeddings", D.Fv, D.Hv, CRCT_SITE_IMG_EMB);
   e->ev.color = e->P("bert.v_embeddings.color_emb.weight");
   e->ev.wloc = e->P("bert.v_embeddings.new_loc_emb.weight");
   e->ev.bloc = e->P("bert.v_embeddings.new_loc_emb.bias");
@@ -996,6 +1015,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     for (int k = 0; k < 4; ++k) e->colsum_part[k] = ar.take((size_t)64 * nmax * 4);
   }
   e->km_t = ar.take(Mt); e->km_v = ar.take(Mv);      // uint8 key masks built from sep_indices / hist_len / image_mask (CrctBatch)
+  {
+    // split-K slab space per data stream: the narrow outputs (N <= the widest hidden size) with up to 4 slices; wider outputs
+    // have enough tiles and are never split.  Ticket words: zeroed at the start of every engine call.
+    const int Hmax = std::max(std::max(D.H, D.Hv), D.Hb);
+    e->sk_ws_elems[0] = (size_t)crct_gemm_splitk_ws_elems((int)Mt, Hmax, 4);
+    e->sk_ws_elems[1] = (size_t)crct_gemm_splitk_ws_elems((int)Mv, Hmax, 4);
+    e->sk_tickets = std::max(crct_gemm_splitk_tickets((int)Mt, Hmax), crct_gemm_splitk_tickets((int)Mv, Hmax));
+    e->sk_tickets = (e->sk_tickets + 3) / 4 * 4;
+    for (int k = 0; k < 2; ++k) e->sk_ws[k] = ar.take(e->sk_ws_elems[k] * 4);
+    e->sk_cnt[0] = ar.take((size_t)2 * e->sk_tickets * 4);      // [text | visual] in one block: one memset per call
+    e->sk_cnt[1] = e->sk_cnt[0] + (size_t)e->sk_tickets * 4;
+  }
   e->ws_bytes = ar.top;
 
   // ---- taps + final outputs, following the schedule
@@ -1053,11 +1084,6 @@ extern "C" int crct_engine_segment_range(const crct_engine_t* e, int seg, int64_
 namespace {
 
 int ensure_streams(crct_engine* e) {
-  static const char* env = getenv("CRCT_STREAMS");      // "0": single stream, "1": visual stream only, default: all
-  if (!e->streams_forced) {
-    if (env && env[0] == '0') { e->use_vis_stream = false; e->use_wgrad_stream = false; }
-    if (env && env[0] == '1') { e->use_wgrad_stream = false; }
-  }
   // all internal streams share the caller's (default) priority: giving the weight-gradient streams the lowest or the
   // visual stream the highest priority (hipStreamCreateWithPriority) was measured to DOUBLE the step time on MI355X
   // (10.7 -> 21.9 ms, round 1) -- cross-priority event waits are slow -- so there is no priority knob
@@ -1072,8 +1098,6 @@ int ensure_streams(crct_engine* e) {
 }
 
 bool pairing_on(crct_engine* e, const CrctStepCfg* cfg) {
-  static const char* env = getenv("CRCT_PAIR");
-  if (!e->pair_forced && env) e->pair_mode = env[0] != '0';
   const bool f8 = cfg->fp8 && cfg->params_fp8 && cfg->fp8_w_scale && cfg->fp8_act_scale && cfg->fp8_act_amax;
   return e->pair_mode && !f8 && e->first_conn >= 0;
 }
@@ -1089,6 +1113,18 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
            e->partials[1], e->colsum_part[1], e->colsum_part[3]};
   Rt.sets[0] = &e->st; Rt.sets[1] = &e->st2;
   Rv.sets[0] = &e->sv; Rv.sets[1] = &e->sv2;
+  Rt.which = 0; Rv.which = 1;
+}
+
+// the split-K ticket words of both data streams start every engine call at zero (an aborted launch must not poison the next)
+int reset_tickets(crct_engine* e, void* ws, hipStream_t s) {
+  bool any = false;
+  for (int a = 1; a < CRCT_SITE_COUNT && !any; ++a)
+    for (int k = 0; k < 2; ++k)
+      for (int ph = 0; ph < 2; ++ph) any = any || e->policy[a][k][ph].split_k > 1;
+  if (!any) return 0;
+  CRCT_CHECK_HIP(hipMemsetAsync((char*)ws + e->sk_cnt[0], 0, (size_t)2 * e->sk_tickets * 4, s));
+  return 0;
 }
 
 }  // namespace
@@ -1112,6 +1148,7 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   batch = &bl;
   Run Rt, Rv;
   make_runs(e, params_f32, params_bf16, nullptr, workspace, (hipStream_t)stream, batch, cfg, Rt, Rv);
+  if (int r = reset_tickets(e, workspace, (hipStream_t)stream)) return r;
   Rv.fail(order_streams(e, Rt.s, Rv.s));                 // fork: the visual stream starts after the caller's prior work
   // parameters of backward-segment `seg` may still be in the hands of an optimizer update running on another
   // stream (crct.optim overlap mode): wait for its event right before the first kernel that reads them
@@ -1133,6 +1170,7 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   for (const Step& st : e->sched) {
     const int seg = (int)e->sched.size() - step_i;       // backward segment of this schedule step
     Rt.defer = Rv.defer = paired && step_i >= e->first_conn;
+    Rt.phase = (e->first_conn < 0 || step_i < e->first_conn) ? 0 : 1;      // text-only prefix: nothing else on the data path
     ++step_i;
     if (st.kind == 't') wait_params(Rt, seg);
     else if (st.kind == 'v') wait_params(Rv, seg);
@@ -1155,6 +1193,7 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
     if (Rt.defer && (st.kind != 'v' || step_i == (int)e->sched.size() || e->sched[step_i].kind != 't')) Rt.pair_flush(Rv);
   }
   Rt.defer = Rv.defer = false;
+  Rt.phase = 1;
   wait_params(Rt, 0);
   wait_params(Rv, 0);
   Rt.heads_branch_fwd(false, xt);
@@ -1194,6 +1233,7 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
       else { xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
     }
   }
+  if (int r = reset_tickets(e, workspace, (hipStream_t)stream)) return r;
   // fork: every internal stream starts after the caller's prior work (previous segment, optimizer, ...)
   Rv.fail(order_streams(e, Rt.s, Rv.s));
   const bool paired = pairing_on(e, cfg);
@@ -1202,6 +1242,7 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
     const bool in_sched = sgi != 0 && sgi != nseg - 1;
     const size_t si = in_sched ? e->sched.size() - (size_t)sgi : 0;
     Rt.defer = Rv.defer = paired && in_sched && (int)si >= e->first_conn;
+    Rt.phase = (in_sched && (e->first_conn < 0 || (int)si < e->first_conn)) ? 0 : 1;      // backward tail through the text-only layers
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
       Rt.heads_bwd(Rv, e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
@@ -1249,8 +1290,6 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   Rt.main_after_wgrad();
   Rv.main_after_wgrad();
   Rt.fail(order_streams(e, Rv.s, Rt.s));
-  static const bool dbg_ev = getenv("CRCT_DEBUG_EVENTS") != nullptr;
-  if (dbg_ev) fprintf(stderr, "[crct] backward: %d ordering events\n", (int)e->evnext);
   return Rt.rc ? Rt.rc : Rv.rc;
 }
 
@@ -1299,7 +1338,7 @@ extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, 
 // peer visibility) in every record, which these same-device stream orderings do not need.
 extern "C" void* crct_event_create(void) {
   hipEvent_t ev = nullptr;
-  static const unsigned flags = getenv("CRCT_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+  const unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
   if (hipEventCreateWithFlags(&ev, flags) != hipSuccess) { crct_set_error("event_create: hipEventCreateWithFlags failed"); return nullptr; }
   return ev;
 }
@@ -1325,6 +1364,15 @@ extern "C" int crct_event_query(void* ev) {          // 1: everything before the
 extern "C" int crct_event_synchronize(void* ev) {
   CRCT_REQUIRE(ev, "event_synchronize: null event");
   CRCT_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev));
+  return 0;
+}
+
+extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind, int phase, int cfg, int split_k) {
+  CRCT_REQUIRE(e && site > 0 && site < CRCT_SITE_COUNT && (kind == CRCT_KIND_FWD || kind == CRCT_KIND_DGRAD) && phase <= 1,
+               "set_site_policy: bad site / kind / phase (%d, %d, %d)", site, kind, phase);
+  CRCT_REQUIRE(cfg >= -1 && cfg <= 15 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
+  for (int ph = 0; ph < 2; ++ph)
+    if (phase < 0 || phase == ph) { e->policy[site][kind][ph].cfg = cfg; e->policy[site][kind][ph].split_k = split_k; }
   return 0;
 }
 

@@ -524,6 +524,65 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
   }
 }
 
+// ====================================================================================== split-K seam
+// S workgroups share one output tile.  Each parks its accumulators as they lie in registers (slab layout: 16-byte unit
+// (a * WTM + b) * threads + tid, so every store / load instruction of a wave covers 1 KiB of consecutive bytes) with
+// WRITE-THROUGH stores (sc1: the bytes are at the memory side once vmcnt has drained -- no release fence, which would write
+// back the whole L2), drains, meets its workgroup at a barrier, and ONE lane draws a ticket (agent-scope atomic).  The
+// workgroup that draws S - 1 knows the other S - 1 slabs are complete: one agent-scope acquire (drops this CU's L1 lines),
+// then it reads ALL S slabs -- its own included, so the summation order is slice 0, 1, .. S - 1 whichever slice it is -- with
+// sc1 loads, and carries on into the ordinary epilogue.  Correct for any placement of a tile's slices over CUs / XCDs
+// (cdna_hip_programming.md section 5 "Projection GEMM at M = 256" item 2, Guideline 16 R1); the block -> (tile, slice) map only
+// keeps a tile's slices on one XCD for speed.  The ticket is put back to 0 by the last arriver (all S adds have happened).
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+template <int BM, int BN, int NW, int WTM, int WTN>
+__device__ __forceinline__ bool splitk_reduce(const CrctGemmArgs& g, f4_t (&acc)[WTN][WTM], char* smem, int slice, int tile_lin, int tid) {
+  const int S = g.split_k;
+  if (S <= 1) return true;
+  constexpr int NT = NW * 64;
+  constexpr int SLAB = BM * BN * 4;                                   // bytes per slab
+  static_assert(WTM * WTN * NT * 16 == SLAB, "slab layout covers the tile");
+  char* tile_ws = reinterpret_cast<char*>(g.splitk_ws) + (size_t)tile_lin * S * SLAB;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(tile_ws, 0, S * SLAB, 0x00020000);
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTM; ++b)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, acc[a][b]), rw, slice * SLAB + ((a * WTM + b) * NT + tid) * 16, 0, 16 /* sc1 */);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // EVERY storing wave drains its stores ...
+  __syncthreads();                                                    // ... before the one lane that signals for all of them
+  unsigned* flag = reinterpret_cast<unsigned*>(smem);                 // the operand ring is idle: every wave is past its last fragment read
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(g.splitk_cnt + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)(S - 1)) {
+      __hip_atomic_store(g.splitk_cnt + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    flag[0] = t;
+  }
+  __syncthreads();
+  const unsigned ticket = flag[0];
+  if (ticket != (unsigned)(S - 1)) return false;
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int s2 = 0; s2 < S; ++s2) {
+    u4_t v[WTN][WTM];
+#pragma unroll
+    for (int a = 0; a < WTN; ++a)
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) v[a][b] = __builtin_amdgcn_raw_buffer_load_b128(rw, s2 * SLAB + ((a * WTM + b) * NT + tid) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+    for (int a = 0; a < WTN; ++a)
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) acc[a][b] += __builtin_bit_cast(f4_t, v[a][b]);
+  }
+  return true;
+}
+
 // ====================================================================================== pipelined
 // LDS-DMA variant (K % 64 == 0): operand tiles go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds
 // (no VGPR staging, no ds_write), NS stages deep, ONE raw s_barrier per K-step and a counted
@@ -577,8 +636,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // Block tile (32*TM) x (32*TN), WM x WN waves (4 or 8), each wave owning a (BM/WM) x (BN/WN) sub-tile.
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
-__device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg) {
+// SK: K-partitioned variant (CrctGemmArgs.split_k): workgroup (tile, slice) contracts K tiles [kt0, kt0 + nk) and the last of
+// a tile's slices to arrive reduces the slabs (see splitk_reduce).
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, bool SK = false>
+__device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg,
+                                               const int slice = 0, const int tile_lin = 0) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave per K tile
@@ -622,15 +684,20 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-  const int nk = g.K / BK;
+  int kt0 = 0, nk = g.K / BK;
+  if constexpr (SK) {
+    const int S = g.split_k, nk_all = nk;
+    kt0 = (int)((long)slice * nk_all / S);
+    nk = (int)((long)(slice + 1) * nk_all / S) - kt0;
+  }
   auto issue = [&](int kt, int st) {
     char* base = smem + st * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + i * NW * 1024), 16, (int)offA[i], kt * stepA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + i * NW * 1024), 16, (int)offA[i], (kt0 + kt) * stepA, 0, 0);
 #pragma unroll
     for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NW * 1024), 16, (int)offB[i], kt * stepB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NW * 1024), 16, (int)offB[i], (kt0 + kt) * stepB, 0, 0);
   };
 
   const int npre = nk < NS - 1 ? nk : NS - 1;
@@ -744,6 +811,9 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
       for (int b = 0; b < WTM; ++b) asm volatile("" ::"v"(acc[a][b]));
     return;
   }
+  if constexpr (SK) {
+    if (!splitk_reduce<BM, BN, NW, WTM, WTN>(g, acc, smem, slice, tile_lin, tid)) return;     // not the last slice of this tile
+  }
   if (do_rs) {
     // every row of the 16x16 result holds the same sums: row 0 lives in lanes 0..15, register 0
     static_assert((WN & (WN - 1)) == 0 && WN * BM * 4 <= NS * STAGE, "row-sum staging");
@@ -771,6 +841,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmA
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tile_m, tile_n, tmap.dbg);
+}
+
+// K-partitioned launch: block j of XCD x is slice j % S of the (j / S)-th tile of that XCD's rectangle -- a tile's slices share
+// an L2 (speed only).  Grid = 8 * rm * rn * S.
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  const int S = g.split_k;
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  int tile_m, tile_n;
+  if (!map_tile(tmap, ((j / S) << 3) | x, tile_m, tile_n)) return;
+  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, true>(g, tile_m, tile_n, 0, j % S, tile_m * tmap.tiles_n + tile_n);
 }
 
 // ====================================================================================== fp8 forward (BASELINE configs[4])
@@ -972,6 +1053,32 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   return hipGetLastError();
 }
 
+// split-K launcher: only the configurations the step uses it with are instantiated (forward and data gradient)
+template <int TM, int TN, int WM, int WN, int NS>
+hipError_t launch_splitk(const CrctGemmArgs& g, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  int tiles = 0;
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
+  const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_SK(TB_)                                                                                                \
+  do {                                                                                                                     \
+    auto kern = gemm_splitk_kernel<TM, TN, WM, WN, false, TB_, NS>;                                                        \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    launch_kernel(kern, dim3(tiles * g.split_k), dim3(WM * WN * 64), lds, s, g, tmap);                                     \
+  } while (0)
+  if (g.ta) return hipErrorInvalidValue;
+  if (g.tb) CRCT_LAUNCH_SK(true);
+  else CRCT_LAUNCH_SK(false);
+#undef CRCT_LAUNCH_SK
+  return hipGetLastError();
+}
+
 template <int TM, int TN, int WM, int WN, int NS>
 hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -1039,10 +1146,9 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 // L2->LDS traffic and prefetch latency, so 8-wave workgroups with 2 resident per CU win.
 //   12: 128x64, 8 waves (4x2), 2 stages    15: the same with 3 stages (narrow output, long K)    3: 64x64, 4 waves, 4 stages
 //   grouped weight gradients: 4 = 128x128, 8 waves (2x4), 3 stages
-static int env_cfg(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
 // Shape classes of the step's forward / data-gradient GEMMs and the configuration each one runs with (ids of the switch in
-// crct_gemm_launch).  CRCT_GEMM_CLS="tw=9,vm=15,..." overrides single classes for A/B runs of the whole step (developer
-// knob: every id computes the same result).
+// crct_gemm_launch).  Per-site overrides for A/B runs of the whole step go through crct_engine_set_site_policy (CrctGemmArgs.tile):
+// no environment variable changes what a shipped kernel launch does.
 //   tw   text rows (M <= 2000), wide output (N >= 2304)          FFN-up / QKV forward, FFN-down data gradient
 //   tn   text rows, narrow output (N <= 1024), K <= 1024          attention-output / dense2 forward and data gradient
 //   tnl  text rows, narrow output, long K (> 1024)                FFN-down forward, FFN-up / QKV data gradient
@@ -1056,49 +1162,63 @@ static int env_cfg(const char* name) { const char* v = getenv(name); return v ? 
 // so the kernels of the other internal streams can no longer share the CUs.  The 48-72 KB configurations below stay.
 enum { CLS_TW, CLS_TN, CLS_TNL, CLS_VW, CLS_VM, CLS_VML, CLS_COUNT };
 static const int* class_table() {
-  static int tab[CLS_COUNT] = {12, 12, 15, 12, 12, 4};      // vml: 128x128, 3 stages (long context 12.33 -> 12.19 ms, configs[1] 7.61 -> 7.56)
-  static bool init = false;
-  if (!init) {
-    init = true;
-    const char* names[CLS_COUNT] = {"tw", "tn", "tnl", "vw", "vm", "vml"};
-    if (const char* e = getenv("CRCT_GEMM_CLS")) {
-      std::string str(e);
-      for (int c = 0; c < CLS_COUNT; ++c) {
-        const std::string key = std::string(names[c]) + "=";
-        size_t pos = 0;
-        while ((pos = str.find(key, pos)) != std::string::npos) {
-          if (pos == 0 || str[pos - 1] == ',') { tab[c] = atoi(str.c_str() + pos + key.size()); break; }
-          pos += key.size();
-        }
-      }
-    }
-  }
+  static const int tab[CLS_COUNT] = {12, 12, 15, 12, 12, 4};      // vml: 128x128, 3 stages (long context 12.33 -> 12.19 ms, configs[1] 7.61 -> 7.56)
   return tab;
 }
 static int pick_pipe_config(const CrctGemmArgs& g) {
   if (g.M <= 96) return 3;                                          // head / regressor GEMMs: B rows
-  if (g.ta) {                                                       // single weight gradient (grouped ones: crct_gemm_launch_grouped)
-    static const int ov_w = env_cfg("CRCT_GEMM_WGRAD");
-    if (ov_w >= 0) return ov_w;
-    return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 9;
-  }
+  if (g.ta) return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 9;      // single weight gradient (grouped ones: crct_gemm_launch_grouped)
   const bool text = g.M <= 2000, wide = g.N >= 2304, longk = g.K > 1024;
   const int cls = text ? (wide ? CLS_TW : (longk ? CLS_TNL : CLS_TN)) : (wide ? CLS_VW : (longk ? CLS_VML : CLS_VM));
   const int t = class_table()[cls];
   return (t < 0 || t > 15) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
 }
 
-// ---- optional live profiling: HIP events around every GEMM launch, on the launch stream ----------
-// (bench.py: roofline.achieved = algorithmic FLOPs per launch / average launch duration per variant)
+// ---- optional live profiling: begin / end stamps of every GEMM kernel, on the launch stream ----------
+// (bench.py: roofline.achieved = algorithmic FLOPs per launch / average launch duration, per variant and per model site)
 namespace {
-struct ProfSlot { hipEvent_t a, b; int variant; };
+struct ProfSlot { hipEvent_t a, b; int variant; int nsite; short site[GROUP_MAX]; double fl[GROUP_MAX]; };   // site[] = site * 3 + kind
 struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
   static constexpr int NV = 72;        // (16 LDS-DMA configurations + 4 register-staged + spare) x {fwd, dgrad, wgrad}
   double flops[NV] = {0}; long count[NV] = {0};
+  bool log_on = false;
+  std::vector<CrctLaunchRec> log;
 } g_prof;
+
+inline int kind_of(const CrctGemmArgs& g) { return g.ta ? CRCT_KIND_WGRAD : (g.tb ? CRCT_KIND_DGRAD : CRCT_KIND_FWD); }
+inline int site_of(const CrctGemmArgs& g) { return (g.site > 0 && g.site < CRCT_SITE_COUNT) ? g.site : 0; }
+
+ProfSlot* prof_begin(int variant, const CrctGemmArgs* gs, int n) {
+  if (!g_prof.on) return nullptr;
+  if (g_prof.used == g_prof.slots.size()) {
+    ProfSlot ns;
+    if (hipEventCreate(&ns.a) != hipSuccess || hipEventCreate(&ns.b) != hipSuccess) return nullptr;
+    g_prof.slots.push_back(ns);
+  }
+  ProfSlot* slot = &g_prof.slots[g_prof.used++];
+  slot->variant = variant;
+  slot->nsite = n;
+  g_prof.count[variant] += 1;
+  for (int i = 0; i < n; ++i) {
+    const double fl = 2.0 * gs[i].M * gs[i].N * gs[i].K;
+    slot->site[i] = (short)(site_of(gs[i]) * 3 + kind_of(gs[i]));
+    slot->fl[i] = fl;
+    g_prof.flops[variant] += fl;
+  }
+  g_time_start = slot->a; g_time_stop = slot->b;
+  return slot;
+}
+void log_launch(const CrctGemmArgs* gs, int n, int cfg, int grid) {
+  if (!g_prof.log_on) return;
+  CrctLaunchRec r;
+  r.site = n == 1 ? site_of(gs[0]) : -1; r.kind = kind_of(gs[0]); r.M = gs[0].M; r.N = gs[0].N; r.K = gs[0].K;
+  r.cfg = cfg; r.split_k = gs[0].split_k > 1 ? gs[0].split_k : 1; r.grid = grid; r.n_problems = n; r.flops = 0;
+  for (int i = 0; i < n; ++i) r.flops += 2.0 * gs[i].M * gs[i].N * gs[i].K;
+  g_prof.log.push_back(r);
+}
 }  // namespace
 
 static bool g_force_generic = false;
@@ -1114,54 +1234,95 @@ extern "C" int crct_prof_reset(void) {
   for (int i = 0; i < Prof::NV; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
   return 0;
 }
+static int slot_ms(const ProfSlot& sl, float* ms) {
+  if (hipEventSynchronize(sl.b) != hipSuccess) return 1;
+  return hipEventElapsedTime(ms, sl.a, sl.b) != hipSuccess;
+}
 // variant = config * 3 + {0: fwd (NT), 1: dgrad (tb), 2: wgrad (ta, tb)}; config 0..15 = LDS-DMA kernel, 16..19 = register-staged
-// configurations, 13..16 = register-staged kernel tiles 0..3.  Synchronises the events.
+// kernel tiles 0..3, 20 / 21 = fp8.  Synchronises the events.
 extern "C" int crct_prof_read(int variant, long* count, double* flops, double* ms) {
   if (variant < 0 || variant >= Prof::NV) return 1;
   double t = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     if (g_prof.slots[i].variant != variant) continue;
     float e = 0;
-    if (hipEventSynchronize(g_prof.slots[i].b) != hipSuccess) return 1;
-    if (hipEventElapsedTime(&e, g_prof.slots[i].a, g_prof.slots[i].b) != hipSuccess) return 1;
+    if (slot_ms(g_prof.slots[i], &e)) return 1;
     t += e;
   }
   *count = g_prof.count[variant]; *flops = g_prof.flops[variant]; *ms = t;
   return 0;
 }
+extern "C" int crct_prof_read_site(int site, int kind, long* count, double* flops, double* ms, int* apportioned) {
+  if (site < 0 || site >= CRCT_SITE_COUNT || kind < 0 || kind > 2) return 1;
+  const short key = (short)(site * 3 + kind);
+  long n = 0; double fl = 0, t = 0; int app = 0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    const ProfSlot& sl = g_prof.slots[i];
+    double mine = 0, all = 0;
+    int hits = 0;
+    for (int j = 0; j < sl.nsite; ++j) { all += sl.fl[j]; if (sl.site[j] == key) { mine += sl.fl[j]; ++hits; } }
+    if (!hits) continue;
+    float e = 0;
+    if (slot_ms(sl, &e)) return 1;
+    n += hits; fl += mine;
+    t += all > 0 ? (double)e * mine / all : 0.0;
+    if (sl.nsite > 1) app = 1;
+  }
+  *count = n; *flops = fl; *ms = t;
+  if (apportioned) *apportioned = app;
+  return 0;
+}
+extern "C" int crct_launch_log_enable(int on) {
+  g_prof.log_on = on != 0;
+  if (on) g_prof.log.clear();
+  return 0;
+}
+extern "C" int crct_launch_log_count(void) { return (int)g_prof.log.size(); }
+extern "C" int crct_launch_log_read(int i, CrctLaunchRec* out) {
+  if (i < 0 || i >= (int)g_prof.log.size() || !out) return 1;
+  *out = g_prof.log[i];
+  return 0;
+}
 
-hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
-  if (g.M <= 0 || g.N <= 0) return hipSuccess;
+// split-K needs the LDS-DMA kernel; the slab space is sized for the larger of the tiles it is built with (128 x 128)
+extern "C" int64_t crct_gemm_splitk_ws_elems(int M, int N, int split_k) {
+  if (split_k <= 1) return 0;
+  const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128;
+  return tm * tn * 128 * 128 * (int64_t)split_k;
+}
+extern "C" int crct_gemm_splitk_tickets(int M, int N) { return ((M + 127) / 128) * ((N + 63) / 64); }
+static bool splitk_ok(const CrctGemmArgs& g) {
+  return g.split_k > 1 && g.split_k <= 8 && !g.ta && !g.fp8 && !g.rowsum_out && g.splitk_ws && g.splitk_cnt && g.K / BK >= 2 * g.split_k;
+}
+
+hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
+  if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
+  CrctGemmArgs g = g_in;
   if (g.fp8 && !f8_ok(g)) return hipErrorInvalidValue;
   if (g.q_out && !g.fp8) return hipErrorInvalidValue;           // the e4m3 output copy exists in the fp8 kernel only
   const bool pipe = g.fp8 || (pipe_ok(g) && !g_force_generic);
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
   if (t > 15) t = 12;
-  // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21); a developer override
-  // CRCT_GEMM_F8=<stages> forces one of them
-  if (g.fp8) {
-    static const int ov = env_cfg("CRCT_GEMM_F8");
-    t = (g.tile == 20 || g.tile == 21) ? g.tile : (ov == 2 || ov == 3) ? 18 + ov : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
-  }
+  // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21)
+  if (g.fp8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
-  ProfSlot* slot = nullptr;
-  if (g_prof.on) {
-    if (g_prof.used == g_prof.slots.size()) {
-      ProfSlot ns;
-      if (hipEventCreate(&ns.a) != hipSuccess || hipEventCreate(&ns.b) != hipSuccess) return hipErrorOutOfMemory;
-      g_prof.slots.push_back(ns);
-    }
-    slot = &g_prof.slots[g_prof.used++];
-    slot->variant = (pipe ? t : 16 + (t & 3)) * 3 + (g.ta ? 2 : (g.tb ? 1 : 0));
-    g_prof.count[slot->variant] += 1;
-    g_prof.flops[slot->variant] += 2.0 * g.M * g.N * g.K;
-    g_time_start = slot->a; g_time_stop = slot->b;
-  }
+  // K-partitioned launch: the four configurations it is built for; anything else runs unsplit (same function, other summation order)
+  if (g.split_k > 1 && !(pipe && splitk_ok(g) && (t == 4 || t == 9 || t == 12 || t == 15))) g.split_k = 0;
+  if (g.split_k <= 1) g.split_k = 0;
+  prof_begin((pipe ? t : 16 + (t & 3)) * 3 + kind_of(g), &g, 1);
   hipError_t e;
+  int grid = 0;
   if (g.fp8) {
     e = t == 21 ? launch_f8<4, 2, 4, 2, 3>(g, s) : launch_f8<4, 2, 4, 2, 2>(g, s);
+  } else if (pipe && g.split_k) {
+    switch (t) {
+      case 4: e = launch_splitk<4, 4, 2, 4, 3>(g, s); break;
+      case 9: e = launch_splitk<4, 4, 2, 4, 2>(g, s); break;
+      case 15: e = launch_splitk<4, 2, 4, 2, 3>(g, s); break;
+      default: e = launch_splitk<4, 2, 4, 2, 2>(g, s); break;
+    }
   } else if (pipe) {
     switch (t) {
       case 0: e = launch_pipe<4, 4, 2, 2, 3>(g, s); break;
@@ -1190,6 +1351,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s) {
     }
   }
   g_time_start = g_time_stop = nullptr;
+  log_launch(&g, 1, pipe ? t : 16 + (t & 3), grid);
   return e;
 }
 
@@ -1210,24 +1372,10 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
     }
     return hipSuccess;
   }
-  static const int cfg_w = getenv("CRCT_GEMM_GROUP") ? atoi(getenv("CRCT_GEMM_GROUP")) : 4;   // weight gradients: 128x128, 8 waves, 3 stages
-  static const int cfg_p = getenv("CRCT_GEMM_PAIR") ? atoi(getenv("CRCT_GEMM_PAIR")) : 9;     // forward / dgrad pairs: 128x128, 8 waves, 2 stages
-  const int cfg = gs[0].ta ? cfg_w : cfg_p;
-  ProfSlot* slot = nullptr;
-  if (g_prof.on) {                     // one timed slot for the whole group, FLOPs summed
-    if (g_prof.used == g_prof.slots.size()) {
-      ProfSlot ns;
-      if (hipEventCreate(&ns.a) != hipSuccess || hipEventCreate(&ns.b) != hipSuccess) return hipErrorOutOfMemory;
-      g_prof.slots.push_back(ns);
-    }
-    slot = &g_prof.slots[g_prof.used++];
-    slot->variant = (cfg == 12 || cfg == 9 ? cfg : 4) * 3 + (gs[0].ta ? 2 : (gs[0].tb ? 1 : 0));
-    g_prof.count[slot->variant] += 1;
-    for (int i = 0; i < n; ++i) g_prof.flops[slot->variant] += 2.0 * gs[i].M * gs[i].N * gs[i].K;
-    g_time_start = slot->a; g_time_stop = slot->b;
-  }
-  const hipError_t e = cfg == 12 ? launch_group<4, 2, 4, 2, 2>(gs, n, s)
-                       : cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s);
+  const int cfg = gs[0].ta ? 4 : 9;    // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages
+  prof_begin(cfg * 3 + kind_of(gs[0]), gs, n);
+  const hipError_t e = cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s);
   g_time_start = g_time_stop = nullptr;
+  log_launch(gs, n, cfg, 0);
   return e;
 }

@@ -1019,27 +1019,16 @@ int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct
 
 // the embedding backward kernels write 7 partial rows per wave: fewer, longer-running waves than the LayerNorm backward
 static int embed_bwd_blocks(long M) {
-  static const int cap = [] {
-    const char* e = getenv("CRCT_EMBED_BWD_BLOCKS");   // developer knob
-    const int v = e ? atoi(e) : 0;
-    return v > 0 && v < CRCT_LN_BWD_MAX_BLOCKS ? v : CRCT_LN_BWD_MAX_BLOCKS;
-  }();
-  return row_grid(M, cap);
+  return row_grid(M, CRCT_LN_BWD_MAX_BLOCKS);
 }
 int crct_layernorm_bwd_blocks(int M) {
-  static const int cap = [] {
-    const char* e = getenv("CRCT_LN_BWD_BLOCKS");   // developer knob (buffers are sized for 4 x CRCT_LN_BWD_MAX_BLOCKS partial rows)
-    const int v = e ? atoi(e) : 0;
-    return v > 0 && v <= 4 * CRCT_LN_BWD_MAX_BLOCKS ? v : CRCT_LN_BWD_MAX_BLOCKS;
-  }();
-  return row_grid(M, cap);
+  return row_grid(M, CRCT_LN_BWD_MAX_BLOCKS);
 }
 
 // rows pass only: dx / dx_lin and the per-workgroup column partials [3][nblk][H]
 // the LayerNorm backward combines its waves' partial rows in LDS when [3][4][H] fp32 fit the default 64 KB
 static bool ln_bwd_combines(int H) {
-  static const bool off = getenv("CRCT_LN_BWD_NO_COMBINE") != nullptr;      // developer A/B switch
-  return !off && (size_t)3 * ROWS_PER_BLOCK * H * 4 <= 64 * 1024;
+  return (size_t)3 * ROWS_PER_BLOCK * H * 4 <= 64 * 1024;
 }
 static LnBwdP ln_bwd_problem(const CrctLnBwdArgs& a) {
   return LnBwdP{(const bf16_t*)a.dy, (const bf16_t*)a.x, a.mean, a.rstd, a.gamma, (bf16_t*)a.dx, (bf16_t*)a.dx_lin, a.partials,
@@ -1232,7 +1221,8 @@ __global__ __launch_bounds__(256) void fp8_weights_kernel(const float* __restric
 // (reset != 0 clears them: the caller does that every few hundred steps, the "max over a history window" of the usual fp8
 // recipes): a wave only issues an atomic when it raises the word it reports into, so after the first steps of a window the
 // kernels issue none at all -- resetting every step cost 2.4 ms per step in atomic storms (round-2 measurement).
-__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n, int reset) {
+__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n, int reset, const float* __restrict__ skip_if) {
+  if (skip_if && skip_if[0] != 0.f) return;      // a skipped optimizer step (GradScaler found inf / nan) leaves the shadow, hence its scales, alone
   const int i = blockIdx.x * (blockDim.x / CRCT_FP8_AMAX_LANES) + threadIdx.x / CRCT_FP8_AMAX_LANES, l = threadIdx.x % CRCT_FP8_AMAX_LANES;
   if (i < n) {          // one wave (64 lanes = LANES) per entry
     float* w = amax + (long)i * CRCT_FP8_AMAX_LANES + l;
@@ -1255,10 +1245,10 @@ int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* am
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, crct_stream_t stream) {
+int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, crct_stream_t stream) {
   CRCT_REQUIRE(scale && amax && n >= 0, "fp8_update_scales: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset, skip_if);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1272,7 +1262,7 @@ int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, c
   CRCT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)n_slots * CRCT_FP8_AMAX_LANES * 4, s));
   hipLaunchKernelGGL(fp8_weights_kernel<0>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0, (const float*)nullptr);
   hipLaunchKernelGGL(fp8_weights_kernel<1>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());

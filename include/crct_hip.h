@@ -65,7 +65,33 @@ typedef struct CrctGemmArgs {
   int32_t fp8;
   const float* scale_a; const float* scale_b;
   void* q_out; const float* q_scale; float* q_amax; int64_t ld_q;
+  /* Which Linear of the model this launch belongs to (CRCT_SITE_*; 0 = untagged): only read by the live profile
+   * (crct_prof_read_site) and the launch log -- never by a kernel. */
+  int32_t site;
+  /* K-partitioned launch (forward / data-gradient GEMMs of the LDS-DMA kernel whose output has too few tiles for 256 CUs:
+   * M = 1600 rows x N = 768 is 78-156 workgroups).  split_k = S > 1: S workgroups per output tile each contract 1/S of the K
+   * tiles, park their fp32 accumulators in splitk_ws (write-through stores) and draw a ticket from splitk_cnt[tile]; the one
+   * that draws S - 1 adds the S slabs IN SLICE ORDER (so the result does not depend on which slice finished last), runs the
+   * epilogue and puts the ticket back to 0.  splitk_ws: device fp32, >= tiles * S * BM * BN elements (crct_gemm_splitk_ws_elems);
+   * splitk_cnt: device uint32 [tiles], zero before the first use.  Both belong to ONE stream: launches that share them must be
+   * stream-ordered.  0 / 1 = off.  Not with ta (weight gradients), rowsum_out or fp8. */
+  int32_t split_k;
+  float* splitk_ws; uint32_t* splitk_cnt;
 } CrctGemmArgs;
+
+/* GEMM sites of the step.  The FFN group of BASELINE.md section 4 ("fraction of the FFN-GEMM roofline") = the four *_FFN_* sites. */
+enum {
+  CRCT_SITE_NONE = 0,
+  CRCT_SITE_T_QKV = 1, CRCT_SITE_T_OUT = 2, CRCT_SITE_T_FFN_UP = 3, CRCT_SITE_T_FFN_DN = 4,      /* text stream: BertLayer + the text side of BertConnectionLayer's FFN */
+  CRCT_SITE_V_QKV = 5, CRCT_SITE_V_OUT = 6, CRCT_SITE_V_FFN_UP = 7, CRCT_SITE_V_FFN_DN = 8,      /* visual stream */
+  CRCT_SITE_C_QKV_T = 9, CRCT_SITE_C_QKV_V = 10, CRCT_SITE_C_OUT_T = 11, CRCT_SITE_C_OUT_V = 12, /* co-attention: query2/key2/value2, query1/key1/value1, biOutput.dense2, dense1 */
+  CRCT_SITE_IMG_EMB = 13, CRCT_SITE_HEAD = 14, CRCT_SITE_COUNT = 15
+};
+enum { CRCT_KIND_FWD = 0, CRCT_KIND_DGRAD = 1, CRCT_KIND_WGRAD = 2 };
+/* fp32 elements of split-K slab space an M x N output needs for `split_k` slices with the tile configuration the launcher
+ * would use (an upper bound over the split-K configurations), and the number of ticket words. */
+int64_t crct_gemm_splitk_ws_elems(int M, int N, int split_k);
+int crct_gemm_splitk_tickets(int M, int N);
 
 int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
 /* n <= 8 independent GEMMs in ONE grid (same ta/tb, no epilogue extras besides the output type and accumulate):
@@ -86,6 +112,19 @@ int crct_gemm_force_generic(int on);
 int crct_prof_enable(int on);
 int crct_prof_reset(void);
 int crct_prof_read(int variant, long* count, double* flops, double* ms);
+/* The same stamps keyed by model site (CRCT_SITE_*) and kind (CRCT_KIND_*).  A grouped launch (the weight gradients of a layer
+ * in one grid) is ONE kernel: its duration is apportioned to its member problems by their share of the launch's FLOPs
+ * (`apportioned` != 0 tells the caller that this (site, kind) contains such shares). */
+int crct_prof_read_site(int site, int kind, long* count, double* flops, double* ms, int* apportioned);
+/* Launch log (developer tooling: tools/pmc_sites.py matches it against a rocprofv3 counter collection, which serialises
+ * dispatches in host enqueue order): while enabled, every GEMM kernel launch appends one record. */
+typedef struct CrctLaunchRec {
+  int32_t site, kind, M, N, K, cfg, split_k, grid, n_problems;   /* grouped launch: site = -1, M/N/K of problem 0, n_problems > 1 */
+  double flops;
+} CrctLaunchRec;
+int crct_launch_log_enable(int on);      /* on != 0 also clears the log */
+int crct_launch_log_count(void);
+int crct_launch_log_read(int i, CrctLaunchRec* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm (TF style, eps inside sqrt) -- BertLayerNorm, vilbert.py:281-294 -- over rows that
@@ -120,7 +159,9 @@ int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct
 #define CRCT_FP8_AMAX_LANES 64
 /* fp8 (OCP e4m3, per-tensor delayed scaling) helpers.  All scales / amax values are device fp32.
  *  crct_fp8_quantize_bf16   q[i] = e4m3(x[i] * *scale), *amax = max(*amax, max |x|)            (n % 8 == 0)
- *  crct_fp8_update_scales   scale[i] = 448 / amax[i] where amax[i] > 0; reset != 0 also clears amax[i].  The amax values are
+ *  crct_fp8_update_scales   scale[i] = 448 / amax[i] where amax[i] > 0; reset != 0 also clears amax[i]; skip_if (device fp32,
+ *                           may be NULL) != 0 leaves everything untouched (GradScaler's found_inf: a skipped optimizer step
+ *                           does not requantise the weight shadow, so its scales must stay too).  The amax values are
  *                           RUNNING maxima: call it once per step with reset = 0 and every few hundred steps with reset = 1
  *                           (a history window); clearing every step makes every wave of every producer issue an atomic
  *  crct_fp8_quantize_weights  exact per-tensor scaling of fp32 weights into the flat e4m3 shadow (same element offsets as
@@ -128,7 +169,7 @@ int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct
  *                           (blk_seg, blk_off) from crct_adamw_plan; writes scale[slot] = 448 / max |w|.  Used at start-up
  *                           and after a load_state_dict; the optimizer keeps the shadow current afterwards (CrctFp8Shadow). */
 int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* amax, int64_t n, crct_stream_t stream);
-int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, crct_stream_t stream);
+int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, crct_stream_t stream);
 int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, const int64_t* seg_len, const int32_t* seg_slot,
                               const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk, float* scale, float* amax, int n_slots,
                               crct_stream_t stream);
@@ -201,8 +242,11 @@ int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_
                        crct_stream_t stream);
 /* Two implementations share these entry points: Tq, Tk <= 112 with d in {32, 48, 64} run one wave per
  * (batch, head) on MFMA (attention_mfma.hip); everything else (and everything after
- * crct_attention_force_valu(1) / CRCT_ATTN_VALU=1) the fp32 VALU kernels.  Same dropout stream in both. */
+ * crct_attention_force_valu(1)) the fp32 VALU kernels.  Same dropout stream in both. */
 void crct_attention_force_valu(int on);
+/* Test hook of the MFMA kernels: n = 1 / 2 / 4 waves per (batch, head) where the tile counts allow it, 0 = automatic.  Every
+ * count computes the same bits (tests/test_kernels_gpu.py). */
+void crct_attention_force_split(int n);
 /* Backward: recomputes P from q,k (no probabilities are stored).  dq/dk/dv have the layout of q/k/v.
  * accumulate_kv != 0 adds into dk/dv instead of overwriting (unused by the step; kept for tests). */
 int crct_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* keymask,
@@ -329,7 +373,8 @@ int crct_eval_select(const float* logits, const float* reg_out, const float* reg
 typedef struct CrctAmpState { const float* grad_scale; const float* found_inf; const int32_t* step; } CrctAmpState;
 int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_stream_t stream);
 /* e4m3 shadow of the weights the fp8 forward GEMMs read: q = flat byte buffer with the element offsets of the fp32 buffer,
- * seg_slot[s] = scale slot of AdamW segment s (-1: tensor has no fp8 shadow), scale / amax = device fp32 [n_slots].  The update
+ * seg_slot[s] = scale slot of AdamW segment s (-1: tensor has no fp8 shadow), scale = device fp32 [n_slots], amax = device fp32
+ * [n_slots * CRCT_FP8_AMAX_LANES].  The update
  * quantises the NEW weights with scale[slot] and max-es max |w| into amax[slot]; the caller runs crct_fp8_update_scales on
  * (scale, amax) before the NEXT update (delayed scaling).  All pointers device memory; q == NULL switches it off. */
 typedef struct CrctFp8Shadow { void* q; const int32_t* seg_slot; const float* scale; float* amax; } CrctFp8Shadow;
@@ -433,6 +478,12 @@ int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad
  * (crct_gemm_bf16_grouped with n = 2, crct_layernorm_*_pair) instead of running on two concurrent streams.  Results are
  * bit-identical in both modes.  The fp8 forward always uses the two-stream schedule. */
 int crct_engine_set_pairing(crct_engine_t*, int on);
+/* Per-site launch policy of the forward / data-gradient GEMMs (A/B switch of the developer tools and the tests; the defaults
+ * are the measured choices).  phase 0 = the text-only part of the schedule (layers t0 .. before the first
+ * co-attention layer: nothing else on the chip's data path), phase 1 = beside the visual stream; phase < 0 sets both.
+ * cfg = kernel configuration id (-1 = the shape-class default), split_k = K slices (0 / 1 = off).  Every choice computes the
+ * same function; split_k changes the summation order over K (deterministically). */
+int crct_engine_set_site_policy(crct_engine_t*, int site, int kind, int phase, int cfg, int split_k);
 /* The weight gradients (flat offsets / element counts into grads_f32, sorted by offset) that exactly one weight-gradient
  * GEMM per backward pass produces and nothing else adds to: every Linear weight of the encoder layers, the image embedding,
  * the poolers and the regressor pipes.  The set is fixed by the schedule at crct_engine_create (it does not depend on the

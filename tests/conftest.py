@@ -31,8 +31,12 @@ def _gpu_selected(config):
     return "gpu" in m and "not gpu" not in m
 
 
-def pytest_sessionstart(session):
-    if not _gpu_selected(session.config) or os.environ.get("CRCT_NO_DDP_WORKERS"):
+def pytest_collection_finish(session):
+    """Runs after collection and before any test (so before this process touches the GPU).  The workers are only started
+    when tests/test_ddp_gpu.py is among the selected items: a ``-k`` subset without it runs with the GPU to itself."""
+    if not _gpu_selected(session.config) or os.environ.get("CRCT_NO_DDP_WORKERS") or _DDP["workers"]:
+        return
+    if not any(os.path.basename(str(it.fspath)) == "test_ddp_gpu.py" for it in session.items):
         return
     try:
         import torch

@@ -131,6 +131,61 @@ def test_gemm_wgrad_with_bias_gradient(R, gemm_path):
         assert rel_err(out, refs[0][0]) < 2e-3 and rel_err(db, refs[0][1] - 2.0) < 2e-3, tile
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(1600, 768, 3072, False), (1600, 768, 3072, True), (1600, 768, 2304, True), (1600, 768, 768, False),
+                                      (2880, 1024, 3072, True), (1600, 768, 1024, False), (300, 1000, 1280, False), (130, 72, 512, True)])
+@pytest.mark.parametrize("tile", [-1, 4, 9, 12, 15])
+@pytest.mark.parametrize("S", [2, 3, 4])
+def test_gemm_split_k_matches_unsplit_and_is_reproducible(M, N, K, tb, tile, S, gemm_path):
+    """CrctGemmArgs.split_k: S workgroups per output tile, slabs + ticket, the last arriver sums the slabs in slice order and
+    runs the FULL epilogue (bias, pre-activation copy, GELU, dropout, residual).  Against fp32 torch within the bf16 bound,
+    against the unsplit launch within the fp32 re-association bound, and twice in a row bit for bit (the summation order does not
+    depend on which slice finishes last); ragged M / N edges and a K that does not divide evenly into slices included."""
+    if gemm_path == "generic":
+        pytest.skip("split-K exists in the LDS-DMA kernel only")
+    x = bf(rand(M, K, seed=1))
+    w = bf(rand(K, N, scale=0.05, seed=2)) if tb else bf(rand(N, K, scale=0.05, seed=2))
+    b, add = rand(N, seed=3), bf(rand(M, N, seed=6))
+    ref = (x.float() @ (w.float() if tb else w.float().t())) + b + add.float()
+    kw = dict(tb=tb, bias=b, addend=add, tile=tile)
+    y1 = ops.gemm(x, w, M, N, K, **kw)
+    ys = ops.gemm(x, w, M, N, K, split_k=S, **kw)
+    ys2 = ops.gemm(x, w, M, N, K, split_k=S, **kw)
+    assert rel_err(ys, ref) < 1e-2
+    assert rel_err(ys, y1) < 8e-3                 # both round the same fp32 sums (up to re-association) to bf16
+    assert torch.equal(ys, ys2)
+    y32 = ops.gemm(x, w, M, N, K, split_k=S, out_f32=True, **kw)
+    assert rel_err(y32, ref) < 2e-3
+    # the epilogue extras: saved pre-activation, GELU, dropout keyed by the element index (same mask as the unsplit launch)
+    pre1, pre2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    g1 = ops.gemm(x, w, M, N, K, tb=tb, bias=b, act="gelu", preact_out=pre1, p_drop=0.1, site=5, seed=11, tile=tile)
+    g2 = ops.gemm(x, w, M, N, K, tb=tb, bias=b, act="gelu", preact_out=pre2, p_drop=0.1, site=5, seed=11, tile=tile, split_k=S)
+    assert rel_err(pre2, pre1) < 8e-3
+    assert torch.equal(g1 == 0, g2 == 0) or float(((g1 == 0) != (g2 == 0)).float().mean()) < 1e-4      # same dropout mask (gelu(x) == 0 only by underflow)
+    assert rel_err(g2, g1) < 1.5e-2
+
+
+def test_gemm_split_k_under_uneven_load():
+    """The hand-off must hold when the slices of a tile finish far apart and the reducer's CU has the other slabs' lines in its
+    L1 from the previous launch: many back-to-back launches over the SAME slab space, beside a bandwidth hog on another stream,
+    every output compared in full with the first (MI355X_MICROARCH.md: test hand-offs under uneven load, L1-warm)."""
+    L.load().crct_gemm_force_generic(0)
+    M, N, K = 1600, 768, 3072
+    x, w = bf(rand(M, K, seed=1)), bf(rand(N, K, scale=0.05, seed=2))
+    hog_a = torch.empty(64 << 20, device=DEV)
+    side = torch.cuda.Stream()
+    ref = {S: ops.gemm(x, w, M, N, K, split_k=S, tile=t).clone() for S, t in ((2, 12), (3, 4), (4, 15))}
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(60):
+        with torch.cuda.stream(side):
+            hog_a.mul_(1.0001)
+        for S, t in ((2, 12), (3, 4), (4, 15)):
+            y = ops.gemm(x, w, M, N, K, split_k=S, tile=t)
+            bad += int(not torch.equal(y, ref[S]))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
 def test_gemm_strided_rows():
     # CLS-row gather: A rows are hidden_states[:, 0] with row stride T*H
     B, T, H, N = 80, 20, 768, 1024
@@ -534,46 +589,40 @@ def test_device_events_order_streams_without_the_system_fence(gemm_path):
 
 
 # ------------------------------------------------------------------------------------------- attention: waves per (batch, head)
-_ATTN_SPLIT_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from crct import ops
-out = {}
-for name, B, h, Tq, Tk, d in (("self100", 3, 16, 100, 100, 64), ("co40x100", 3, 32, 40, 100, 32), ("self36", 5, 16, 36, 36, 64),
-                              ("self20", 5, 16, 20, 20, 48), ("self64", 2, 16, 64, 50, 48)):
-    g = torch.Generator().manual_seed(Tq * 1000 + Tk)
-    q = torch.randn(B, Tq, h * d, generator=g).cuda().bfloat16(); k = torch.randn(B, Tk, h * d, generator=g).cuda().bfloat16()
-    v = torch.randn(B, Tk, h * d, generator=g).cuda().bfloat16(); do = torch.randn(B, Tq, h * d, generator=g).cuda().bfloat16()
-    km = torch.ones(B, Tk, dtype=torch.uint8, device="cuda"); km[:, Tk - 3:] = 0
-    out[name + ".ctx"] = ops.attention_fwd(q, k, v, km, h, d, p_drop=0.1, site=3, seed=9).cpu()
-    dq, dk, dv = ops.attention_bwd(q, k, v, km, do, h, d, p_drop=0.1, site=3, seed=9)
-    out[name + ".dq"], out[name + ".dk"], out[name + ".dv"] = dq.cpu(), dk.cpu(), dv.cpu()
-torch.cuda.synchronize()
-torch.save(out, sys.argv[2])
-"""
+def _attn_split_case():
+    out = {}
+    for name, B, h, Tq, Tk, d in (("self100", 3, 16, 100, 100, 64), ("co40x100", 3, 32, 40, 100, 32), ("self36", 5, 16, 36, 36, 64),
+                                  ("self20", 5, 16, 20, 20, 48), ("self64", 2, 16, 64, 50, 48)):
+        g = torch.Generator().manual_seed(Tq * 1000 + Tk)
+        q = torch.randn(B, Tq, h * d, generator=g).cuda().bfloat16()
+        k = torch.randn(B, Tk, h * d, generator=g).cuda().bfloat16()
+        v = torch.randn(B, Tk, h * d, generator=g).cuda().bfloat16()
+        do = torch.randn(B, Tq, h * d, generator=g).cuda().bfloat16()
+        km = torch.ones(B, Tk, dtype=torch.uint8, device="cuda")
+        km[:, Tk - 3:] = 0
+        out[name + ".ctx"] = ops.attention_fwd(q, k, v, km, h, d, p_drop=0.1, site=3, seed=9).cpu()
+        dq, dk, dv = ops.attention_bwd(q, k, v, km, do, h, d, p_drop=0.1, site=3, seed=9)
+        out[name + ".dq"], out[name + ".dk"], out[name + ".dv"] = dq.cpu(), dk.cpu(), dv.cpu()
+    return out
 
 
-def test_attention_gives_the_same_bits_for_every_wave_count(gemm_path, tmp_path):
+def test_attention_gives_the_same_bits_for_every_wave_count(gemm_path):
     """attention_mfma.hip splits one (batch, head) over 1, 2 or 4 waves (query tiles, then key tiles); every tile is computed the
-    same way in the same summation order, so CRCT_ATTN_SPLIT=1 (one wave, the round-1 kernel) and the default must agree bit
-    for bit -- forward, dq, dk, dv, with dropout, at 7 x 7, 3 x 7, 4 x 4, 3 x 3 and 2 x 2 tiles."""
+    same way in the same summation order, so one wave per pair (crct_attention_force_split(1), the round-1 kernel), two, and the
+    default must agree bit for bit -- forward, dq, dk, dv, with dropout, at 7 x 7, 3 x 7, 4 x 4, 3 x 3 and 2 x 2 tiles."""
     if gemm_path != "pipelined":
         pytest.skip("no GEMM in this test")
-    import os
-    import subprocess
-    import sys
-    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cqa-crct_amd")
+    from crct import lib as L
+    lib = L.load()
     res = {}
-    for split in ("1", "0"):
-        path = str(tmp_path / ("attn_%s.pt" % split))
-        env = dict(os.environ)
-        env.pop("CRCT_ATTN_SPLIT", None)
-        if split != "0":
-            env["CRCT_ATTN_SPLIT"] = split
-        r = subprocess.run([sys.executable, "-c", _ATTN_SPLIT_SCRIPT, pkg, path], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[split] = torch.load(path)
-    assert set(res["1"]) == set(res["0"]) and len(res["0"]) == 20
-    for key in res["0"]:
-        assert torch.equal(res["0"][key], res["1"][key]), key
-        assert float(res["0"][key].float().abs().max()) > 0
+    try:
+        for split in (1, 2, 0):
+            lib.crct_attention_force_split(split)
+            res[split] = _attn_split_case()
+    finally:
+        lib.crct_attention_force_split(0)
+    assert set(res[1]) == set(res[0]) and len(res[0]) == 20
+    for key in res[0]:
+        assert torch.equal(res[0][key], res[1][key]), key
+        assert torch.equal(res[0][key], res[2][key]), key
+        assert float(res[0][key].float().abs().max()) > 0

@@ -1,7 +1,9 @@
 // Developer microbenchmark for the GEMM kernels (not part of the product or the tests); links the in-tree library:
 //   hipcc -O2 -std=c++17 --offload-arch=gfx950 -Iinclude tools/gemm_lab.cpp -Lcqa-crct_amd/crct -lcrct_hip \
 //         -Wl,-rpath,'$ORIGIN/../cqa-crct_amd/crct' -o tools/gemm_lab.bin
-//   ./tools/gemm_lab.bin [iters] [shape | -1] [tile | -1] [first_tile]
+//   ./tools/gemm_lab.bin [iters] [shape | -1] [tile | -1] [first_tile] [cold] [max_split_k]
+// max_split_k > 1: every forward / data-gradient shape whose output is narrow (N <= 1024) is also timed K-partitioned
+// (CrctGemmArgs.split_k = 2 .. max_split_k) with the configurations built for it (4, 9, 12, 15).
 // Every configuration is checked against the register-staged kernel on the same operands (max |diff| printed).
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -22,6 +24,7 @@ int main(int argc, char** argv) {
   // cold > 0: every launch reads a different copy of B (weights) out of a pool larger than the 256 MiB Infinity Cache, and a
   // different copy of A out of 4 -- the state the GEMMs of a training step run in (weights come from HBM, once per step)
   const int cold = argc > 5 ? atoi(argv[5]) : 0;
+  const int max_sk = argc > 6 ? atoi(argv[6]) : 1;
   std::vector<Shape> shapes = {
       {"t.qkv fwd   ", 1600, 2304, 768, 0, 0},  {"t.ffn_up fwd", 1600, 3072, 768, 0, 0},  {"t.ffn_dn fwd", 1600, 768, 3072, 0, 0},
       {"t.out fwd   ", 1600, 768, 768, 0, 0},   {"v.qkv fwd   ", 2880, 3072, 1024, 0, 0}, {"v.ffn fwd   ", 2880, 1024, 1024, 0, 0},
@@ -43,6 +46,8 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < maxel; ++i) { float f = (rand() / (float)RAND_MAX - 0.5f); unsigned u; memcpy(&u, &f, 4); h[i] = u >> 16; }
   hipMemcpy(B, h.data(), maxel * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float* sk_ws; unsigned* sk_cnt;
+  hipMalloc(&sk_ws, (size_t)crct_gemm_splitk_ws_elems(6400, 1024, 4) * 4); hipMalloc(&sk_cnt, 65536); hipMemset(sk_cnt, 0, 65536);
   float* scales; hipMalloc(&scales, 8); { float h2[2] = {1.f, 1.f}; hipMemcpy(scales, h2, 8, hipMemcpyHostToDevice); }
   const size_t pool_bytes = cold ? (size_t)640 << 20 : 0;
   char* poolB = nullptr; char* poolA = nullptr;
@@ -71,10 +76,13 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     if (f32) { hr.resize(nout); hipMemcpy(hr.data(), Cref, nout * 4, hipMemcpyDeviceToHost); }
     else { hrb.resize(nout); hipMemcpy(hrb.data(), Cref, nout * 2, hipMemcpyDeviceToHost); }
-    for (int tile = first_tile; tile < 22; ++tile) {
+    for (int tile = first_tile; tile < 22; ++tile)
+     for (int sk = 1; sk <= max_sk; ++sk) {
       if (tile >= 16 && tile < 20) continue;
       if (only_tile >= 0 && tile != only_tile) continue;
+      if (sk > 1 && (s.ta || s.N > 1024 || !(tile == 4 || tile == 9 || tile == 12 || tile == 15) || s.K / 64 < 2 * sk)) continue;
       CrctGemmArgs g = make(tile, C);
+      if (sk > 1) { g.split_k = sk; g.splitk_ws = sk_ws; g.splitk_cnt = sk_cnt; }
       const bool f8 = tile >= 20;          // fp8 forward kernel (2 / 3 stages): same byte buffers read as e4m3, timing only
       if (f8) {
         if (s.ta || s.tb || s.K % 128) continue;
@@ -98,7 +106,7 @@ int main(int argc, char** argv) {
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       double us = ms * 1e3 / iters, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
-      printf("%s M=%5d N=%5d K=%5d tile=%2d  %8.2f us  %7.1f TF  maxdiff %.3g%s\n", s.name, s.M, s.N, s.K, tile, us, tf, maxd,
+      printf("%s M=%5d N=%5d K=%5d tile=%2d S=%d  %8.2f us  %7.1f TF  maxdiff %.3g%s\n", s.name, s.M, s.N, s.K, tile, sk, us, tf, maxd,
              (maxd > 0.26 && !f8) ? "  <-- MISMATCH" : "");
       fflush(stdout);
     }
