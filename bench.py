@@ -53,7 +53,9 @@ VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
               5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x128w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
               10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 15: "dma128x64w8s3", 16: "reg128x128", 17: "reg128x64",
-              18: "reg64x128", 19: "reg64x64", 20: "f8e4m3_128x64w8s2", 21: "f8e4m3_128x64w8s3"}
+              18: "reg64x128", 19: "reg64x64", 20: "f8e4m3_128x64w8s2", 21: "f8e4m3_128x64w8s3", 22: "dma160x128w4s2", 23: "dma160x128w4s3",
+              24: "dma160x96w4s3", 25: "dma160x96w4s2", 26: "dma96x64w4s3", 27: "dma96x64w4s4", 28: "dma160x64w4s3", 29: "dma64x96w4s4", 30: "dma160x128w4s3p", 31: "dma160x128w4s2p",
+              32: "dma128x128w4s3p", 33: "dma128x128w8s3p", 34: "dma256x128w8s3p", 35: "dma160x96w4s3p"}
 KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
@@ -82,6 +84,13 @@ def parse():
     ap.add_argument("--adamw-wgs", type=int, default=-1, help="workgroups per overlapped AdamW launch (0 = full width; default: the optimizer's)")
     ap.add_argument("--opt-early", type=int, default=0, help="1: AdamW of a segment starts when backward has finished the segment")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW as one launch on the main stream")
+    ap.add_argument("--grad-dtype", choices=("bf16", "fp32"), default="bf16", help="payload of the gradient all-reduce when N > 1 (bf16: 2 B per "
+                    "parameter, consumed by the fused AdamW as it lies; fp32: the reference's payload)")
+    ap.add_argument("--force-exchange", action="store_true", help="N = 1 only: run the bucketed exchange (per-segment callback, pack, all_reduce on a "
+                    "single-rank RCCL communicator, AdamW from the bf16 buffer) inside the timed step -- the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--emulate-ranks", type=int, default=1, help="test hook (N = 1): every step's batch is the CONCATENATION of the batches R "
+                    "ranks would draw (batch R x --batch): the run a data-parallel R-rank run must agree with (config.global_loss)")
+    ap.add_argument("--no-dropout", action="store_true", help="test hook: dropout probabilities 0 (run-to-run and rank-count independent losses)")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
                     "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
     ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
@@ -112,7 +121,7 @@ def gemm_profile(run_step, n_steps):
         return dict(kernel=label, launches_per_step=cnt / n_steps, gflop_per_launch=fl / cnt / 1e9, us_per_launch=ms * 1e3 / cnt,
                     ms_per_step=ms / n_steps, tflops=fl / (ms * 1e-3) / 1e12, frac_of_bf16_peak=fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, **extra)
 
-    for v in range(72):
+    for v in range(120):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue
@@ -245,18 +254,27 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    elif a.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
 
     from crct.model import VisualDialogEncoder
     from crct.optim import get_optimizer, WarmupLinearScheduleNonZero
     from crct.step_adapter import forward as step_forward
-    from crct.ddp import FlatGradDDP, all_reduce_stats
+    from crct.ddp import FlatGradDDP, AsyncStats
     from crct.input_pipeline import DevicePrefetcher
 
     cfg = CFG.vilbert_config(v_feature_size=a.feat)
+    if a.no_dropout:
+        cfg = CFG.vilbert_config(v_feature_size=a.feat, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                 v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
     params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0, fp8=a.dtype == "fp8")
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
+    if a.no_dropout:
+        core.cls_dropout = 0.0
     site_policy = []
     for item in filter(None, a.site_policy.split(",")):
         s, k, ph, c, sk = item.split(":")
@@ -272,8 +290,17 @@ def main():
     if a.opt_early and opt.overlap:
         opt.set_early(True)                          # ... or start per segment as soon as backward has finished it
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
-    ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb) if world > 1 else None   # noqa: F841 -- attaches itself to the model
+    exchange = world > 1 or a.force_exchange
+    ddp = None
+    if exchange:                                     # attaches itself to the model
+        ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32)
+        ddp.force_exchange = bool(a.force_exchange)
+    stats_red = AsyncStats(world, device=dev) if exchange else None
     host_pool = [S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i) for i in range(8)]
+    if a.emulate_ranks > 1:                          # what `emulate_ranks` data-parallel ranks see in one step, as ONE batch
+        assert world == 1
+        parts = [[S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + r + 97 * i) for r in range(a.emulate_ranks)] for i in range(8)]
+        host_pool = [{k: torch.cat([p[k] for p in ps], 0) for k in ps[0]} for ps in parts]
     dev_pool = [stage(b, dev) for b in host_pool]
     host_feed = host_pool
     if a.host_feat == "bf16":                        # the data loader ships bf16 features: half the H2D bytes of the step
@@ -300,14 +327,16 @@ def main():
     def run_step():
         batch = next(cur["feed"])
         loss = step_forward(model, batch, params)[0]
-        if world > 1:
-            # the reference's per-iteration stats exchange (train.py:181-189) on a COPY, as the reference builds a new tensor: the
-            # loss autograd returns is a view of the same output buffer and must not be modified in place before backward
-            all_reduce_stats(core.last_stats[8:17].clone(), world)
+        if stats_red is not None:
+            # the reference's per-iteration stats exchange (train.py:181-189): copied and all-reduced on a side stream while
+            # backward runs, collected at the end of the step (no collective between forward and backward on the main stream)
+            stats_red.launch(core.last_stats[8:17])
         loss.backward()
         opt.step()
         opt.zero_grad()
         sched.step()
+        if stats_red is not None:
+            cur["stats"] = stats_red.result()
         return loss
 
     def fence():
@@ -346,7 +375,9 @@ def main():
         with open(a.launch_log, "w") as f:
             json.dump(dict(steps=a.steps, source_hash=source_hash(), workload=[a.batch, a.vis, a.tokens, a.feat], launches=recs), f)
     final_loss = float(loss.detach())
-    qa_per_s = a.batch * world * a.steps / dt
+    # mean loss of the last timed step over the GLOBAL batch: the all-reduced stats when ranks exchange, else the local loss
+    global_loss = float(cur["stats"][0]) if (stats_red is not None and cur.get("stats") is not None) else final_loss
+    qa_per_s = a.batch * a.emulate_ranks * world * a.steps / dt
 
     h2d = None
     if a.input == "resident" and not a.no_h2d_leg:
@@ -365,7 +396,7 @@ def main():
         prefetcher = None
 
     comm = None
-    if world > 1:
+    if exchange:
         # evidence for the data-parallel exchange: the flat gradient buffer all-reduced on its own, after the
         # timed region (the step itself overlaps it with backward in >= bucket_mb pieces)
         used = int(max(hi for _, hi in core._engine.segments)) if core._engine is not None else core.flat_grads.numel()
@@ -379,7 +410,11 @@ def main():
         torch.cuda.synchronize()
         ar = (time.perf_counter() - t1) / 5
         comm = {"allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
-                "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9}
+                "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9,
+                "step_payload": {"dtype": a.grad_dtype, "bytes_per_step": used * (2 if a.grad_dtype == "bf16" else 4),
+                                 "buckets": len(ddp._buckets or ()), "bucket_mb_of_fp32_gradients": a.bucket_mb,
+                                 "collectives_issued_inside_the_backward_call": ddp.issued_inside_engine_call,
+                                 "single_rank_forced": bool(a.force_exchange and world == 1)}}
 
     # profiled steps run on EVERY rank (they contain the collectives of a normal step); only rank 0 reads the stamps
     rows, sites = gemm_profile(run_step, a.profile_steps) if a.profile_steps > 0 else ([], [])
@@ -391,7 +426,8 @@ def main():
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
                                       "; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.dtype == "fp8" else ""),
-                          "global_batch": a.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss, "input": a.input,
+                          "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                          "global_loss": global_loss, "input": a.input,
                           "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None,
                           "gemm_sites": sites, "gemm_variants": rows}}
         if flop_qa:

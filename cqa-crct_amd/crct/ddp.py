@@ -1,25 +1,35 @@
 """Data-parallel gradient exchange for the CRCT step: RCCL all-reduce of the flat gradient buffer,
-overlapped with backward.
+launched WHILE backward is being enqueued and overlapped with it.
 
 Reference behaviour being replaced: ``DistributedDataParallel(model, device_ids=[gpu],
 find_unused_parameters=True)`` (CRCT/train.py:138-143) = parameter broadcast from rank 0 at
-construction + bucketed gradient all-reduce (AVG) triggered by autograd hooks, with the 36
-never-used tensors tolerated.  Here:
+construction + bucketed gradient all-reduce (AVG) triggered by autograd hooks as backward produces
+the gradients, with the 36 never-used tensors tolerated; plus the per-iteration 9-float stats
+all-reduce (train.py:181-189).  Here:
 
-  * parameters live in one flat buffer ordered by first use, so each backward segment of the
-    native engine (heads, then the encoder schedule reversed, then the embeddings) completes one
-    CONTIGUOUS range of the flat gradient buffer;
-  * consecutive segments are merged into buckets of >= ``bucket_mb``.  Backward is ONE engine call;
-    the engine records events on its internal streams after every segment, and the ``all_reduce(SUM)``
-    of a bucket is queued on a communication stream behind the events of the bucket's last segment
-    -- the RCCL process group runs it on its own HIP stream, so the exchange of bucket k overlaps the
-    backward kernels of bucket k+1 (``event_mode=False`` falls back to one engine call per segment
-    with the collectives launched in between; measured 21 % slower per step on one MI355X);
-  * the 1/world averaging is folded into the loss-gradient seeds (no extra pass over 953 MB);
-  * tensors that never receive a gradient sit at the tail of the layout and are never sent.
+  * parameters live in one flat buffer ordered by first use, so each backward segment of the native
+    engine (heads, then the encoder schedule reversed, then the embeddings) completes one CONTIGUOUS
+    range of the flat gradient buffer; consecutive segments are merged into buckets of >= ``bucket_mb``;
+  * backward is ONE engine call.  The engine records four events (one per internal stream) after it
+    has enqueued a segment and then calls back into ``FlatGradDDP`` (``CrctStepCfg.seg_enqueued``) --
+    still inside the call, while the host goes on enqueuing the rest of backward -- and the bucket that
+    segment completes is launched right there: the communication stream waits for the four events,
+    packs the bucket to bf16 and issues ``all_reduce(SUM, async)``.  The first collective is in RCCL's
+    queue ~0.3 ms into backward, as with torch DDP's autograd hooks, not after the host has enqueued
+    all of it (round 2);
+  * payload: ``grad_dtype=torch.bfloat16`` (default) sends 2 bytes per parameter -- 477 MB per step
+    instead of 953 MB: at ~350 GB/s of bus bandwidth over xGMI that is ~2.4 ms, which
+    hides behind the 4 ms backward, where the fp32 payload (4.8 ms) cannot.  The fused AdamW consumes
+    the all-reduced bf16 bucket as it lies (``crct_adamw_step(g_bf16=...)``); ``materialize_grads=True``
+    also writes it back into the fp32 ``.grad`` views (for anything else that reads them: GradScaler's
+    inf check, clipping).  ``grad_dtype=torch.float32`` is the reference's payload;
+  * the 1/world averaging is folded into the loss-gradient seeds (no extra pass over the gradients);
+  * tensors that never receive a gradient sit at the tail of the layout and are never sent;
+  * the 9-float stats all-reduce runs asynchronously on the communication stream (``AsyncStats``) and
+    is waited for at the end of the step, not between forward and backward.
 
 xGMI note (MI355X: 7 links x ~153 GB/s per GPU, point-to-point): few large messages let RCCL use all
-links; the default 64 MB buckets give ~15 collectives per step.
+links; 64 MB buckets of fp32 gradients (32 MB of bf16 payload) give ~15 collectives per step.
 """
 import contextlib
 
@@ -49,7 +59,8 @@ def plan_buckets(segments, bucket_elems):
 def reduce_while_running(flat_grads, segments, buckets, run_segment, group=None):
     """Run backward segment by segment; launch the async all-reduce of every finished bucket.
     ``run_segment(i)`` enqueues segment i on the current stream.  Returns after all collectives
-    have been ordered before further work on the current stream (no host block on GPU)."""
+    have been ordered before further work on the current stream (no host block on GPU).
+    (The pre-event call pattern, kept as ``FlatGradDDP.event_mode = False``.)"""
     works, b = [], 0
     for i in range(len(segments)):
         run_segment(i)
@@ -61,35 +72,73 @@ def reduce_while_running(flat_grads, segments, buckets, run_segment, group=None)
         w.wait()
 
 
-def reduce_behind_events(flat_grads, buckets, seg_events, comm_stream, group=None):
-    """The whole backward has been enqueued in ONE engine call that recorded ``seg_events[4*i .. 4*i+3]`` after
-    segment i.  Launch every bucket's all-reduce on ``comm_stream`` behind the events of its last segment; the
-    exchange overlaps the backward kernels still running.  The current stream is ordered after all collectives."""
-    works = []
-    with torch.cuda.stream(comm_stream):
-        for last, lo, hi in buckets:
-            for ev in seg_events[4 * last:4 * last + 4]:
-                comm_stream.wait_event(ev)
-            works.append(dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
-    for w in works:
-        w.wait()
+class BucketExchange(object):
+    """The exchange of ONE backward pass: ``launch(b)`` is called (from the engine's callback) when the last segment of
+    bucket b has been enqueued; ``finish()`` after the engine call launches whatever is left and orders the consumer.
+
+    Device-agnostic: on CUDA tensors ``wait_events(b)`` makes the communication stream wait for the segment's events and
+    pack / unpack are HIP kernels; the CPU / gloo tests pass plain functions."""
+
+    def __init__(self, flat_grads, buckets, group, comm_buf=None, materialize=False, stream_ctx=None, wait_events=None,
+                 pack=None, unpack=None, after_bucket=None):
+        self.flat, self.buckets, self.group = flat_grads, buckets, group
+        self.comm_buf, self.materialize = comm_buf, materialize
+        self.stream_ctx = stream_ctx or contextlib.nullcontext
+        self.wait_events = wait_events or (lambda b: None)
+        self.pack = pack or (lambda src, dst: dst.copy_(src))
+        self.unpack = unpack or (lambda src, dst: dst.copy_(src))
+        self.after_bucket = after_bucket or (lambda b: None)
+        self.works = [None] * len(buckets)
+        self.issue_order = []
+
+    def launch(self, b):
+        if self.works[b] is not None:
+            return
+        _, lo, hi = self.buckets[b]
+        with self.stream_ctx():
+            self.wait_events(b)
+            if self.comm_buf is not None:
+                self.pack(self.flat[lo:hi], self.comm_buf[lo:hi])
+                payload = self.comm_buf[lo:hi]
+            else:
+                payload = self.flat[lo:hi]
+            w = dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works[b] = w
+            self.issue_order.append(b)
+            w.wait()              # RCCL: orders the communication stream behind the collective (no host block); gloo: blocks
+            if self.comm_buf is not None and self.materialize:
+                self.unpack(self.comm_buf[lo:hi], self.flat[lo:hi])
+            self.after_bucket(b)
+
+    def finish(self):
+        for b in range(len(self.buckets)):
+            self.launch(b)
 
 
 class FlatGradDDP(object):
     """Attach to a ``VisualDialogEncoder`` / ``CrctModel``: ``FlatGradDDP(model)`` after
     ``dist.init_process_group(backend='nccl', ...)`` (RCCL on ROCm)."""
 
-    def __init__(self, model, process_group=None, bucket_mb=64, broadcast=True):
+    def __init__(self, model, process_group=None, bucket_mb=64, broadcast=True, grad_dtype=torch.bfloat16, materialize_grads=False):
         from .optim import _crct_core
         self.core = _crct_core(model)
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        if grad_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("grad_dtype must be torch.bfloat16 or torch.float32")
+        self.grad_dtype = grad_dtype
+        self.materialize_grads = bool(materialize_grads)
         self._buckets = None
-        self._events = self._comm = None
+        self._events = self._comm = self._bucket_done = None
+        self._comm_buf = None
+        self._seg_bucket = None
         self.event_mode = True       # False: segment-by-segment engine calls with the collectives launched in between
         self.require_sync = True
-        self.force_exchange = False  # developer switch: run the bucketed exchange even on a single rank
+        self.force_exchange = False  # run the bucketed exchange even on a single rank (single-rank RCCL communicator: tests, probes)
+        self.last_exchange = None    # BucketExchange of the last synchronised backward pass
+        self.issued_inside_engine_call = 0      # collectives launched from the engine's callback during the last pass
+        self._grad_source_valid = False
         if broadcast:      # DDP constructor semantics: rank 0's parameters win (train.py:139)
             dist.broadcast(self.core.flat_params, 0, group=process_group)
             self.core._invalidate_shadow()
@@ -104,37 +153,141 @@ class FlatGradDDP(object):
         finally:
             self.require_sync = old
 
+    # ------------------------------------------------------------------ what the optimizer reads
+    def grad_source(self):
+        """The bf16 buffer (element offsets of the flat gradient buffer) that holds the all-reduced gradients of the last
+        synchronised backward pass, or None when the fp32 gradient buffer does (fp32 payload, or ``materialize_grads``)."""
+        if self._grad_source_valid and self._comm_buf is not None and not self.materialize_grads:
+            return self._comm_buf
+        return None
+
+    def wait_all(self, stream):
+        """Order ``stream`` behind every collective of the last pass (system scope: peers wrote these bytes)."""
+        if self._bucket_done and self.last_exchange is not None and self.core.flat_grads.is_cuda:
+            stream.wait_event(self._bucket_done[-1])       # the communication stream runs the buckets in order
+
+    def segment_waits(self):
+        """Per backward segment: callables ``w(stream)`` that order ``stream`` behind the collective of the bucket the
+        segment belongs to (the optimizer's early mode: AdamW of a bucket behind THAT bucket's all-reduce)."""
+        if not self._bucket_done or self._seg_bucket is None:
+            return None
+        return [[(lambda st, ev=self._bucket_done[b]: st.wait_event(ev))] for b in self._seg_bucket]
+
+    # ------------------------------------------------------------------ backward
+    def _plan(self, eng):
+        self._buckets = plan_buckets(eng.segments, self.bucket_elems)
+        self._seg_bucket, b = [], 0
+        for i in range(len(eng.segments)):
+            while b < len(self._buckets) - 1 and self._buckets[b][0] < i:
+                b += 1
+            self._seg_bucket.append(b)
+        self._last_of = {last: b for b, (last, _, _) in enumerate(self._buckets)}
+
     def backward(self, core, eng, tensors, step):
         step = dict(step)
         if self.world > 1:      # also on accumulation-only micro-steps: the final SUM then yields the average
             step["grad_scale"] = step.get("grad_scale", 1.0) / self.world      # folded into the head kernel's gradient seeds
+        self._grad_source_valid = False
         if not self.require_sync or (self.world == 1 and not self.force_exchange):
+            self.last_exchange = None
             eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
             return
         if self._buckets is None:
-            self._buckets = plan_buckets(eng.segments, self.bucket_elems)
-        if self.event_mode and core.flat_grads.is_cuda:
-            # one engine call (full overlap of its internal streams); the engine marks the end of every segment with
-            # events and the collectives queue up behind them on a communication stream
-            if self._events is None:
-                self._comm = torch.cuda.Stream(device=core.flat_grads.device)
-                # stock torch events (system-scope release at every record): what follows them is a collective whose peers
-                # read and write across GPUs -- unlike the engine-internal and optimizer events (crct/events.py), which order
-                # streams of one device only
-                self._events = [torch.cuda.Event() for _ in range(4 * len(eng.segments))]
-                for ev in self._events:          # torch creates the hipEvent lazily, at the first record
-                    ev.record()
-            step["seg_done_events"] = self._events
-            eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
-            reduce_behind_events(core.flat_grads, self._buckets, self._events, self._comm, self.group)
+            self._plan(eng)
+        if not (self.event_mode and core.flat_grads.is_cuda):
+            self.last_exchange = None
+            reduce_while_running(core.flat_grads, eng.segments, self._buckets,
+                                 lambda i: eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, i),
+                                 self.group)
             return
-        reduce_while_running(core.flat_grads, eng.segments, self._buckets,
-                             lambda i: eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, i),
-                             self.group)
+        from . import lib as L
+        lib = L.load()
+        dev = core.flat_grads.device
+        if self._events is None:
+            self._comm = torch.cuda.Stream(device=dev)
+            # stock torch events (system-scope release at every record): what follows them is a collective whose peers
+            # read and write across GPUs -- unlike the engine-internal and optimizer events (crct/events.py), which order
+            # streams of one device only
+            self._events = [torch.cuda.Event() for _ in range(4 * len(eng.segments))]
+            self._bucket_done = [torch.cuda.Event() for _ in self._buckets]
+            for ev in self._events + self._bucket_done:          # torch creates the hipEvent lazily, at the first record
+                ev.record()
+        if self.grad_dtype == torch.bfloat16 and self._comm_buf is None:
+            self._comm_buf = torch.zeros(core.flat_grads.numel(), dtype=torch.bfloat16, device=dev)
+        comm = self._comm
+
+        def wait_events(b):
+            last = self._buckets[b][0]
+            for ev in self._events[4 * last:4 * last + 4]:
+                comm.wait_event(ev)
+
+        def pack(src, dst):
+            L.check(lib.crct_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), comm.cuda_stream), "pack gradients")
+
+        def unpack(src, dst):
+            L.check(lib.crct_cast_bf16_f32(src.data_ptr(), dst.data_ptr(), src.numel(), comm.cuda_stream), "unpack gradients")
+
+        ex = BucketExchange(core.flat_grads, self._buckets, self.group,
+                            comm_buf=self._comm_buf if self.grad_dtype == torch.bfloat16 else None,
+                            materialize=self.materialize_grads, stream_ctx=lambda: torch.cuda.stream(comm), wait_events=wait_events,
+                            pack=pack, unpack=unpack, after_bucket=lambda b: self._bucket_done[b].record(comm))
+        self.last_exchange = ex
+
+        def on_segment(seg):          # engine callback: segment `seg` (and its four events) is enqueued
+            b = self._last_of.get(seg)
+            if b is not None:
+                ex.launch(b)
+
+        step["seg_done_events"] = self._events
+        step["seg_enqueued"] = on_segment
+        eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
+        self.issued_inside_engine_call = len(ex.issue_order)
+        ex.finish()                   # nothing left unless the engine ran without the callback
+        self._grad_source_valid = True
+        # consumers on the caller's stream (a plain optimizer, .grad readers) see the reduced gradients; the fused optimizer in
+        # overlap mode orders its own stream instead (wait_all / segment_waits) and this wait then costs nothing extra
+        torch.cuda.current_stream().wait_event(self._bucket_done[-1])
+
+
+class AsyncStats(object):
+    """train.py:181-189 without the host syncs and without stalling the step: the nine training statistics are copied and
+    all-reduced (SUM) on a side stream right after forward; ``result()`` orders the current stream behind the collective and
+    returns the tensor with the first six entries averaged.  One instance per training loop (the buffer is reused)."""
+
+    def __init__(self, world_size, group=None, device=None):
+        self.world, self.group = world_size, group
+        self.buf = torch.zeros(9, device=device)
+        self.cuda = self.buf.is_cuda
+        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.work = None
+
+    def launch(self, stats9):
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.buf.copy_(stats9)
+                self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.buf.copy_(stats9)
+            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def result(self):
+        if self.work is None:
+            return None
+        if self.cuda:
+            with torch.cuda.stream(self.stream):
+                self.work.wait()
+            torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            self.work.wait()
+        self.work = None
+        out = self.buf.clone()
+        out[:-3] = out[:-3] / self.world
+        return out
 
 
 def all_reduce_stats(stats9, world_size, group=None):
-    """train.py:181-189: SUM a 9-float stats tensor, first six entries averaged."""
+    """train.py:181-189: SUM a 9-float stats tensor, first six entries averaged (blocking form)."""
     dist.all_reduce(stats9, op=dist.ReduceOp.SUM, group=group)
     stats9[:-3] = stats9[:-3] / world_size
     return stats9

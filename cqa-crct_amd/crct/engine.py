@@ -110,6 +110,18 @@ class StepEngine(object):
             arr = (C.c_void_p * len(done))(*[ev.cuda_event for ev in done])
             step["_seg_done_keepalive"] = arr
             c.seg_done_events = C.cast(arr, C.c_void_p)
+        cb = step.get("seg_enqueued")
+        if cb is not None:          # python callable(seg): wrapped once per call; exceptions are kept and re-raised after the engine call
+            err = step.setdefault("_seg_enqueued_errors", [])
+
+            def tramp(seg, _user, cb=cb, err=err):
+                try:
+                    cb(int(seg))
+                except BaseException as ex:       # noqa: BLE001 -- must not unwind through the C frame
+                    err.append(ex)
+            fn = L.SEG_ENQUEUED_FN(tramp)
+            step["_seg_enqueued_keepalive"] = fn
+            c.seg_enqueued = C.cast(fn, C.c_void_p)
         return c
 
     def set_site_policy(self, site, kind, cfg=-1, split_k=0, phase=-1):
@@ -185,6 +197,9 @@ class StepEngine(object):
                                               self.workspace.data_ptr(), g32.data_ptr(), self.logits.data_ptr(),
                                               self.reg.data_ptr(), self.stats.data_ptr(), int(seg), L.current_stream()),
                 "engine_backward")
+        errs = step.get("_seg_enqueued_errors")
+        if errs:
+            raise errs[0]
 
     def tap(self, name, B, T, V):
         n_max = B * max(T * self.cfg.hidden_size, V * self.cfg.v_hidden_size)

@@ -84,7 +84,10 @@ class StepCfg(C.Structure):
                 ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("g_loss_dev", vp),
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
-                ("wgrad_overwrite", c_i32)]
+                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("wgrad_overwrite", c_i32)]
+
+
+SEG_ENQUEUED_FN = C.CFUNCTYPE(None, C.c_int, vp)      # void (*seg_enqueued)(int seg, void* user)
 
 
 # name -> (restype, argtypes); every symbol include/crct_hip.h declares
@@ -123,6 +126,7 @@ PROTOTYPES = {
     "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
+    "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
     "crct_attention_force_valu": (None, [C.c_int]),
@@ -134,7 +138,7 @@ PROTOTYPES = {
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),
     "crct_eval_select": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, vp, vp, vp, vp, vp, vp]),
     "crct_adamw_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
-    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "crct_adamw_step": (C.c_int, [vp] * 11 + [c_i64, c_f32, c_f32, c_f32, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "crct_adamw_advance": (C.c_int, [vp, vp, vp]),
     "crct_engine_create": (vp, [C.POINTER(ModelDims), C.c_char_p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crct_engine_destroy": (None, [vp]),

@@ -81,6 +81,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._last = None
         self._step_dev, self._amp_arg, self._amp_keep = None, None, None
         self._fp8_keep = None
+        self._g16 = None                     # bf16 gradient source of the running update (data-parallel bf16 exchange), else None
         # overlap mode: the update runs as one launch per engine backward-segment on its own stream, in first-use
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
@@ -137,7 +138,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                          self._lr_dev.data_ptr(), self._wd_dev.data_ptr(), self._blk_seg.data_ptr() + 4 * b0,
                                          self._blk_off.data_ptr() + 8 * b0, b1 - b0, g0["betas"][0], g0["betas"][1], g0["eps"],
                                          max(self._step, 1), L.ptr(inv_scale), self._amp_arg, self._fp8_arg(), int(max_workgroups),
-                                         int(self.fuse_zero_grad), stream), "adamw_step")
+                                         int(self.fuse_zero_grad), L.ptr(self._g16), stream), "adamw_step")
 
     # ---- torch.amp.GradScaler (train.py:157,208-212).  ``scaler.step(optimizer)`` sees ``_step_supports_amp_scaling`` and
     # hands over ``optimizer.grad_scale`` / ``optimizer.found_inf`` (device scalars) instead of unscaling 524 gradient views
@@ -251,9 +252,19 @@ class FusedAdamW(torch.optim.Optimizer):
         amp = self._amp_begin()
         if not amp:
             self._step += 1
+        # data-parallel bf16 exchange: the all-reduced gradients live in the communication buffer (crct/ddp.py), not in .grad
+        ddp = getattr(core, "_ddp", None)
+        self._g16 = ddp.grad_source() if ddp is not None else None
+        if self._g16 is not None and (amp or inv_scale is not None):
+            raise RuntimeError("GradScaler / unscaling reads the fp32 .grad views: construct FlatGradDDP(..., materialize_grads=True) "
+                               "(or grad_dtype=torch.float32) when training with a GradScaler")
         if self.overlap and not amp and (self._seg_blocks is not None or self._plan_overlap()):
             cur = torch.cuda.current_stream()
-            done = core.take_segment_done_events() if (self.early and inv_scale is None) else None
+            done = None
+            if self.early and inv_scale is None:
+                done = core.take_segment_done_events()
+                if done is None and ddp is not None and ddp.last_exchange is not None:
+                    done = ddp.segment_waits()       # AdamW of a bucket behind THAT bucket's all-reduce, not behind all of them
             n = len(self._seg_blocks)
             if done is None:
                 self._upload_hyper()

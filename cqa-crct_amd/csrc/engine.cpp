@@ -128,7 +128,7 @@ struct crct_engine {
   size_t km_t = 0, km_v = 0;
   // per-site launch policy of the forward / data-gradient GEMMs (crct_engine_set_site_policy): [site][kind][phase]
   struct SitePolicy { int cfg = -1, split_k = 0; };
-  SitePolicy policy[CRCT_SITE_COUNT][2][2];
+  SitePolicy policy[CRCT_SITE_COUNT][3][2];      // kind 2 (weight gradient): cfg only -- the layer's grouped launch takes the first problem's
   size_t sk_ws[2] = {0, 0}, sk_cnt[2] = {0, 0};   // split-K slab space / ticket words per data stream [text, visual]
   size_t sk_ws_elems[2] = {0, 0};
   int sk_tickets = 0;
@@ -381,6 +381,7 @@ struct Run {
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = x; g.C = G(l.w); g.lda = lddy; g.ldb = ldx; g.ldc = l.in; g.M = l.out; g.N = l.in; g.K = M;
     g.ta = 1; g.tb = 1; g.c_is_f32 = 1; g.accumulate = 1; g.tile = -1; g.alpha = 1.0f; g.site = l.site;
+    if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][2][phase].cfg >= 0) g.tile = e->policy[l.site][2][phase].cfg;
     if (c->wgrad_overwrite && e->wgrad_owned.count(l.w)) {
       if (++e->wgrad_pass[l.w] > 1) { rc = 1; crct_set_error("engine_backward: weight gradient at offset %lld is produced twice in one pass but is listed as owned", (long long)l.w); return; }
       g.accumulate = 0;               // the only producer of this gradient: write it, whatever the buffer held
@@ -1121,7 +1122,7 @@ int reset_tickets(crct_engine* e, void* ws, hipStream_t s) {
   bool any = false;
   for (int a = 1; a < CRCT_SITE_COUNT && !any; ++a)
     for (int k = 0; k < 2; ++k)
-      for (int ph = 0; ph < 2; ++ph) any = any || e->policy[a][k][ph].split_k > 1;
+      for (int ph = 0; ph < 2; ++ph) any = any || e->policy[a][k][ph].split_k > 1;      // weight gradients are never split
   if (!any) return 0;
   CRCT_CHECK_HIP(hipMemsetAsync((char*)ws + e->sk_cnt[0], 0, (size_t)2 * e->sk_tickets * 4, s));
   return 0;
@@ -1281,6 +1282,9 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
           hipEvent_t ev = (hipEvent_t)cfg->seg_done_events[4 * sg + k];
           if (ev && hipEventRecord(ev, ss[k]) != hipSuccess) { crct_set_error("engine_backward: cannot record a segment event"); Rt.rc = 1; }
         }
+      // the data-parallel caller launches the bucket this segment completes NOW, while the rest of backward is still being enqueued
+      if (cfg->seg_enqueued && !Rt.rc)
+        for (int sg = ev_from; sg <= sgi; ++sg) cfg->seg_enqueued(sg, cfg->seg_enqueued_user);
     }
     ev_from = sgi + 1;
   }
@@ -1368,9 +1372,9 @@ extern "C" int crct_event_synchronize(void* ev) {
 }
 
 extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind, int phase, int cfg, int split_k) {
-  CRCT_REQUIRE(e && site > 0 && site < CRCT_SITE_COUNT && (kind == CRCT_KIND_FWD || kind == CRCT_KIND_DGRAD) && phase <= 1,
+  CRCT_REQUIRE(e && site > 0 && site < CRCT_SITE_COUNT && kind >= CRCT_KIND_FWD && kind <= CRCT_KIND_WGRAD && phase <= 1,
                "set_site_policy: bad site / kind / phase (%d, %d, %d)", site, kind, phase);
-  CRCT_REQUIRE(cfg >= -1 && cfg <= 15 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
+  CRCT_REQUIRE(cfg >= -1 && cfg <= 35 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
   for (int ph = 0; ph < 2; ++ph)
     if (phase < 0 || phase == ph) { e->policy[site][kind][ph].cfg = cfg; e->policy[site][kind][ph].split_k = split_k; }
   return 0;

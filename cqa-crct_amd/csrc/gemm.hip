@@ -49,13 +49,6 @@ constexpr int BK = 64;
 #ifndef CRCT_GEMM_NT_F32
 #define CRCT_GEMM_NT_F32 1
 #endif
-#ifndef CRCT_GEMM_PIPE_MODE
-// 1: register-pipelined main loop (fragments of the next K tile read under the MFMAs of the current one).  Measured, not
-// the default: stand-alone it is within +-3 % of mode 0 (0 to 20 % slower at K = 768), and in the step it costs 0.8 ms
-// (8.9 -> 9.7 ms): 110 instead of 74 VGPRs per lane means two instead of three 8-wave workgroups per CU, and the
-// co-residency with the other streams' kernels is worth more than the overlap inside one workgroup.
-#define CRCT_GEMM_PIPE_MODE 0
-#endif
 
 // byte offset of 16-byte chunk `ch` (0..7) of row r in the [R][64] bf16 image (128-B rows)
 __device__ __forceinline__ int off_rowmajor(int r, int ch) { return r * 128 + ((ch ^ (r & 7)) << 4); }
@@ -638,7 +631,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Block tile (32*TM) x (32*TN), WM x WN waves (4 or 8), each wave owning a (BM/WM) x (BN/WN) sub-tile.
 // SK: K-partitioned variant (CrctGemmArgs.split_k): workgroup (tile, slice) contracts K tiles [kt0, kt0 + nk) and the last of
 // a tile's slices to arrive reduces the slabs (see splitk_reduce).
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, bool SK = false>
+// PM = 1: register-pipelined main loop (the fragments of K tile k + 1 are read from LDS while the MFMAs of tile k run): what the
+// 128 x 64 tiles cannot use -- they sit on the ~70 GB/s per CU L2 -> LDS fill rate either way -- but the larger tiles need: with
+// half the fill bytes per FLOP their time is the serial "read fragments, then multiply" of the plain loop.
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, bool SK = false, int PM = 0>
 __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg,
                                                const int slice = 0, const int tile_lin = 0) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
@@ -750,10 +746,9 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
         }
     }
   };
-#if CRCT_GEMM_PIPE_MODE == 1
+  if constexpr (PM == 1) {
   // register-pipelined: while the MFMAs of tile kt run from one register set, the reads of tile kt+1 fill the other;
   // tile t lives in stage t % NS and its stage goes back to the DMA one barrier after its reads have completed
-  {
     bf8_t fmA[2][WTM], fnA[2][WTN], fmB[2][WTM], fnB[2][WTN];
     auto step = [&](int kt, int stg, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN], bf8_t (&fm_n)[2][WTM], bf8_t (&fn_n)[2][WTN]) {
       frag_async_wait<0>();                            // tile kt is in registers
@@ -782,8 +777,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
         stg = stg + 1 == NS ? 0 : stg + 1;
       }
     }
-  }
-#else
+  } else {
   int st = 0, st_next = NS - 1;      // stage holding tile kt; stage the next prefetch goes to
   for (int kt = 0; kt < nk; ++kt) {
     wait_tile(kt);
@@ -803,7 +797,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
   }
-#endif
+  }
   if (lab_bits(dbg) & 1) {      // ablation (lab build only): keep the accumulators alive, skip the epilogue
 #pragma unroll
     for (int a = 0; a < WTN; ++a)
@@ -836,11 +830,11 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
   gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int PM = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmArgs g, const TileMap tmap) {
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
-  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tile_m, tile_n, tmap.dbg);
+  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tile_m, tile_n, tmap.dbg);
 }
 
 // K-partitioned launch: block j of XCD x is slice j % S of the (j / S)-th tile of that XCD's rectangle -- a tile's slices share
@@ -1079,7 +1073,7 @@ hipError_t launch_splitk(const CrctGemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int TM, int TN, int WM, int WN, int NS>
+template <int TM, int TN, int WM, int WN, int NS, int PM = 0>
 hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
@@ -1088,7 +1082,7 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_PIPE(TA_, TB_)                                                                                         \
   do {                                                                                                                     \
-    auto kern = gemm_pipe_kernel<TM, TN, WM, WN, TA_, TB_, NS>;                                                            \
+    auto kern = gemm_pipe_kernel<TM, TN, WM, WN, TA_, TB_, NS, PM>;                                                        \
     static bool attr_set = false;                                                                                          \
     if (lds > 64 * 1024 && !attr_set) {                                                                                    \
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
@@ -1182,7 +1176,7 @@ struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
-  static constexpr int NV = 72;        // (16 LDS-DMA configurations + 4 register-staged + spare) x {fwd, dgrad, wgrad}
+  static constexpr int NV = 120;       // (30 LDS-DMA / fp8 / register-staged configuration ids + spare) x {fwd, dgrad, wgrad}
   double flops[NV] = {0}; long count[NV] = {0};
   bool log_on = false;
   std::vector<CrctLaunchRec> log;
@@ -1303,7 +1297,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   const bool pipe = g.fp8 || (pipe_ok(g) && !g_force_generic);
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 15) t = 12;
+  if (t > 15 && !(t >= 22 && t <= 35 && pipe && !g.fp8)) t = 12;
   // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21)
   if (g.fp8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
@@ -1340,6 +1334,22 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 13: e = launch_pipe<4, 2, 4, 2, 4>(g, s); break;    // 128x64, 8 waves (4x2), 4 stages: long K, one block per CU
       case 14: e = launch_pipe<4, 2, 4, 2, 6>(g, s); break;    // 128x64, 8 waves (4x2), 6 stages
       case 15: e = launch_pipe<4, 2, 4, 2, 3>(g, s); break;    // 128x64, 8 waves (4x2), 3 stages
+      // 160-row tiles: M = 1600 (text) and 2880 (visual) are exact multiples, 4 waves with 80 x (BN / 2) wave tiles
+      case 22: e = launch_pipe<5, 4, 2, 2, 2>(g, s); break;    // 160x128, 4 waves, 2 stages (72 KB: two per CU)
+      case 23: e = launch_pipe<5, 4, 2, 2, 3>(g, s); break;    // 160x128, 4 waves, 3 stages
+      case 24: e = launch_pipe<5, 3, 2, 2, 3>(g, s); break;    // 160x96, 4 waves, 3 stages
+      case 25: e = launch_pipe<5, 3, 2, 2, 2>(g, s); break;    // 160x96, 4 waves, 2 stages
+      case 26: e = launch_pipe<3, 2, 2, 2, 3>(g, s); break;    // 96x64, 4 waves, 3 stages
+      case 27: e = launch_pipe<3, 2, 2, 2, 4>(g, s); break;    // 96x64, 4 waves, 4 stages
+      case 28: e = launch_pipe<5, 2, 2, 2, 3>(g, s); break;    // 160x64, 4 waves, 3 stages
+      case 29: e = launch_pipe<2, 3, 2, 2, 4>(g, s); break;    // 64x96, 4 waves, 4 stages
+      // register-pipelined main loop (PM = 1), one workgroup per CU
+      case 30: e = launch_pipe<5, 4, 2, 2, 3, 1>(g, s); break; // 160x128, 4 waves, 3 stages
+      case 31: e = launch_pipe<5, 4, 2, 2, 2, 1>(g, s); break; // 160x128, 4 waves, 2 stages
+      case 32: e = launch_pipe<4, 4, 2, 2, 3, 1>(g, s); break; // 128x128, 4 waves, 3 stages
+      case 33: e = launch_pipe<4, 4, 2, 4, 3, 1>(g, s); break; // 128x128, 8 waves, 3 stages
+      case 34: e = launch_pipe<8, 4, 4, 2, 3, 1>(g, s); break; // 256x128, 8 waves, 3 stages
+      case 35: e = launch_pipe<5, 3, 2, 2, 3, 1>(g, s); break; // 160x96, 4 waves, 3 stages
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
   } else {
@@ -1372,7 +1382,9 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
     }
     return hipSuccess;
   }
-  const int cfg = gs[0].ta ? 4 : 9;    // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages
+  // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages; CrctGemmArgs.tile of the first
+  // problem may pick the other one (crct_engine_set_site_policy: A/B runs)
+  const int cfg = (gs[0].tile == 4 || gs[0].tile == 9) ? gs[0].tile : (gs[0].ta ? 4 : 9);
   prof_begin(cfg * 3 + kind_of(gs[0]), gs, n);
   const hipError_t e = cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s);
   g_time_start = g_time_stop = nullptr;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const int32_t* __restrict__ blk_seg, const int64_t* __restrict__ blk_off,
                                                     float beta1, float beta2, float eps, float inv_bc1, float inv_sqrt_bc2,
                                                     const float* __restrict__ inv_scale_dev, const CrctAmpState amp, const CrctFp8Shadow f8,
-                                                    int n_blk, int zero_g) {
+                                                    int n_blk, int zero_g, const bf16_t* __restrict__ g16) {
  // loss scaling (torch.amp.GradScaler): a step whose gradients held an inf / nan is skipped as a whole, the scale divides
  // the gradients, and the step count behind the bias corrections is the device counter that only advances on real steps
  if (amp.found_inf && amp.found_inf[0] != 0.f) return;
@@ -54,11 +54,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     if (i + 4 <= n) {
 #if CRCT_ADAMW_NT      // streamed once per step: non-temporal, so the 7 GB do not evict the forward's operands from L2 / MALL
       const f4_t pv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p + e));
-      const f4_t gv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g + e));
+      f4_t gv;
+      if (g16) {      // the exchanged bf16 gradient as it lies in the communication buffer (8 bytes per 4 elements)
+        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+        const u2_t raw = __builtin_nontemporal_load(reinterpret_cast<const u2_t*>(g16 + e));
+        gv = f4_t{bf2f((bf16_t)(raw[0] & 0xffff)), bf2f((bf16_t)(raw[0] >> 16)), bf2f((bf16_t)(raw[1] & 0xffff)), bf2f((bf16_t)(raw[1] >> 16))};
+      } else {
+        gv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(g + e));
+      }
       const f4_t mv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(m + e));
       const f4_t vv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(v + e));
 #else
-      const f4_t pv = *reinterpret_cast<const f4_t*>(p + e), gv = *reinterpret_cast<const f4_t*>(g + e);
+      const f4_t pv = *reinterpret_cast<const f4_t*>(p + e);
+      f4_t gv = g16 ? f4_t{bf2f(g16[e]), bf2f(g16[e + 1]), bf2f(g16[e + 2]), bf2f(g16[e + 3])} : *reinterpret_cast<const f4_t*>(g + e);
       const f4_t mv = *reinterpret_cast<const f4_t*>(m + e), vv = *reinterpret_cast<const f4_t*>(v + e);
 #endif
       float pa[4] = {pv[0], pv[1], pv[2], pv[3]}, ga[4] = {gv[0] * gsc, gv[1] * gsc, gv[2] * gsc, gv[3] * gsc};
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       for (int64_t k = i; k < n; ++k) {
         const int64_t q = base + k;
         float pa = p[q] * decay;
-        const float ga = g[q] * gsc;
+        const float ga = (g16 ? bf2f(g16[q]) : g[q]) * gsc;
         const float ma = beta1 * m[q] + (1.0f - beta1) * ga;
         const float va = beta2 * v[q] + (1.0f - beta2) * ga * ga;
         pa -= step_size * ma / (sqrtf(va) * inv_sqrt_bc2 + eps);
@@ -155,7 +163,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
                                const int64_t* seg_len, const float* seg_lr, const float* seg_wd, const int32_t* blk_seg,
                                const int64_t* blk_off, int64_t n_blk, float beta1, float beta2, float eps, int step,
                                const float* inv_scale_dev, const CrctAmpState* amp_state, const CrctFp8Shadow* fp8_shadow,
-                               int max_workgroups, int zero_grads, crct_stream_t stream) {
+                               int max_workgroups, int zero_grads, const void* g_bf16, crct_stream_t stream) {
   CRCT_REQUIRE(step >= 1, "adamw: step must be >= 1 (got %d)", step);
   CrctAmpState amp = {nullptr, nullptr, nullptr};
   if (amp_state) amp = *amp_state;
@@ -170,7 +178,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      seg_off, seg_len, seg_lr, seg_wd, blk_seg, blk_off, beta1, beta2, eps, (float)(1.0 / bc1),
-                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, f8, (int)n_blk, zero_grads);
+                     (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, f8, (int)n_blk, zero_grads, (const bf16_t*)g_bf16);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

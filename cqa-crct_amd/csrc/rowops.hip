@@ -761,6 +761,22 @@ __global__ void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
     for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
 }
 
+__global__ void uncast_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (; i + 8 <= n; i += stride) {
+    const uint4 u = *reinterpret_cast<const uint4*>(x + i);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); f[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+    *reinterpret_cast<float4*>(y + i) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(y + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  if (i < n && i + 8 > n)
+    for (long j = i; j < n; ++j) y[j] = bf2f(x[j]);
+}
+
 // ------------------------------------------------------------------------------ text embedding
 // first question/answer token of a batch row (segments -1 or 1), T if none: vilbert.py:327-332
 __device__ __forceinline__ int first_qa_index(const int64_t* segs_row, int T, int lane) {
@@ -1275,6 +1291,17 @@ int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream)
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream) {
+  if (n <= 0) return 0;
+  CRCT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cast_bf16_f32: 16-byte aligned buffers");
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(uncast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, (long)n);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

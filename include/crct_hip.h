@@ -227,6 +227,8 @@ int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_strea
 
 /* fp32 -> bf16 copy (weight shadow refresh). */
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
+/* bf16 -> fp32 copy (a gradient bucket exchanged as bf16 put back into the fp32 gradient buffer for callers that read .grad). */
+int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scaled-dot-product attention over short sequences, one workgroup per (batch, head), everything
@@ -383,7 +385,10 @@ int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
                     const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
                     const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk,
                     float beta1, float beta2, float eps, int step, const float* inv_scale_dev, const CrctAmpState* amp,
-                    const CrctFp8Shadow* fp8_shadow, int max_workgroups, int zero_grads, crct_stream_t stream);
+                    const CrctFp8Shadow* fp8_shadow, int max_workgroups, int zero_grads, const void* g_bf16, crct_stream_t stream);
+/* g_bf16 (may be NULL): bf16 gradient buffer with the element offsets of g -- the data-parallel exchange's payload
+ * (crct/ddp.py: each bucket is packed to bf16, all-reduced, and consumed here as it lies: 2 B instead of 4 B per parameter on
+ * the wire and in this kernel's reads).  When set, every gradient element is read from it; g is only written (zero_grads). */
 
 /* ---------------------------------------------------------------------------------------------
  * Step engine: the whole forward + loss + backward of one batch as one native call
@@ -451,6 +456,13 @@ typedef struct CrctStepCfg {
    *   fp8_act_amax    device fp32 [same]: max |activation| seen by this pass, for the caller's crct_fp8_update_scales */
   int32_t fp8;
   const void* params_fp8; const float* fp8_w_scale; const float* fp8_act_scale; float* fp8_act_amax;
+  /* Host callback of crct_engine_backward(seg < 0): invoked on the calling thread, INSIDE the call, right after the four
+   * seg_done_events of segment s have been recorded -- i.e. while the host is still enqueuing the rest of backward.  A
+   * data-parallel caller launches the gradient all-reduce of the bucket that segment s completes from here (behind those
+   * events, on its own stream), the way torch DDP's autograd hooks do (train.py:138-143): the first collective is in RCCL's
+   * queue ~0.3 ms into backward instead of after the host has enqueued all of it.  Must not call back into the engine. */
+  void (*seg_enqueued)(int seg, void* user);
+  void* seg_enqueued_user;
   int32_t wgrad_overwrite;   /* backward only.  != 0: the caller guarantees that nothing has been accumulated into the weight
                                 gradients listed by crct_engine_wgrad_owned since they were last consumed; those gradients are
                                 then WRITTEN instead of added to (bit-identical to adding into zeros) and need not be zeroed --
@@ -481,8 +493,9 @@ int crct_engine_set_pairing(crct_engine_t*, int on);
 /* Per-site launch policy of the forward / data-gradient GEMMs (A/B switch of the developer tools and the tests; the defaults
  * are the measured choices).  phase 0 = the text-only part of the schedule (layers t0 .. before the first
  * co-attention layer: nothing else on the chip's data path), phase 1 = beside the visual stream; phase < 0 sets both.
- * cfg = kernel configuration id (-1 = the shape-class default), split_k = K slices (0 / 1 = off).  Every choice computes the
- * same function; split_k changes the summation order over K (deterministically). */
+ * cfg = kernel configuration id (-1 = the shape-class default), split_k = K slices (0 / 1 = off).  kind = CRCT_KIND_WGRAD: cfg
+ * only (4 / 9: the layer's grouped weight-gradient launch takes the configuration of its first problem).  Every choice computes
+ * the same function; split_k changes the summation order over K (deterministically). */
 int crct_engine_set_site_policy(crct_engine_t*, int site, int kind, int phase, int cfg, int split_k);
 /* The weight gradients (flat offsets / element counts into grads_f32, sorted by offset) that exactly one weight-gradient
  * GEMM per backward pass produces and nothing else adds to: every Linear weight of the encoder layers, the image embedding,

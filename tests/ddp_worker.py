@@ -51,7 +51,8 @@ def main():
     # rank 1 starts from DIFFERENT weights: the constructor's broadcast from rank 0 (train.py:139 semantics) must fix that
     S.seeded_fill_(model.state_dict(), base_seed=7 if rank == 0 else 8)
     core._invalidate_shadow()
-    ddp = FlatGradDDP(model, bucket_mb=bucket_mb)
+    # the reference's payload first (fp32: the numbers of steps (1) and (2) are compared with the oracle at the fp32 bounds)
+    ddp = FlatGradDDP(model, bucket_mb=bucket_mb, grad_dtype=torch.float32)
     assert ddp.event_mode
     mine = halves(batch, rank, world)
     out = {}
@@ -64,6 +65,8 @@ def main():
     out["g_sync"] = core.flat_grads.detach().cpu().numpy().copy()
     out["loss"] = np.array([float(res[0])])
     out["n_buckets"] = np.array([len(ddp._buckets)])
+    # every bucket's collective was launched from the engine's per-segment callback, i.e. before the backward call returned
+    out["issued_inside_call"] = np.array([ddp.issued_inside_engine_call])
     st = core.last_stats[8:17].clone()
     all_reduce_stats(st, world)
     out["stats9"] = st.cpu().numpy()
@@ -79,6 +82,39 @@ def main():
     torch.cuda.synchronize()
     out["g_accum"] = core.flat_grads.detach().cpu().numpy().copy()
     out["params_after_broadcast"] = core.flat_params.detach().cpu().numpy().copy()[:4096]
+
+    # (3) the bf16 payload (default): the all-reduced gradient lives in the communication buffer; .grad keeps the local fp32 one
+    from crct.optim import get_optimizer
+    from crct.ddp import AsyncStats
+    ddp16 = FlatGradDDP(model, bucket_mb=bucket_mb, broadcast=False)
+    assert ddp16.grad_dtype == torch.bfloat16 and core._ddp is ddp16
+    core.zero_flat_grads()
+    red = AsyncStats(world, device=dev)
+    res = step_forward(model, mine, params)
+    red.launch(core.last_stats[8:17])
+    res[0].backward()
+    src = ddp16.grad_source()
+    assert src is not None and src.dtype == torch.bfloat16
+    torch.cuda.synchronize()
+    out["g_bf16"] = src.float().cpu().numpy().copy()
+    out["g_bf16_local_fp32"] = core.flat_grads.detach().cpu().numpy().copy()
+    out["issued_inside_call_bf16"] = np.array([ddp16.issued_inside_engine_call])
+    out["stats9_async"] = red.result().cpu().numpy()
+    # ... and the fused AdamW consumes it as it lies: one step, both ranks must end on identical parameters
+    opt = get_optimizer(params, model)
+    opt.overlap = case != "tiny"
+    opt.step()
+    opt.zero_grad()
+    opt.synchronize()
+    torch.cuda.synchronize()
+    out["params_after_step"] = core.flat_params.detach().cpu().numpy().copy()
+    # (4) materialize_grads: the all-reduced bf16 bucket is written back into the fp32 .grad views
+    ddp16.materialize_grads = True
+    core.zero_flat_grads()
+    step_forward(model, mine, params)[0].backward()
+    assert ddp16.grad_source() is None
+    torch.cuda.synchronize()
+    out["g_materialized"] = core.flat_grads.detach().cpu().numpy().copy()
     np.savez(os.path.join(outdir, "%s_rank%d.npz" % (case, rank)), **out)
     dist.barrier()
     dist.destroy_process_group()

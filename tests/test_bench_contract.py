@@ -63,20 +63,37 @@ def test_two_rank_bench_runs_end_to_end():
     all-reduce on the buffer the loss is a view of -- every N > 1 run died in backward; this test is the guard.)"""
     import subprocess
     import sys
-    env = dict(os.environ, CRCT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env = dict({k: v for k, v in os.environ.items() if not k.startswith("CRCT_")},        # bench.py refuses stray CRCT_* switches
+               CRCT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     import socket
     with socket.socket() as sock:                       # a free rendezvous port
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--profile-steps", "0", "--no-h2d-leg"]
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    common = ["--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--profile-steps", "0", "--no-h2d-leg", "--no-dropout"]
+    losses = {}
+    for dtype in ("fp32", "bf16"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grad-dtype", dtype] + common
+        res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        rows = [r for r in res.stdout.strip().split("\n") if r.startswith("{")]
+        assert len(rows) == 1, rows
+        line = json.loads(rows[0])
+        assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+        assert line["config"]["global_batch"] == 2 * 16 and line["value"] > 0
+        pay = line["config"]["gradient_allreduce"]["step_payload"]
+        assert pay["dtype"] == dtype and pay["collectives_issued_inside_the_backward_call"] == pay["buckets"] >= 8
+        losses[dtype] = line["config"]["global_loss"]
+    # the same four optimizer steps by ONE rank on the concatenation of the two ranks' batches: the data-parallel run must land on
+    # the same mean loss (1/world folded into the gradient seeds, SUM all-reduce, every rank applying the same update)
+    env1 = {k: v for k, v in env.items() if k != "CRCT_BENCH_SHARE_GPU"}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--emulate-ranks", "2"] + common, cwd=ROOT, env=env1,
+                         capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    rows = [r for r in res.stdout.strip().split("\n") if r.startswith("{")]
-    assert len(rows) == 1, rows
-    line = json.loads(rows[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["global_batch"] == 2 * 80 and line["value"] > 0
+    one = json.loads([r for r in res.stdout.strip().split("\n") if r.startswith("{")][0])
+    assert one["config"]["global_batch"] == 32
+    ref = one["config"]["global_loss"]
+    assert abs(losses["fp32"] - ref) <= 2e-3 * abs(ref), (losses, ref)       # different batch split -> other summation orders / bf16 roundings
+    assert abs(losses["bf16"] - ref) <= 5e-3 * abs(ref), (losses, ref)

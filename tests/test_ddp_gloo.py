@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 from crct import config as CFG
 from crct import layout as LY
-from crct.ddp import plan_buckets, reduce_while_running, all_reduce_stats
+from crct.ddp import plan_buckets, reduce_while_running, all_reduce_stats, BucketExchange, AsyncStats
 
 
 def _segments(cfg, params):
@@ -73,6 +73,38 @@ def _worker(rank, world, port, q):
     stats = torch.tensor([1.0 + rank, 2, 3, 4, 5, 6, 7 + rank, 8, 9])
     all_reduce_stats(stats, world)
     ok = ok and bool(torch.allclose(stats, torch.tensor([1.5, 2, 3, 4, 5, 6, 15.0, 16, 18])))
+
+    # ---- the exchange as FlatGradDDP drives it: buckets launched from the per-segment callback WHILE "backward" is still
+    # running, bf16 payload in a communication buffer with the flat buffer's offsets, optional write-back into the fp32 buffer
+    for materialize in (False, True):
+        flat2 = torch.zeros(total)
+        comm = torch.zeros(total, dtype=torch.bfloat16)
+        launched_at = []
+        ex = BucketExchange(flat2, buckets, None, comm_buf=comm, materialize=materialize,
+                            pack=lambda src, dst: dst.copy_(src.to(torch.bfloat16)), unpack=lambda src, dst: dst.copy_(src.float()))
+        last_of = {last: b for b, (last, _, _) in enumerate(buckets)}
+        for i in range(len(segs)):                 # the engine: enqueue segment i, then call back
+            lo, hi = segs[i]
+            flat2[lo:hi] += (rank + 1.0) * (i + 1) / world
+            if i in last_of:
+                ex.launch(last_of[i])
+                launched_at.append(i)
+        n_inside = len(ex.issue_order)
+        ex.finish()
+        ok = ok and n_inside == len(buckets) and ex.issue_order == list(range(len(buckets))) and launched_at == [b[0] for b in buckets]
+        for i, (lo, hi) in enumerate(segs):
+            want = torch.full((hi - lo,), (i + 1) * (world + 1) / 2.0)
+            ok = ok and bool(torch.allclose(comm[lo:hi].float(), want, rtol=1e-2))          # bf16 payload: 8 significant bits
+            if materialize:
+                ok = ok and bool(torch.equal(flat2[lo:hi], comm[lo:hi].float()))
+            else:                                                                           # the fp32 buffer keeps the LOCAL gradient
+                ok = ok and bool(torch.allclose(flat2[lo:hi], torch.full((hi - lo,), (rank + 1.0) * (i + 1) / world)))
+    # ---- asynchronous stats all-reduce (train.py:181-189 off the critical path)
+    red = AsyncStats(world)
+    src = torch.tensor([1.0 + rank, 2, 3, 4, 5, 6, 7 + rank, 8, 9])
+    red.launch(src)
+    src.zero_()                                     # the caller's tensor is free again at once: the reducer works on its copy
+    ok = ok and bool(torch.allclose(red.result(), torch.tensor([1.5, 2, 3, 4, 5, 6, 15.0, 16, 18]))) and red.result() is None
     q.put((rank, ok, len(buckets)))
     dist.destroy_process_group()
 

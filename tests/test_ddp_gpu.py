@@ -63,9 +63,15 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     from crct.layout import parameter_table
     table, total = parameter_table(cfg, cpu_params)
     assert int(r0["n_buckets"][0]) >= (4 if case == "tiny" else 8)
+    # train.py:138-143 semantics: the collectives go out WHILE backward is being issued -- every bucket was launched from the
+    # engine's per-segment callback, before the backward call returned (round 2 queued them all after it)
+    for r in (r0, r1):
+        assert int(r["issued_inside_call"][0]) == int(r["n_buckets"][0]) == int(r["issued_inside_call_bf16"][0])
     # identical on both ranks, and equal to the mean of the ranks' losses' gradient
-    for key in ("g_sync", "g_accum"):
+    for key in ("g_sync", "g_accum", "g_bf16", "g_materialized", "params_after_step", "stats9_async"):
         assert np.array_equal(r0[key], r1[key]), key
+    assert not np.array_equal(r0["g_bf16_local_fp32"], r1["g_bf16_local_fp32"])       # .grad keeps the LOCAL gradient in bf16-direct mode
+    assert np.array_equal(r0["stats9_async"], r0["stats9"])
     mean_loss = 0.5 * (float(r0["loss"][0]) + float(r1["loss"][0]))
     assert abs(mean_loss - float(ref[0])) <= 2e-2 * abs(float(ref[0]))
     assert np.array_equal(r0["params_after_broadcast"], r1["params_after_broadcast"])
@@ -75,7 +81,7 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
             continue
         r = sd[e.name].grad.flatten()
         rn = float(r.double().norm())
-        for key in ("g_sync", "g_accum"):
+        for key in ("g_sync", "g_accum", "g_bf16"):       # g_bf16: each rank's gradient rounded to bf16 before the sum, summed in bf16
             g = torch.from_numpy(r0[key][e.offset:e.offset + e.numel])
             if rn < 1e-7:
                 assert float(g.double().norm()) < 1e-3, (e.name, key)
@@ -86,6 +92,15 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
             if c < tol_c or abs(ratio - 1) > tol_r:
                 bad.append((key, e.name, round(c, 4), round(ratio, 4)))
     assert not bad, (len(bad), bad[:10])
+    # the bf16 payload against the fp32 payload of the same step: 8 significant bits per addend
+    used = np.concatenate([np.arange(e.offset, e.offset + e.numel) for e in table if e.used])
+    a, b = torch.from_numpy(r0["g_bf16"][used]).double(), torch.from_numpy(r0["g_sync"][used]).double()
+    assert float((a - b).norm() / b.norm()) < 8e-3
+    # materialize_grads: what the fp32 .grad views hold afterwards is that bf16 result (rewritten for this pass's batch: equal
+    # to g_bf16 up to the dropout-free determinism of the step)
+    assert np.array_equal(r0["g_materialized"][used], r0["g_bf16"][used])
+    # the AdamW step from the bf16 buffer moved the parameters (both ranks identically: asserted above)
+    assert not np.array_equal(r0["params_after_step"][:4096], r0["params_after_broadcast"])
     # no exchange on the accumulation-only micro-step: the two ranks' local gradients differ
     assert not np.array_equal(r0["g_local_after_no_sync"], r1["g_local_after_no_sync"])
     # stats: first six averaged over the ranks, last three summed (train.py:181-189)

@@ -406,7 +406,7 @@ def test_adamw_matches_torch():
         opt.step()
         L.check(lib.crct_adamw_step(p.data_ptr(), (grad * step).data_ptr(), m.data_ptr(), v.data_ptr(), pb.data_ptr(), seg_off.data_ptr(),
                                     seg_len.data_ptr(), seg_lr.data_ptr(), seg_wd.data_ptr(), bs.data_ptr(), bo.data_ptr(), bs.numel(),
-                                    0.9, 0.999, 1e-8, step, None, None, None, 2 if step == 2 else 0, 0, L.current_stream()))   # step 2: throttled grid
+                                    0.9, 0.999, 1e-8, step, None, None, None, 2 if step == 2 else 0, 0, None, L.current_stream()))   # step 2: throttled grid
     for rp, o, s in zip(ref_params, offs, sizes):
         assert torch.allclose(p[o:o + s].cpu(), rp.detach(), rtol=1e-5, atol=1e-7)
         assert torch.equal(pb[o:o + s].cpu(), p[o:o + s].cpu().to(torch.bfloat16))
@@ -459,7 +459,12 @@ def test_fp8_quantisers_and_layernorm_copy():
     L.check(lib.crct_fp8_quantize_bf16(x.data_ptr(), q.data_ptr(), sc.data_ptr(), am.data_ptr(), x.numel(), L.current_stream()))
     assert torch.equal(q.view(torch.float8_e4m3fn).float(), _q8(x, 17.0).float())
     assert float(am.max()) == float(x.float().abs().max())
-    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, L.current_stream()))
+    # skip_if != 0 (GradScaler's found_inf): the call must leave scale AND amax untouched
+    skip = torch.ones(1, device=DEV)
+    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, skip.data_ptr(), L.current_stream()))
+    assert float(sc) == 17.0 and float(am.max()) == float(x.float().abs().max())
+    skip.zero_()
+    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, skip.data_ptr(), L.current_stream()))
     assert abs(float(sc) - 448.0 / float(x.float().abs().max())) < 1e-4 * float(sc) and float(am.abs().max()) == 0.0
     # LayerNorm with the e4m3 copy: the copy is the quantisation of the bf16 output the kernel stores
     xs = (torch.randn(1600, 768, device=DEV)).to(torch.bfloat16)

@@ -76,14 +76,14 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     if (f32) { hr.resize(nout); hipMemcpy(hr.data(), Cref, nout * 4, hipMemcpyDeviceToHost); }
     else { hrb.resize(nout); hipMemcpy(hrb.data(), Cref, nout * 2, hipMemcpyDeviceToHost); }
-    for (int tile = first_tile; tile < 22; ++tile)
+    for (int tile = first_tile; tile < 36; ++tile)
      for (int sk = 1; sk <= max_sk; ++sk) {
       if (tile >= 16 && tile < 20) continue;
       if (only_tile >= 0 && tile != only_tile) continue;
       if (sk > 1 && (s.ta || s.N > 1024 || !(tile == 4 || tile == 9 || tile == 12 || tile == 15) || s.K / 64 < 2 * sk)) continue;
       CrctGemmArgs g = make(tile, C);
       if (sk > 1) { g.split_k = sk; g.splitk_ws = sk_ws; g.splitk_cnt = sk_cnt; }
-      const bool f8 = tile >= 20;          // fp8 forward kernel (2 / 3 stages): same byte buffers read as e4m3, timing only
+      const bool f8 = tile == 20 || tile == 21;          // fp8 forward kernel (2 / 3 stages): same byte buffers read as e4m3, timing only
       if (f8) {
         if (s.ta || s.tb || s.K % 128) continue;
         g.fp8 = 1; g.scale_a = scales; g.scale_b = scales + 1; g.tile = tile; g.lda = s.K; g.ldb = s.K;

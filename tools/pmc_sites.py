@@ -43,6 +43,8 @@ def load(path):
             d = int(r["Dispatch_Id"])
             ent = rows.setdefault(d, (name, {}, int(r.get("Grid_Size", 0) or 0), int(r.get("Workgroup_Size", 1) or 1)))
             ent[1][r["Counter_Name"]] = ent[1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):       # kernel begin / end stamps of the (serialised) dispatch, ns
+                ent[1]["_duration_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return [rows[d] for d in sorted(rows)]
 
 
@@ -84,24 +86,28 @@ def main():
             wc = max(m["SQ_WAVE_CYCLES"], 1.0)
             e["wave_wait_frac"] = m.get("SQ_WAIT_ANY", 0.0) / wc
             e["wave_issue_stall_frac"] = m.get("SQ_WAIT_INST_ANY", 0.0) / wc
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
-            # kernel duration in shader cycles ~ GRBM_GUI_ACTIVE / 8 (summed over the 8 XCDs); MFMA-busy is summed over 1024 SIMDs
-            cyc = max(m["GRBM_GUI_ACTIVE"] / 8.0, 1.0)
-            e["kernel_cycles"] = cyc
-            e["mfma_busy_frac_of_chip"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+        if "_duration_ns" in m:
+            e["us_serialised"] = m.pop("_duration_ns") / 1e3
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "us_serialised" in e:
+            # MFMA-busy is summed over the 1024 SIMDs; the denominator is the kernel's own duration at the 2.4 GHz peak clock (the
+            # chip holds less under load: a lower bound of the busy fraction).  GRBM_GUI_ACTIVE / 8 is NOT used as the duration:
+            # on dispatches this short it reads 20+ us high (MI355X_MICROARCH.md, DVFS give-back)
+            e["mfma_busy_frac_of_chip"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["us_serialised"] * 2400.0 * 1024.0)
+            e["tflops_serialised"] = e["gflop"] / e["us_serialised"] * 1e-3 * 1e3
         sites[key] = e
     out = dict(_source_hash=log.get("source_hash"), _workload=log.get("workload"), _steps=log.get("steps"), _mismatched_dispatches=mismatches,
                _note="per launch averages; dispatches serialised by the profiler (caches / order of the real step, no concurrency)", sites=sites)
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1)
     print("matched %d launches per pass, %d mismatches" % (len(recs), mismatches))
-    hdr = "%-18s %5s %6s %6s %6s %5s %8s %8s %8s %7s %7s %7s" % ("site", "n", "M", "N", "K", "S", "GFLOP", "rd MB", "wr MB", "L2hit", "wait", "mfma")
+    hdr = "%-18s %5s %6s %6s %6s %4s %7s %7s %7s %7s %6s %6s %6s %6s" % ("site", "n", "M", "N", "K", "cfg", "GFLOP", "us(ser)", "rd MB", "wr MB", "L2hit", "wait", "stall", "mfma")
     print(hdr)
     for key, e in sites.items():
-        print("%-18s %5d %6d %6d %6d %5d %8.2f %8.2f %8.2f %7s %7s %7s" % (
-            key, e["launches"], e["M"], e["N"], e["K"], e["split_k"], e["gflop"], e.get("read_bytes_per_launch", 0) / 1e6,
+        print("%-18s %5d %6d %6d %6d %4d %7.2f %7.1f %7.2f %7.2f %6s %6s %6s %6s" % (
+            key, e["launches"], e["M"], e["N"], e["K"], e["cfg"], e["gflop"], e.get("us_serialised", 0.0), e.get("read_bytes_per_launch", 0) / 1e6,
             e.get("write_bytes_per_launch", 0) / 1e6, ("%.3f" % e["l2_hit_rate"]) if "l2_hit_rate" in e else "-",
             ("%.3f" % e["wave_wait_frac"]) if "wave_wait_frac" in e else "-",
+            ("%.3f" % e["wave_issue_stall_frac"]) if "wave_issue_stall_frac" in e else "-",
             ("%.3f" % e["mfma_busy_frac_of_chip"]) if "mfma_busy_frac_of_chip" in e else "-"))
 
 
