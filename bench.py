@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--emulate-ranks", type=int, default=1, help="test hook (N = 1): every step's batch is the CONCATENATION of the batches R "
                     "ranks would draw (batch R x --batch): the run a data-parallel R-rank run must agree with (config.global_loss)")
     ap.add_argument("--no-dropout", action="store_true", help="test hook: dropout probabilities 0 (run-to-run and rank-count independent losses)")
+    ap.add_argument("--exchange-skip", default="", help="timing experiment: comma list of exchange parts to leave out (pack, collective, stats)")
+    ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
+                    "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
                     "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
     ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
@@ -280,6 +283,10 @@ def main():
         s, k, ph, c, sk = item.split(":")
         site_policy.append(dict(site=s, kind=k, phase=int(ph), cfg=int(c), split_k=int(sk)))
     core.site_policy = site_policy
+    # with a gradient exchange the engine's weight gradients share ONE side stream: the exchange (auxiliary stream) then has a
+    # hardware queue to itself -- a collective that really moves data must not sit in a compute stream's queue
+    wg_mode = a.wgrad_streams if a.wgrad_streams >= 0 else (2 if (world > 1 or a.force_exchange) else 1)
+    core.stream_mode = (1, wg_mode)
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1
@@ -295,7 +302,8 @@ def main():
     if exchange:                                     # attaches itself to the model
         ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32)
         ddp.force_exchange = bool(a.force_exchange)
-    stats_red = AsyncStats(world, device=dev) if exchange else None
+        ddp.debug_skip = tuple(filter(None, a.exchange_skip.split(",")))
+    stats_red = AsyncStats(world, device=dev, ddp=ddp) if (exchange and "stats" not in a.exchange_skip) else None
     host_pool = [S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i) for i in range(8)]
     if a.emulate_ranks > 1:                          # what `emulate_ranks` data-parallel ranks see in one step, as ONE batch
         assert world == 1
@@ -350,6 +358,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             loss = run_step()
+        cur["host_ms_per_step"] = (time.perf_counter() - t0) / n * 1e3       # host time to ENQUEUE a step (before the final sync)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -374,6 +383,7 @@ def main():
                              split_k=r.split_k, n_problems=r.n_problems, flops=r.flops))
         with open(a.launch_log, "w") as f:
             json.dump(dict(steps=a.steps, source_hash=source_hash(), workload=[a.batch, a.vis, a.tokens, a.feat], launches=recs), f)
+    host_ms = cur.get("host_ms_per_step")
     final_loss = float(loss.detach())
     # mean loss of the last timed step over the GLOBAL batch: the all-reduced stats when ranks exchange, else the local loss
     global_loss = float(cur["stats"][0]) if (stats_red is not None and cur.get("stats") is not None) else final_loss
@@ -401,12 +411,20 @@ def main():
         # timed region (the step itself overlaps it with backward in >= bucket_mb pieces)
         used = int(max(hi for _, hi in core._engine.segments)) if core._engine is not None else core.flat_grads.numel()
         buf = core.flat_grads[:used]
+        rc, aux = ddp.communicator(), core.aux_stream()
+
+        def all_reduce():            # the step's own route: RCCL on the engine's auxiliary stream (torch.distributed only in the gloo developer mode)
+            if rc is not None:
+                rc.all_reduce_(buf, aux)
+            else:
+                dist.all_reduce(buf)
+        torch.cuda.synchronize()
         for _ in range(2):
-            dist.all_reduce(buf)
+            all_reduce()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            dist.all_reduce(buf)
+            all_reduce()
         torch.cuda.synchronize()
         ar = (time.perf_counter() - t1) / 5
         comm = {"allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
@@ -414,6 +432,8 @@ def main():
                 "step_payload": {"dtype": a.grad_dtype, "bytes_per_step": used * (2 if a.grad_dtype == "bf16" else 4),
                                  "buckets": len(ddp._buckets or ()), "bucket_mb_of_fp32_gradients": a.bucket_mb,
                                  "collectives_issued_inside_the_backward_call": ddp.issued_inside_engine_call,
+                                 "route": "RCCL called directly on the engine's auxiliary stream" if rc is not None else "torch.distributed (%s)" % dist.get_backend(),
+                                 "hardware_queue_classes_seen": getattr(core, "queue_classes", None), "weight_gradient_streams": wg_mode,
                                  "single_rank_forced": bool(a.force_exchange and world == 1)}}
 
     # profiled steps run on EVERY rank (they contain the collectives of a normal step); only rank 0 reads the stamps
@@ -427,7 +447,7 @@ def main():
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
                                       "; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.dtype == "fp8" else ""),
                           "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                          "global_loss": global_loss, "input": a.input,
+                          "global_loss": global_loss, "input": a.input, "host_enqueue_ms_per_step": host_ms,
                           "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None,
                           "gemm_sites": sites, "gemm_variants": rows}}
         if flop_qa:
@@ -453,6 +473,7 @@ def main():
         prefetcher.close()
     if world > 1:
         dist.barrier()
+    if exchange:
         dist.destroy_process_group()
 
 

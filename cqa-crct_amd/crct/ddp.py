@@ -80,7 +80,7 @@ class BucketExchange(object):
     pack / unpack are HIP kernels; the CPU / gloo tests pass plain functions."""
 
     def __init__(self, flat_grads, buckets, group, comm_buf=None, materialize=False, stream_ctx=None, wait_events=None,
-                 pack=None, unpack=None, after_bucket=None):
+                 pack=None, unpack=None, after_bucket=None, collective=None):
         self.flat, self.buckets, self.group = flat_grads, buckets, group
         self.comm_buf, self.materialize = comm_buf, materialize
         self.stream_ctx = stream_ctx or contextlib.nullcontext
@@ -88,8 +88,12 @@ class BucketExchange(object):
         self.pack = pack or (lambda src, dst: dst.copy_(src))
         self.unpack = unpack or (lambda src, dst: dst.copy_(src))
         self.after_bucket = after_bucket or (lambda b: None)
+        # the collective: by default torch.distributed (gloo in the CPU tests; blocks until done), on the GPU RCCL called
+        # directly on the communication stream (crct/rccl.py)
+        self.collective = collective or (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait())
         self.works = [None] * len(buckets)
         self.issue_order = []
+        self.debug_skip = ()         # timing experiments only (tools/): leave out "pack" / "collective"
 
     def launch(self, b):
         if self.works[b] is not None:
@@ -98,14 +102,19 @@ class BucketExchange(object):
         with self.stream_ctx():
             self.wait_events(b)
             if self.comm_buf is not None:
-                self.pack(self.flat[lo:hi], self.comm_buf[lo:hi])
+                if "pack" not in self.debug_skip:
+                    self.pack(self.flat[lo:hi], self.comm_buf[lo:hi])
                 payload = self.comm_buf[lo:hi]
             else:
                 payload = self.flat[lo:hi]
-            w = dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.works[b] = w
+            if "collective" in self.debug_skip:
+                self.works[b] = True
+                self.issue_order.append(b)
+                self.after_bucket(b)
+                return
+            self.collective(payload)
+            self.works[b] = True
             self.issue_order.append(b)
-            w.wait()              # RCCL: orders the communication stream behind the collective (no host block); gloo: blocks
             if self.comm_buf is not None and self.materialize:
                 self.unpack(self.comm_buf[lo:hi], self.flat[lo:hi])
             self.after_bucket(b)
@@ -139,6 +148,7 @@ class FlatGradDDP(object):
         self.last_exchange = None    # BucketExchange of the last synchronised backward pass
         self.issued_inside_engine_call = 0      # collectives launched from the engine's callback during the last pass
         self._grad_source_valid = False
+        self._rccl = None
         if broadcast:      # DDP constructor semantics: rank 0's parameters win (train.py:139)
             dist.broadcast(self.core.flat_params, 0, group=process_group)
             self.core._invalidate_shadow()
@@ -152,6 +162,14 @@ class FlatGradDDP(object):
             yield
         finally:
             self.require_sync = old
+
+    def communicator(self):
+        """The RCCL communicator of the exchange (crct/rccl.py), created on first use; None when the process group is not an RCCL
+        one (the gloo-on-one-GPU tests: the collectives then go through torch.distributed)."""
+        if self._rccl is None and self.core.flat_grads.is_cuda and dist.get_backend(self.group) == "nccl":
+            from .rccl import Communicator
+            self._rccl = Communicator(self.core.flat_grads.device, self.group)
+        return self._rccl
 
     # ------------------------------------------------------------------ what the optimizer reads
     def grad_source(self):
@@ -203,14 +221,18 @@ class FlatGradDDP(object):
         from . import lib as L
         lib = L.load()
         dev = core.flat_grads.device
+        self._comm = core.aux_stream()           # the engine's auxiliary stream (the optimizer's too): idle during backward, on a hardware queue of its own
         if self._events is None:
-            self._comm = torch.cuda.Stream(device=dev)
-            # stock torch events (system-scope release at every record): what follows them is a collective whose peers
-            # read and write across GPUs -- unlike the engine-internal and optimizer events (crct/events.py), which order
-            # streams of one device only
-            self._events = [torch.cuda.Event() for _ in range(4 * len(eng.segments))]
+            from .events import DeviceEvent
+            # The 4 x 26 per-segment events only order the communication stream behind the engine's internal streams -- ONE
+            # device -- so they are device-scope events (no system-scope fence in the record: 104 cache write-back /
+            # invalidations per backward pass cost 0.9 ms of GPU time, tools/step_phases.py --exchange).  What peers must see is
+            # released at system scope by the event torch's ProcessGroupNCCL itself records on the communication stream
+            # BEHIND those waits, right before the collective; what peers have written is acquired through the stock torch
+            # events recorded after each bucket (bucket_done), which every consumer of the reduced gradients waits for.
+            self._events = [DeviceEvent() for _ in range(4 * len(eng.segments))]
             self._bucket_done = [torch.cuda.Event() for _ in self._buckets]
-            for ev in self._events + self._bucket_done:          # torch creates the hipEvent lazily, at the first record
+            for ev in self._events + self._bucket_done:          # created / recorded once so that a wait before the first record is legal
                 ev.record()
         if self.grad_dtype == torch.bfloat16 and self._comm_buf is None:
             self._comm_buf = torch.zeros(core.flat_grads.numel(), dtype=torch.bfloat16, device=dev)
@@ -219,7 +241,7 @@ class FlatGradDDP(object):
         def wait_events(b):
             last = self._buckets[b][0]
             for ev in self._events[4 * last:4 * last + 4]:
-                comm.wait_event(ev)
+                ev.wait(comm)
 
         def pack(src, dst):
             L.check(lib.crct_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), comm.cuda_stream), "pack gradients")
@@ -227,11 +249,14 @@ class FlatGradDDP(object):
         def unpack(src, dst):
             L.check(lib.crct_cast_bf16_f32(src.data_ptr(), dst.data_ptr(), src.numel(), comm.cuda_stream), "unpack gradients")
 
+        rccl = self.communicator()
+        collective = (lambda t: rccl.all_reduce_(t, comm)) if rccl is not None else None        # on the auxiliary stream itself: no hidden stream
         ex = BucketExchange(core.flat_grads, self._buckets, self.group,
                             comm_buf=self._comm_buf if self.grad_dtype == torch.bfloat16 else None,
                             materialize=self.materialize_grads, stream_ctx=lambda: torch.cuda.stream(comm), wait_events=wait_events,
-                            pack=pack, unpack=unpack, after_bucket=lambda b: self._bucket_done[b].record(comm))
+                            pack=pack, unpack=unpack, after_bucket=lambda b: self._bucket_done[b].record(comm), collective=collective)
         self.last_exchange = ex
+        ex.debug_skip = getattr(self, "debug_skip", ())
 
         def on_segment(seg):          # engine callback: segment `seg` (and its four events) is enqueued
             b = self._last_of.get(seg)
@@ -240,6 +265,7 @@ class FlatGradDDP(object):
 
         step["seg_done_events"] = self._events
         step["seg_enqueued"] = on_segment
+        step["seg_done_mask"] = [int(i in self._last_of) for i in range(len(eng.segments))]      # events / callbacks at bucket ends only
         eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
         self.issued_inside_engine_call = len(ex.issue_order)
         ex.finish()                   # nothing left unless the engine ran without the callback
@@ -250,36 +276,41 @@ class FlatGradDDP(object):
 
 
 class AsyncStats(object):
-    """train.py:181-189 without the host syncs and without stalling the step: the nine training statistics are copied and
-    all-reduced (SUM) on a side stream right after forward; ``result()`` orders the current stream behind the collective and
-    returns the tensor with the first six entries averaged.  One instance per training loop (the buffer is reused)."""
+    """train.py:181-189 without the host syncs and without stalling the step: the nine training statistics are copied into
+    this object's buffer and all-reduced (SUM, asynchronously: the process group's own stream picks the work up behind the
+    current stream) right after forward; ``result()`` -- at the end of the step -- orders the current stream behind the
+    collective and returns the tensor with the first six entries averaged.  No stream of its own (hardware queues are scarce:
+    see ``CrctModel.aux_stream``).  One instance per training loop (the buffer is reused)."""
 
-    def __init__(self, world_size, group=None, device=None):
-        self.world, self.group = world_size, group
+    def __init__(self, world_size, group=None, device=None, ddp=None):
+        self.world, self.group, self.ddp = world_size, group, ddp
         self.buf = torch.zeros(9, device=device)
-        self.cuda = self.buf.is_cuda
-        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
-        self.work = None
+        self.work = self.done = None
 
     def launch(self, stats9):
-        if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
+        rccl = self.ddp.communicator() if self.ddp is not None else None
+        if rccl is not None:          # on the engine's auxiliary stream, behind the forward pass that produced the statistics
+            from .events import order_streams
+            aux = self.ddp.core.aux_stream()
+            order_streams(torch.cuda.current_stream(), aux)
+            with torch.cuda.stream(aux):
                 self.buf.copy_(stats9)
-                self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
-            self.buf.copy_(stats9)
-            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                rccl.all_reduce_(self.buf, aux)
+                if self.done is None:
+                    self.done = torch.cuda.Event()
+                self.done.record(aux)
+            self.work = True
+            return
+        self.buf.copy_(stats9)
+        self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def result(self):
         if self.work is None:
             return None
-        if self.cuda:
-            with torch.cuda.stream(self.stream):
-                self.work.wait()
-            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.work is True:
+            torch.cuda.current_stream().wait_event(self.done)
         else:
-            self.work.wait()
+            self.work.wait()          # RCCL group of torch: a stream-level wait on the current stream; gloo: blocks the host
         self.work = None
         out = self.buf.clone()
         out[:-3] = out[:-3] / self.world

@@ -110,6 +110,11 @@ class StepEngine(object):
             arr = (C.c_void_p * len(done))(*[ev.cuda_event for ev in done])
             step["_seg_done_keepalive"] = arr
             c.seg_done_events = C.cast(arr, C.c_void_p)
+        mask = step.get("seg_done_mask")
+        if mask is not None:
+            arr = (C.c_int32 * len(mask))(*[int(bool(m)) for m in mask])
+            step["_seg_mask_keepalive"] = arr
+            c.seg_done_mask = C.cast(arr, C.c_void_p)
         cb = step.get("seg_enqueued")
         if cb is not None:          # python callable(seg): wrapped once per call; exceptions are kept and re-raised after the engine call
             err = step.setdefault("_seg_enqueued_errors", [])

@@ -84,7 +84,7 @@ class StepCfg(C.Structure):
                 ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("g_loss_dev", vp),
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
-                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("wgrad_overwrite", c_i32)]
+                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32)]
 
 
 SEG_ENQUEUED_FN = C.CFUNCTYPE(None, C.c_int, vp)      # void (*seg_enqueued)(int seg, void* user)
@@ -148,6 +148,7 @@ PROTOTYPES = {
     "crct_engine_forward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp]),
     "crct_engine_backward": (C.c_int, [vp, vp, vp, C.POINTER(Batch), C.POINTER(StepCfg), vp, vp, vp, vp, vp, C.c_int, vp]),
     "crct_engine_set_streams": (C.c_int, [vp, C.c_int, C.c_int]),
+    "crct_engine_aux_stream": (vp, [vp, vp, C.POINTER(C.c_int)]),
     "crct_event_create": (vp, []),
     "crct_event_destroy": (None, [vp]),
     "crct_event_record": (C.c_int, [vp, vp]),

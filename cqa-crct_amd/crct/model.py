@@ -11,6 +11,7 @@ parameters are views into ONE flat fp32 HBM buffer (+ a bf16 shadow, + a flat fp
 and ``forward`` / ``backward`` are single calls into the native step engine (hand-written gfx950
 kernels, ``include/crct_hip.h``).  The module refuses to run without the HIP library or off-GPU.
 """
+import ctypes as C
 import math
 import os
 
@@ -364,7 +365,25 @@ class CrctModel(nn.Module):
             self._engine = StepEngine(self.config, self.params, mb, mt, mv, self._flat_p.device, self.cls_dropout)
             for pol in getattr(self, "site_policy", ()):          # developer / test overrides of the per-site launch policy
                 self._engine.set_site_policy(**pol)
+            mode = getattr(self, "stream_mode", None)             # (use_visual_stream, use_wgrad_streams) of crct_engine_set_streams
+            if mode is not None:
+                L.check(self._engine.lib.crct_engine_set_streams(self._engine.handle, int(mode[0]), int(mode[1])), "set_streams")
         return self._engine
+
+    def aux_stream(self):
+        """THE side stream of the host-side glue: the optimizer's overlapped update runs on it during the next forward, the
+        data-parallel exchange (pack, collectives) during backward -- one stream, because MI355X schedules HIP streams onto
+        4 hardware queues and streams that share a queue are serialised: the engine's internal streams already use them."""
+        if getattr(self, "_aux_stream", None) is None or self._aux_stream.device != self._flat_p.device or self._aux_engine is not self._engine:
+            if self._engine is None:
+                raise RuntimeError("the auxiliary stream belongs to the step engine: run a forward pass first")
+            n = C.c_int(0)
+            ptr = self._engine.lib.crct_engine_aux_stream(self._engine.handle, L.current_stream(), C.byref(n))
+            if not ptr:
+                raise RuntimeError("crct_engine_aux_stream failed: %s" % self._engine.lib.crct_last_error().decode())
+            self._aux_stream = torch.cuda.ExternalStream(ptr, device=self._flat_p.device)
+            self._aux_engine, self.queue_classes = self._engine, int(n.value)
+        return self._aux_stream
 
     def segment_done_events(self):
         """4 events per backward segment, recorded by the engine on its internal streams when the segment is enqueued."""

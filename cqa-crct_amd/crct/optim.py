@@ -220,7 +220,7 @@ class FusedAdamW(torch.optim.Optimizer):
         covered = sum(b1 - b0 for b0, b1 in self._seg_blocks)
         if covered != len(blk_seg):
             raise RuntimeError("optimizer overlap plan does not cover every block (%d of %d)" % (covered, len(blk_seg)))
-        self._opt_stream = torch.cuda.Stream(device=self.core.flat_params.device)
+        self._opt_stream = self.core.aux_stream()        # shared with the data-parallel exchange (crct/ddp.py)
         from .events import DeviceEvent
         self._events = [DeviceEvent() for _ in eng.segments]
         return True
@@ -260,6 +260,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                "(or grad_dtype=torch.float32) when training with a GradScaler")
         if self.overlap and not amp and (self._seg_blocks is not None or self._plan_overlap()):
             cur = torch.cuda.current_stream()
+            self._opt_stream = core.aux_stream()          # the engine's auxiliary stream (re-fetched: an engine rebuilt for a larger batch has new streams)
             done = None
             if self.early and inv_scale is None:
                 done = core.take_segment_done_events()

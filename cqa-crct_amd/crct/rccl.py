@@ -1,0 +1,91 @@
+"""RCCL called directly (ctypes on the librccl.so torch itself ships and has already loaded), for ONE reason: the collective
+must run on a HIP stream this package chose.
+
+``torch.distributed``'s NCCL process group enqueues every collective on a stream of its own.  MI355X schedules all HIP streams
+of a process onto 4 hardware queues, and streams that share a queue are serialised (``csrc/streams.hip``); where the process
+group's stream lands is an accident of creation order.  Measured on one MI355X with a single-rank communicator, i.e. with
+collectives that move nothing: 10 ``dist.all_reduce`` calls per step cost 0.66 ms of GPU time, because the group's stream sat
+on the queue of one of the engine's compute streams and its event waits stalled that queue (profiles/r3_ddp_stream_placement.txt);
+with real transfers the collectives themselves would run inside a compute stream's queue.  Called directly, ``ncclAllReduce``
+takes the stream as an argument: the engine's auxiliary stream (``crct_engine_aux_stream``), which has a hardware queue to itself.
+
+Bootstrap: rank 0 draws the ``ncclUniqueId`` and the existing ``torch.distributed`` group (any backend) broadcasts its 128
+bytes -- the only thing torch.distributed is used for on this path (plus what the training loop itself does with it).
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+NCCL_UNIQUE_ID_BYTES = 128
+ncclSum = 0
+DTYPES = {torch.float32: 7, torch.bfloat16: 9, torch.float16: 6, torch.int32: 2, torch.int64: 4, torch.uint8: 1}      # rccl.h ncclDataType_t
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            raise RuntimeError("librccl.so not found next to torch (%s): the data-parallel exchange needs RCCL" % path)
+        lib = C.CDLL(path)
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("RCCL %s failed: %s" % (what, _load().ncclGetErrorString(rc).decode()))
+
+
+class Communicator(object):
+    """One RCCL communicator over the ranks of ``group`` (default: the world), created on ``device``."""
+
+    def __init__(self, device, group=None):
+        lib = _load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]      # the raw 128 bytes (.internal would stop at a NUL)
+        if self.world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+        raw = box[0]
+        if len(raw) != NCCL_UNIQUE_ID_BYTES:       # c_char arrays stop at the first NUL when read as .value: take the raw buffer
+            raise RuntimeError("ncclUniqueId has %d bytes" % len(raw))
+        C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+        self.comm = C.c_void_p()
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def all_reduce_(self, t, stream):
+        """In-place SUM of a contiguous CUDA tensor, enqueued on ``stream`` (a torch stream); returns at once."""
+        if not t.is_contiguous() or not t.is_cuda:
+            raise RuntimeError("all_reduce_: contiguous CUDA tensor required")
+        _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), DTYPES[t.dtype], ncclSum, self.comm, stream.cuda_stream), "ncclAllReduce")
+
+    def broadcast_(self, t, root, stream):
+        _check(_load().ncclBroadcast(t.data_ptr(), t.data_ptr(), t.numel(), DTYPES[t.dtype], int(root), self.comm, stream.cuda_stream), "ncclBroadcast")
+
+    def destroy(self):
+        """Explicit only (not from __del__: at interpreter exit the HIP runtime may already be gone)."""
+        if getattr(self, "comm", None):
+            _load().ncclCommDestroy(self.comm)
+            self.comm = None

@@ -140,6 +140,7 @@ struct crct_engine {
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
+  bool one_wgrad_stream = false;       // both data streams' weight gradients on ONE side stream (frees a hardware queue for the exchange)
   // paired mode (off by default -- measured 1 ms per step slower in situ; CRCT_PAIR=1 or crct_engine_set_pairing(e, 1)
   // turn it on): from the first co-attention layer on, the
   // text and the visual side run on ONE stream as grouped / pair launches instead of two concurrent streams (Run::pair_flush);
@@ -147,6 +148,14 @@ struct crct_engine {
   bool pair_mode = false, pair_forced = false;
   int first_conn = -1;                  // schedule index of the first co-attention layer
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
+  // hardware-queue placement (streams.hip): the four streams below sit on queues other than the caller's stream's -- visual and
+  // text-wgrad on queues of their own, the auxiliary stream (optimizer overlap during forward, gradient exchange during
+  // backward: crct_engine_aux_stream) on the third, which the visual-wgrad stream shares (it is idle whenever the optimizer
+  // runs; with one_wgrad_stream it is not used and the exchange has that queue to itself)
+  hipStream_t aux = nullptr;
+  hipStream_t placed_for = nullptr;
+  bool placed = false;
+  int queue_classes = 0;
   std::vector<hipEvent_t> evpool;
   size_t evnext = 0;
   std::vector<std::pair<int64_t, int64_t>> seg_range;
@@ -1072,6 +1081,7 @@ extern "C" void crct_engine_destroy(crct_engine_t* e) {
   if (!e) return;
   for (auto ev : e->evpool) (void)hipEventDestroy(ev);
   for (auto st : e->side) if (st) (void)hipStreamDestroy(st);
+  if (e->aux && e->aux != e->side[0] && e->aux != e->side[1]) (void)hipStreamDestroy(e->aux);
   delete e;
 }
 extern "C" size_t crct_engine_workspace_bytes(const crct_engine_t* e) { return e ? e->ws_bytes : 0; }
@@ -1084,12 +1094,20 @@ extern "C" int crct_engine_segment_range(const crct_engine_t* e, int seg, int64_
 
 namespace {
 
-int ensure_streams(crct_engine* e) {
+int ensure_streams(crct_engine* e, hipStream_t main) {
   // all internal streams share the caller's (default) priority: giving the weight-gradient streams the lowest or the
   // visual stream the highest priority (hipStreamCreateWithPriority) was measured to DOUBLE the step time on MI355X
   // (10.7 -> 21.9 ms, round 1) -- cross-priority event waits are slow -- so there is no priority knob
+  if (!e->placed) {          // once per engine: streams on hardware queues that do not collide with the caller's or each other
+    e->placed = true;
+    e->placed_for = main;
+    hipStream_t out[4];
+    if (int r = crct_streams_place(main, out, &e->queue_classes)) return r;
+    e->side[0] = out[0]; e->side[1] = out[1]; e->aux = out[2]; e->side[2] = out[3];
+    if (!e->aux) e->aux = out[1] ? out[1] : out[0];          // fewer than four queue classes: share
+  }
   for (int k = 0; k < 3; ++k) {
-    const bool need = k == 0 ? e->use_vis_stream : e->use_wgrad_stream;
+    const bool need = k == 0 ? e->use_vis_stream : (e->use_wgrad_stream && !(k == 2 && e->one_wgrad_stream));
     if (need && !e->side[k] && hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) {
       crct_set_error("engine: cannot create an internal HIP stream");
       return 1;
@@ -1110,7 +1128,7 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
   hipStream_t vis = (e->use_vis_stream && !paired) ? e->side[0] : main;
   Rt = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, main, batch, cfg, e->use_wgrad_stream ? e->side[1] : main,
            e->partials[0], e->colsum_part[0], e->colsum_part[2]};
-  Rv = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, vis, batch, cfg, e->use_wgrad_stream ? e->side[2] : vis,
+  Rv = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, vis, batch, cfg, e->use_wgrad_stream ? e->side[e->one_wgrad_stream ? 1 : 2] : vis,
            e->partials[1], e->colsum_part[1], e->colsum_part[3]};
   Rt.sets[0] = &e->st; Rt.sets[1] = &e->st2;
   Rv.sets[0] = &e->sv; Rv.sets[1] = &e->sv2;
@@ -1135,7 +1153,7 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
                                crct_stream_t stream) {
   CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && logits && reg && stats, "engine_forward: null argument");
   if (int r = check_batch(e, batch)) return r;
-  if (int r = ensure_streams(e)) return r;
+  if (int r = ensure_streams(e, (hipStream_t)stream)) return r;
   e->evnext = 0;
   // key masks the caller did not supply are built here (one launch) and kept in the workspace for the backward pass
   CrctBatch bl = *batch;
@@ -1210,7 +1228,7 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   CRCT_REQUIRE(e && params_f32 && params_bf16 && cfg && workspace && grads_f32 && logits && reg && stats, "engine_backward: null argument");
   CRCT_REQUIRE(batch && batch->labels, "engine_backward: labels are required (training step)");
   if (int r = check_batch(e, batch)) return r;
-  if (int r = ensure_streams(e)) return r;
+  if (int r = ensure_streams(e, (hipStream_t)stream)) return r;
   e->evnext = 0;
   CrctBatch bl = *batch;                                 // masks built by the forward pass of this batch live in the workspace
   if (!bl.text_keymask) bl.text_keymask = (const uint8_t*)workspace + e->km_t;
@@ -1277,14 +1295,15 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
       Rt.flush_wgrads();
       Rv.flush_wgrads();
       hipStream_t ss[4] = {Rt.s, Rt.sw, Rv.s, Rv.sw};
-      for (int sg = ev_from; sg <= sgi; ++sg)
+      for (int sg = ev_from; sg <= sgi; ++sg) {
+        if (cfg->seg_done_mask && !cfg->seg_done_mask[sg]) continue;
         for (int k = 0; k < 4; ++k) {
           hipEvent_t ev = (hipEvent_t)cfg->seg_done_events[4 * sg + k];
           if (ev && hipEventRecord(ev, ss[k]) != hipSuccess) { crct_set_error("engine_backward: cannot record a segment event"); Rt.rc = 1; }
         }
-      // the data-parallel caller launches the bucket this segment completes NOW, while the rest of backward is still being enqueued
-      if (cfg->seg_enqueued && !Rt.rc)
-        for (int sg = ev_from; sg <= sgi; ++sg) cfg->seg_enqueued(sg, cfg->seg_enqueued_user);
+        // the data-parallel caller launches the bucket this segment completes NOW, while the rest of backward is still being enqueued
+        if (cfg->seg_enqueued && !Rt.rc) cfg->seg_enqueued(sg, cfg->seg_enqueued_user);
+      }
     }
     ev_from = sgi + 1;
   }
@@ -1333,6 +1352,7 @@ extern "C" int crct_engine_set_streams(crct_engine_t* e, int use_visual_stream, 
   if (!e) return 1;
   e->use_vis_stream = use_visual_stream != 0;
   e->use_wgrad_stream = use_wgrad_streams != 0;
+  e->one_wgrad_stream = use_wgrad_streams == 2;
   e->streams_forced = true;
   return 0;
 }
@@ -1369,6 +1389,13 @@ extern "C" int crct_event_synchronize(void* ev) {
   CRCT_REQUIRE(ev, "event_synchronize: null event");
   CRCT_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev));
   return 0;
+}
+
+extern "C" crct_stream_t crct_engine_aux_stream(crct_engine_t* e, crct_stream_t main_stream, int* queue_classes) {
+  if (!e) return nullptr;
+  if (ensure_streams(e, (hipStream_t)main_stream)) return nullptr;
+  if (queue_classes) *queue_classes = e->queue_classes;
+  return e->aux;
 }
 
 extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind, int phase, int cfg, int split_k) {

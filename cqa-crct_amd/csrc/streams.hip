@@ -1,0 +1,88 @@
+// Placement of the step's HIP streams on the GPU's hardware queues.
+//
+// MI355X / ROCm 7.2 multiplexes all HIP streams of a process onto GPU_MAX_HW_QUEUES (= 4) hardware queues; a stream is bound
+// to a queue when it is created (the queue with the fewest users) and two streams that share a queue run their kernels
+// strictly one after the other.  Which streams share is an accident of creation order: in a process that has set up RCCL
+// first, the engine's text and visual streams landed on ONE queue and a training step took 12.1 instead of 7.6 ms
+// (profiles/r3_ddp_stream_placement.txt).  There is no API to ask for a queue, but whether two streams share one can be
+// MEASURED: two short spin kernels, one per stream, take twice as long when they are serialised.  crct_streams_place creates
+// candidate streams, sorts them into queue classes against the caller's stream by that probe, and hands back one stream per
+// foreign class (+ a second one of the last class): the engine's visual / weight-gradient streams and the auxiliary stream the
+// host-side glue (optimizer overlap, gradient exchange) runs on.  One-time cost: a few milliseconds per engine.
+#include <vector>
+
+#include "common.hip.h"
+#include "crct_internal.h"
+
+namespace {
+
+__global__ void spin_kernel(long long ticks) {          // s_memrealtime: 100 MHz wall clock
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// do kernels on streams a and b serialise?  (both streams idle on entry)
+int conflict(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, bool* out) {
+  constexpr long long SPIN_US = 120;
+  CRCT_CHECK_HIP(hipEventRecord(e0, a));
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, SPIN_US * 100);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, SPIN_US * 100);
+  CRCT_CHECK_HIP(hipEventRecord(e1, b));
+  CRCT_CHECK_HIP(hipEventSynchronize(e1));
+  CRCT_CHECK_HIP(hipStreamSynchronize(a));
+  float ms = 0.f;
+  CRCT_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *out = ms * 1e3f > 1.6f * SPIN_US;                     // concurrent: ~1.0-1.2 x, serialised: >= 2 x
+  return 0;
+}
+
+}  // namespace
+
+// out[0..2]: streams of three queue classes other than main's (nullptr where fewer classes exist), out[3]: a second stream of
+// out[2]'s class (or nullptr); n_classes = queue classes seen (main's included).  Streams not handed out are destroyed.
+int crct_streams_place(hipStream_t main, hipStream_t out[4], int* n_classes) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  CRCT_CHECK_HIP(hipEventCreate(&e0));
+  CRCT_CHECK_HIP(hipEventCreate(&e1));
+  CRCT_CHECK_HIP(hipStreamSynchronize(main));
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, main, 100);      // code object load / first-launch cost out of the probes
+  CRCT_CHECK_HIP(hipStreamSynchronize(main));
+  std::vector<std::vector<hipStream_t>> cls(1);
+  cls[0].push_back(main);
+  std::vector<hipStream_t> mine;
+  int rc = 0;
+  for (int i = 0; i < 16 && !rc; ++i) {
+    bool done = cls.size() >= 4;
+    for (size_t c = 1; c < cls.size() && done; ++c) done = cls[c].size() >= (c + 1 == cls.size() ? 2u : 1u);
+    if (done) break;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { crct_set_error("streams: cannot create a HIP stream"); rc = 1; break; }
+    mine.push_back(s);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, 100);
+    (void)hipStreamSynchronize(s);
+    size_t home = cls.size();
+    for (size_t c = 0; c < cls.size() && !rc; ++c) {
+      bool same = false;
+      rc = conflict(cls[c][0], s, e0, e1, &same);
+      if (same) { home = c; break; }
+    }
+    if (rc) break;
+    if (home == cls.size()) cls.emplace_back();
+    cls[home].push_back(s);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (int k = 0; k < 4; ++k) out[k] = nullptr;
+  if (!rc) {
+    for (size_t c = 1; c < cls.size() && c <= 3; ++c) out[c - 1] = cls[c][0];
+    const size_t last = cls.size() > 3 ? 3 : cls.size() - 1;
+    if (last >= 1 && cls[last].size() > 1) out[3] = cls[last][1];
+    if (n_classes) *n_classes = (int)cls.size();
+  }
+  for (hipStream_t s : mine) {
+    bool kept = false;
+    for (int k = 0; k < 4; ++k) kept = kept || out[k] == s;
+    if (!kept) (void)hipStreamDestroy(s);
+  }
+  return rc;
+}

@@ -463,6 +463,8 @@ typedef struct CrctStepCfg {
    * queue ~0.3 ms into backward instead of after the host has enqueued all of it.  Must not call back into the engine. */
   void (*seg_enqueued)(int seg, void* user);
   void* seg_enqueued_user;
+  const int32_t* seg_done_mask;   /* optional HOST array [crct_engine_num_segments]: only segments with a non-zero entry get their
+                                events recorded and the callback (a bucketed exchange needs them at bucket ends only); NULL = all */
   int32_t wgrad_overwrite;   /* backward only.  != 0: the caller guarantees that nothing has been accumulated into the weight
                                 gradients listed by crct_engine_wgrad_owned since they were last consumed; those gradients are
                                 then WRITTEN instead of added to (bit-identical to adding into zeros) and need not be zeroed --
@@ -483,8 +485,16 @@ int crct_engine_backward(crct_engine_t*, const float* params_f32, const void* pa
                          crct_stream_t stream);
 /* Internal concurrency (default: both on): the visual stream's layers run on a second HIP stream and all
  * weight-gradient GEMMs / bias column sums on two more, forked from and joined to `stream` inside every call.
- * Results do not depend on the setting (tests compare them bit for bit). */
+ * use_wgrad_streams = 2: ONE side stream for the weight gradients of both data streams (a data-parallel run gives the hardware
+ * queue this frees to the gradient exchange: MI355X schedules HIP streams onto 4 hardware queues, and streams that share one
+ * are serialised).  Results do not depend on the setting (tests compare them bit for bit). */
 int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad_streams);
+/* The auxiliary HIP stream of the step: the engine places its internal streams and this one on hardware queues that do not
+ * collide with `main_stream`'s or with each other (probed once per engine, csrc/streams.hip: streams that share one of the
+ * GPU's 4 hardware queues are serialised, and which ones share is otherwise an accident of creation order).  The host-side
+ * glue runs the overlapped optimizer update (during the next forward) and the data-parallel exchange (during backward) on
+ * it -- nothing else should.  queue_classes (may be NULL): hardware-queue classes the probe saw, 4 when every stream has its own. */
+crct_stream_t crct_engine_aux_stream(crct_engine_t*, crct_stream_t main_stream, int* queue_classes);
 /* Paired mode (default OFF: measured slower in the step; CRCT_PAIR=1 turns it on for A/B runs): from the first co-attention layer
  * on, the text and the visual side of the schedule share ONE stream and leave as grouped GEMM / pair LayerNorm launches
  * (crct_gemm_bf16_grouped with n = 2, crct_layernorm_*_pair) instead of running on two concurrent streams.  Results are

@@ -100,7 +100,18 @@ def main():
     out["g_bf16_local_fp32"] = core.flat_grads.detach().cpu().numpy().copy()
     out["issued_inside_call_bf16"] = np.array([ddp16.issued_inside_engine_call])
     out["stats9_async"] = red.result().cpu().numpy()
-    # ... and the fused AdamW consumes it as it lies: one step, both ranks must end on identical parameters
+    # (4) materialize_grads: the all-reduced bf16 bucket is written back into the fp32 .grad views (same weights, same batch)
+    ddp16.materialize_grads = True
+    core.zero_flat_grads()
+    step_forward(model, mine, params)[0].backward()
+    assert ddp16.grad_source() is None
+    torch.cuda.synchronize()
+    out["g_materialized"] = core.flat_grads.detach().cpu().numpy().copy()
+    # (5) the fused AdamW consumes the bf16 buffer as it lies: one step, both ranks must end on identical parameters
+    ddp16.materialize_grads = False
+    core.zero_flat_grads()
+    step_forward(model, mine, params)[0].backward()
+    assert ddp16.grad_source() is not None
     opt = get_optimizer(params, model)
     opt.overlap = case != "tiny"
     opt.step()
@@ -108,13 +119,6 @@ def main():
     opt.synchronize()
     torch.cuda.synchronize()
     out["params_after_step"] = core.flat_params.detach().cpu().numpy().copy()
-    # (4) materialize_grads: the all-reduced bf16 bucket is written back into the fp32 .grad views
-    ddp16.materialize_grads = True
-    core.zero_flat_grads()
-    step_forward(model, mine, params)[0].backward()
-    assert ddp16.grad_source() is None
-    torch.cuda.synchronize()
-    out["g_materialized"] = core.flat_grads.detach().cpu().numpy().copy()
     np.savez(os.path.join(outdir, "%s_rank%d.npz" % (case, rank)), **out)
     dist.barrier()
     dist.destroy_process_group()

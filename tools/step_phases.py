@@ -13,6 +13,12 @@ from crct.model import VisualDialogEncoder
 from crct.optim import get_optimizer, WarmupLinearScheduleNonZero
 from crct.step_adapter import forward as step_forward
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--exchange", choices=("none", "bf16", "fp32"), default="none", help="run the data-parallel exchange on a single-rank RCCL communicator")
+ap.add_argument("--thread", type=int, default=1)
+ap.add_argument("--stats", type=int, default=0, help="1: the asynchronous 9-float stats all-reduce of bench.py inside the step")
+args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B = 80
 cfg = CFG.vilbert_config(v_feature_size=2048)
@@ -25,6 +31,25 @@ opt = get_optimizer(params, model)
 opt.overlap = True
 sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
 pool = [{k: v.to(dev) for k, v in S.make_batch(B, 20, 36, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
+launch_host = []
+if args.exchange != "none":
+    import torch.distributed as dist
+    from crct import ddp as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    ddp = D.FlatGradDDP(model, grad_dtype=torch.bfloat16 if args.exchange == "bf16" else torch.float32)
+    ddp.force_exchange = True
+    if hasattr(ddp, "use_thread"):
+        ddp.use_thread = bool(args.thread)
+    stats_red = D.AsyncStats(1, device=dev) if args.stats else None
+    _orig_launch = D.BucketExchange.launch
+
+    def timed_launch(self, b):
+        t0 = time.perf_counter()
+        _orig_launch(self, b)
+        launch_host.append((time.perf_counter() - t0) * 1e3)
+    D.BucketExchange.launch = timed_launch
 
 marks = []
 
@@ -54,11 +79,15 @@ for it in range(N):
     mark("step_begin")
     out = step_forward(model, pool[it % 8], params)
     mark("fwd_loss_enqueued")
+    if args.exchange != "none" and stats_red is not None:
+        stats_red.launch(core.last_stats[8:17])
     out[0].backward()
     mark("autograd_done")
     opt.step()
     opt.zero_grad()
     sched.step()
+    if args.exchange != "none" and stats_red is not None:
+        stats_red.result()
     mark("opt_enqueued")
     if it >= W:
         torch.cuda.synchronize()
@@ -78,11 +107,15 @@ for it in range(N):
     mark("step_begin")
     out = step_forward(model, pool[it % 8], params)
     mark("fwd_loss_enqueued")
+    if args.exchange != "none" and stats_red is not None:
+        stats_red.launch(core.last_stats[8:17])
     out[0].backward()
     mark("autograd_done")
     opt.step()
     opt.zero_grad()
     sched.step()
+    if args.exchange != "none" and stats_red is not None:
+        stats_red.result()
     mark("opt_enqueued")
     allm.append(list(marks))
 torch.cuda.synchronize()
@@ -95,3 +128,7 @@ for i, (n, _, _) in enumerate(keep[0]):
 per = sum(allm[k][0][1].elapsed_time(allm[k + 1][0][1]) for k in range(W, N - 1)) / (N - 1 - W)
 hper = sum((allm[k + 1][0][2] - allm[k][0][2]) * 1e3 for k in range(W, N - 1)) / (N - 1 - W)
 print("  step period: gpu %.3f ms, host %.3f ms" % (per, hper))
+if launch_host:
+    print("  host time inside BucketExchange.launch: %.3f ms per launch, %.3f ms per step (%d launches per step)"
+          % (sum(launch_host) / len(launch_host), sum(launch_host) / (2 * N), len(launch_host) // (2 * N)))
+    dist.destroy_process_group()
