@@ -92,6 +92,9 @@ def parse():
                     "ranks would draw (batch R x --batch): the run a data-parallel R-rank run must agree with (config.global_loss)")
     ap.add_argument("--no-dropout", action="store_true", help="test hook: dropout probabilities 0 (run-to-run and rank-count independent losses)")
     ap.add_argument("--exchange-skip", default="", help="timing experiment: comma list of exchange parts to leave out (pack, collective, stats)")
+    ap.add_argument("--prefetch-wgs", type=int, default=-1, help="workgroups of the engine's weight prefetch (0 = off; default: the engine's)")
+    ap.add_argument("--vis-stream", type=int, default=1, help="0: the visual stream's layers on the caller's stream (developer timing experiment)")
+    ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
@@ -285,8 +288,12 @@ def main():
     core.site_policy = site_policy
     # with a gradient exchange the engine's weight gradients share ONE side stream: the exchange (auxiliary stream) then has a
     # hardware queue to itself -- a collective that really moves data must not sit in a compute stream's queue
+    if a.wgrad_wgs >= 0:
+        L.load().crct_gemm_group_max_workgroups(a.wgrad_wgs)
     wg_mode = a.wgrad_streams if a.wgrad_streams >= 0 else (2 if (world > 1 or a.force_exchange) else 1)
-    core.stream_mode = (1, wg_mode)
+    core.stream_mode = (a.vis_stream, wg_mode)
+    if a.prefetch_wgs >= 0:
+        core.prefetch_workgroups = a.prefetch_wgs
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1

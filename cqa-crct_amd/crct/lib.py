@@ -98,6 +98,7 @@ PROTOTYPES = {
     "crct_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "crct_gemm_bf16_grouped": (C.c_int, [C.POINTER(GemmArgs), C.c_int, vp]),
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
+    "crct_gemm_group_max_workgroups": (C.c_int, [C.c_int]),
     "crct_gemm_force_generic": (C.c_int, [C.c_int]),
     "crct_prof_enable": (C.c_int, [C.c_int]),
     "crct_prof_reset": (C.c_int, []),
@@ -125,6 +126,7 @@ PROTOTYPES = {
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
     "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
+    "crct_prefetch": (C.c_int, [vp, c_i64, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
@@ -156,6 +158,7 @@ PROTOTYPES = {
     "crct_event_synchronize": (C.c_int, [vp]),
     "crct_event_query": (C.c_int, [vp]),
     "crct_engine_set_pairing": (C.c_int, [vp, C.c_int]),
+    "crct_engine_set_prefetch": (C.c_int, [vp, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_engine_fp8_sites": (C.c_int, [vp]),
     "crct_engine_fp8_weights": (C.c_int, [vp, vp, vp, C.c_int]),

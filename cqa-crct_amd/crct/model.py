@@ -365,6 +365,8 @@ class CrctModel(nn.Module):
             self._engine = StepEngine(self.config, self.params, mb, mt, mv, self._flat_p.device, self.cls_dropout)
             for pol in getattr(self, "site_policy", ()):          # developer / test overrides of the per-site launch policy
                 self._engine.set_site_policy(**pol)
+            if getattr(self, "prefetch_workgroups", None) is not None:
+                L.check(self._engine.lib.crct_engine_set_prefetch(self._engine.handle, int(self.prefetch_workgroups)), "set_prefetch")
             mode = getattr(self, "stream_mode", None)             # (use_visual_stream, use_wgrad_streams) of crct_engine_set_streams
             if mode is not None:
                 L.check(self._engine.lib.crct_engine_set_streams(self._engine.handle, int(mode[0]), int(mode[1])), "set_streams")

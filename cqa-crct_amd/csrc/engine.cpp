@@ -140,6 +140,8 @@ struct crct_engine {
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
+  int prefetch_wgs = 0;                // workgroups of the weight prefetch one schedule step ahead (crct_engine_set_prefetch).  OFF: measured 7.79-8.04 vs 7.62-7.65 ms
+                                       // per step (the lab gain of 2.4 us per GEMM does not survive in the step)
   bool one_wgrad_stream = false;       // both data streams' weight gradients on ONE side stream (frees a hardware queue for the exchange)
   // paired mode (off by default -- measured 1 ms per step slower in situ; CRCT_PAIR=1 or crct_engine_set_pairing(e, 1)
   // turn it on): from the first co-attention layer on, the
@@ -1135,6 +1137,23 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
   Rt.which = 0; Rv.which = 1;
 }
 
+// Weights are HBM-cold when a GEMM of the step reaches them (each is read once per pass, 476 MB against 256 MB of Infinity
+// Cache), and a GEMM with one or two K tiles in flight per workgroup then pays an HBM round trip per K step: +2.4 us on the
+// 10 us text attention-output GEMM (tools/coldstart_lab.py).  While schedule step i runs, the bf16 weights of step `next` are
+// touched by a few workgroups on a weight-gradient side stream (idle in forward, between two layers' groups in backward).
+void prefetch_step(crct_engine* e, Run& R, const void* p16, int next, const CrctStepCfg* cfg, bool forward) {
+  if (e->prefetch_wgs <= 0 || R.rc || R.sw == R.s || next < 0 || next >= (int)e->sched.size()) return;
+  const int seg = (int)e->sched.size() - next;              // backward segment = gradient / parameter range of that schedule step
+  const auto& r = e->seg_range[seg];
+  if (r.second <= r.first) return;
+  if (forward && cfg->seg_ready_events && cfg->seg_ready_events[seg]) {       // not before the optimizer has rewritten them
+    if (hipStreamWaitEvent(R.sw, (hipEvent_t)cfg->seg_ready_events[seg], 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); R.rc = 1; return; }
+  }
+  const char* base = (const char*)p16 + (size_t)(r.first & ~(int64_t)7) * 2;
+  R.fail(crct_prefetch(base, (int64_t)(r.second - (r.first & ~(int64_t)7)) * 2, e->prefetch_wgs, R.sw));
+  R.sw_dirty = true;
+}
+
 // the split-K ticket words of both data streams start every engine call at zero (an aborted launch must not poison the next)
 int reset_tickets(crct_engine* e, void* ws, hipStream_t s) {
   bool any = false;
@@ -1194,6 +1213,7 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
     if (st.kind == 't') wait_params(Rt, seg);
     else if (st.kind == 'v') wait_params(Rv, seg);
     else { wait_params(Rt, seg); wait_params(Rv, seg); }
+    prefetch_step(e, st.kind == 'v' ? Rv : Rt, params_bf16, step_i, cfg, true);      // step_i is already the NEXT schedule step
     if (st.kind == 't') {
       const SelfLayerA& a = e->tla[st.idx];
       Rt.self_fwd(e->tl[st.idx], a, xt, xtq, site_t, batch->text_keymask, batch->B, batch->T);
@@ -1262,6 +1282,8 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
     const size_t si = in_sched ? e->sched.size() - (size_t)sgi : 0;
     Rt.defer = Rv.defer = paired && in_sched && (int)si >= e->first_conn;
     Rt.phase = (in_sched && (e->first_conn < 0 || (int)si < e->first_conn)) ? 0 : 1;      // backward tail through the text-only layers
+    if (in_sched && si >= 1) prefetch_step(e, e->sched[si].kind == 'v' ? Rv : Rt, params_bf16, (int)si - 1, cfg, false);
+    else if (sgi == 0) prefetch_step(e, Rt, params_bf16, (int)e->sched.size() - 1, cfg, false);
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
       Rt.heads_bwd(Rv, e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
@@ -1396,6 +1418,12 @@ extern "C" crct_stream_t crct_engine_aux_stream(crct_engine_t* e, crct_stream_t 
   if (ensure_streams(e, (hipStream_t)main_stream)) return nullptr;
   if (queue_classes) *queue_classes = e->queue_classes;
   return e->aux;
+}
+
+extern "C" int crct_engine_set_prefetch(crct_engine_t* e, int workgroups) {
+  if (!e || workgroups < 0 || workgroups > 1024) return 1;
+  e->prefetch_wgs = workgroups;
+  return 0;
 }
 
 extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind, int phase, int cfg, int split_k) {

@@ -996,19 +996,29 @@ struct GroupArgs {
   CrctGemmArgs p[GROUP_MAX];           // the problems with their full epilogues (ta / tb are the kernel's template arguments)
 };
 
+// A grid smaller than the tile count (launch_group's max_wgs) makes the workgroups persistent: workgroup b takes tiles b, b + grid,
+// ... -- the weight gradients then occupy at most `grid` CUs' LDS at a time and the data-gradient chain that runs beside them
+// finds free CUs at once (grid a multiple of 8: a workgroup's tiles stay on its XCD's rectangle).
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArgs ga) {
-  int pi = 0;
-  const int bid = blockIdx.x;
+  const int total = ga.tile_begin[ga.n];
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    int pi = 0;
 #pragma unroll
-  for (int i = 1; i < GROUP_MAX; ++i)
-    if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
-  int tm, tn;
-  if (!map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) return;
-  CrctGemmArgs g = ga.p[pi];
-  g.ta = TA; g.tb = TB;
-  gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
+    for (int i = 1; i < GROUP_MAX; ++i)
+      if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
+    int tm, tn;
+    if (map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) {
+      CrctGemmArgs g = ga.p[pi];
+      g.ta = TA; g.tb = TB;
+      gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
+    }
+    if (bid + (int)gridDim.x < total) __syncthreads();      // the next tile's first DMA reuses the ring the epilogue has just read
+  }
 }
+
+static int g_group_max_wgs = 0;        // crct_gemm_group_max_workgroups: 0 = one workgroup per tile
+extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
 
 template <int TM, int TN, int WM, int WN, int NS>
 hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
@@ -1037,7 +1047,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(total), dim3(WM * WN * 64), lds, s, ga);                                                 \
+    launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3(WM * WN * 64), lds, s, ga); \
   } while (0)
   if (gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(true, true);
   else if (!gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(false, true);

@@ -36,7 +36,38 @@ int conflict(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, bool* o
   return 0;
 }
 
+// touch `bytes` bytes: every lane loads 16 bytes per step, 8 loads in flight; the value is kept alive by an asm sink (nothing is
+// written).  The lines land in the Infinity Cache (and in the touching XCD's L2).
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, long n16) {
+  const long stride = (long)gridDim.x * 256;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+  }
+  for (; i < n16; i += stride) { const uint4 v = p[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+  asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));
+}
+
 }  // namespace
+
+// Weights are read once per pass (476 MB of bf16 weights against 256 MB of Infinity Cache): a GEMM of the step finds its
+// weight operand in HBM, and with one or two K tiles in flight per workgroup every K step then waits for an HBM round trip
+// (tools/coldstart_lab.py: the text attention-output GEMM takes 7.6 us with hot operands, 9.8 us from the Infinity Cache,
+// 13.5 us from HBM).  crct_prefetch touches a buffer from a few workgroups on a stream that has nothing better to do, a layer
+// ahead of its use.
+extern "C" int crct_prefetch(const void* ptr, int64_t bytes, int workgroups, crct_stream_t stream) {
+  if (!ptr || bytes <= 0) return 0;
+  const long n16 = bytes / 16;
+  if (workgroups < 1) workgroups = 1;
+  hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const uint4*)ptr, n16);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 // out[0..2]: streams of three queue classes other than main's (nullptr where fewer classes exist), out[3]: a second stream of
 // out[2]'s class (or nullptr); n_classes = queue classes seen (main's included).  Streams not handed out are destroyed.

@@ -97,6 +97,10 @@ int crct_gemm_bf16(const CrctGemmArgs* args, crct_stream_t stream);
 /* n <= 8 independent GEMMs in ONE grid (same ta/tb, no epilogue extras besides the output type and accumulate):
  * the weight gradients of one layer.  Problems that do not qualify are launched one by one. */
 int crct_gemm_bf16_grouped(const CrctGemmArgs* args, int n, crct_stream_t stream);
+/* Cap on the workgroups of a grouped launch (0 = one per tile): with a cap the workgroups are persistent and walk the tiles, so
+ * a layer's weight gradients occupy at most that many CUs at a time beside the data-gradient chain.  Process-wide knob of the
+ * developer tools (bench.py --wgrad-wgs); results are identical for every value. */
+int crct_gemm_group_max_workgroups(int n);
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 
@@ -226,6 +230,9 @@ int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_strea
 int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_stream_t stream);
 
 /* fp32 -> bf16 copy (weight shadow refresh). */
+/* Touch `bytes` bytes at ptr (16-byte aligned) with `workgroups` workgroups: the lines land in the Infinity Cache.  The engine
+ * runs it a layer ahead over the weights the next GEMMs read (they are HBM-cold otherwise: every weight is read once per pass). */
+int crct_prefetch(const void* ptr, int64_t bytes, int workgroups, crct_stream_t stream);
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
 /* bf16 -> fp32 copy (a gradient bucket exchanged as bf16 put back into the fp32 gradient buffer for callers that read .grad). */
 int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream);
@@ -500,6 +507,10 @@ crct_stream_t crct_engine_aux_stream(crct_engine_t*, crct_stream_t main_stream, 
  * (crct_gemm_bf16_grouped with n = 2, crct_layernorm_*_pair) instead of running on two concurrent streams.  Results are
  * bit-identical in both modes.  The fp8 forward always uses the two-stream schedule. */
 int crct_engine_set_pairing(crct_engine_t*, int on);
+/* Weight prefetch: while a schedule step runs, the bf16 weights of the NEXT step (forward) / the previous one (backward) are
+ * touched by `workgroups` workgroups on a weight-gradient side stream, so that the GEMMs find them in the Infinity Cache instead
+ * of in HBM (crct_prefetch).  0 = off.  Only with side streams; reads only -- results are identical. */
+int crct_engine_set_prefetch(crct_engine_t*, int workgroups);
 /* Per-site launch policy of the forward / data-gradient GEMMs (A/B switch of the developer tools and the tests; the defaults
  * are the measured choices).  phase 0 = the text-only part of the schedule (layers t0 .. before the first
  * co-attention layer: nothing else on the chip's data path), phase 1 = beside the visual stream; phase < 0 sets both.

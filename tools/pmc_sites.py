@@ -93,7 +93,7 @@ def main():
             # chip holds less under load: a lower bound of the busy fraction).  GRBM_GUI_ACTIVE / 8 is NOT used as the duration:
             # on dispatches this short it reads 20+ us high (MI355X_MICROARCH.md, DVFS give-back)
             e["mfma_busy_frac_of_chip"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["us_serialised"] * 2400.0 * 1024.0)
-            e["tflops_serialised"] = e["gflop"] / e["us_serialised"] * 1e-3 * 1e3
+            e["tflops_serialised"] = e["gflop"] / e["us_serialised"] * 1e3          # GFLOP / us = PFLOP/s
         sites[key] = e
     out = dict(_source_hash=log.get("source_hash"), _workload=log.get("workload"), _steps=log.get("steps"), _mismatched_dispatches=mismatches,
                _note="per launch averages; dispatches serialised by the profiler (caches / order of the real step, no concurrency)", sites=sites)
