@@ -1083,7 +1083,7 @@ extern "C" void crct_engine_destroy(crct_engine_t* e) {
   if (!e) return;
   for (auto ev : e->evpool) (void)hipEventDestroy(ev);
   for (auto st : e->side) if (st) (void)hipStreamDestroy(st);
-  if (e->aux && e->aux != e->side[0] && e->aux != e->side[1]) (void)hipStreamDestroy(e->aux);
+  if (e->aux) (void)hipStreamDestroy(e->aux);
   delete e;
 }
 extern "C" size_t crct_engine_workspace_bytes(const crct_engine_t* e) { return e ? e->ws_bytes : 0; }
@@ -1106,7 +1106,6 @@ int ensure_streams(crct_engine* e, hipStream_t main) {
     hipStream_t out[4];
     if (int r = crct_streams_place(main, out, &e->queue_classes)) return r;
     e->side[0] = out[0]; e->side[1] = out[1]; e->aux = out[2]; e->side[2] = out[3];
-    if (!e->aux) e->aux = out[1] ? out[1] : out[0];          // fewer than four queue classes: share
   }
   for (int k = 0; k < 3; ++k) {
     const bool need = k == 0 ? e->use_vis_stream : (e->use_wgrad_stream && !(k == 2 && e->one_wgrad_stream));

@@ -100,7 +100,8 @@ int crct_streams_place(hipStream_t main, hipStream_t out[4], int* n_classes) {
     if (rc) break;
     if (home == cls.size()) cls.emplace_back();
     cls[home].push_back(s);
-  }
+    if (i == 5 && cls.size() == 1) break;      // six streams in a row serialise with the caller's: a profiler (rocprofv3 --pmc) or a
+  }                                            // one-queue configuration serialises everything -- placement is moot, take any streams
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   for (int k = 0; k < 4; ++k) out[k] = nullptr;
@@ -115,5 +116,7 @@ int crct_streams_place(hipStream_t main, hipStream_t out[4], int* n_classes) {
     for (int k = 0; k < 4; ++k) kept = kept || out[k] == s;
     if (!kept) (void)hipStreamDestroy(s);
   }
+  for (int k = 0; k < 3 && !rc; ++k)           // fewer than four queue classes: plain streams, wherever they land
+    if (!out[k] && hipStreamCreateWithFlags(&out[k], hipStreamNonBlocking) != hipSuccess) { crct_set_error("streams: cannot create a HIP stream"); rc = 1; }
   return rc;
 }

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r2_bench_n1.json, written by `python bench.py` on the GPU box) keeps the
+"""The committed bench line (profiles/r3_bench_n1.json, written by `python bench.py` on the GPU box) keeps the
 contract the driver parses: metric / unit of BASELINE.json, whole-job value, and the `roofline` and `cpu_baseline`
 objects.  Runs on CPU: it checks the artifact, not the GPU."""
 import json
@@ -7,9 +7,10 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r2_bench_n1.json")
-if not os.path.exists(LINE):
-    LINE = os.path.join(ROOT, "profiles", "r1_bench_n1.json")
+LINE = os.path.join(ROOT, "profiles", "r3_bench_n1.json")
+for _old in ("r2_bench_n1.json", "r1_bench_n1.json"):
+    if not os.path.exists(LINE):
+        LINE = os.path.join(ROOT, "profiles", _old)
 
 
 @pytest.fixture(scope="module")
@@ -46,6 +47,10 @@ def test_roofline_object(line):
     assert r["traffic"] is None or r["traffic"] > 0
     # achieved = algorithmic FLOPs per launch / measured launch duration
     assert abs(r["achieved"] - r["gflop_per_launch"] / r["us_per_launch"] * 1e3) / r["achieved"] < 1e-6    # GFLOP / us = PFLOP/s
+    if "ffn" in r:         # round 3: the kernel group is the FFN GEMMs by model site
+        assert "FFN" in r["kernel"] and r["ffn"]["fwd_dgrad"]["frac"] == r["frac"]
+        for site in ("t.ffn_up.fwd", "t.ffn_down.fwd", "t.ffn_up.dgrad", "t.ffn_down.dgrad", "v.ffn_up.fwd", "v.ffn_down.fwd"):
+            assert 0.0 < r["ffn"][site]["frac"] < 1.0 and r["ffn"][site]["us"] > 0
 
 
 def test_cpu_baseline_object(line):

@@ -23,7 +23,7 @@ GEMM = re.compile(r"gemm_(pipe|splitk|group|f8)?_?kernel<")
 
 
 def kind_of_name(name):
-    m = re.search(r"gemm_(pipe|splitk|group)_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)>", name)
+    m = re.search(r"gemm_(pipe|splitk|group)_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
     if m:
         return "wgrad" if m.group(6) == "true" else ("dgrad" if m.group(7) == "true" else "fwd")
     m = re.search(r"gemm_kernel<(\d+), (\d+), (true|false), (true|false)>", name)
