@@ -97,6 +97,7 @@ def parse():
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
+    ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
                     "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
     ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
@@ -276,6 +277,8 @@ def main():
         cfg = CFG.vilbert_config(v_feature_size=a.feat, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
                                  v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
     params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0, fp8=a.dtype == "fp8")
+    if a.fp8_forward_only:
+        params["fp8_backward"] = False
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
@@ -452,7 +455,9 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
-                                      "; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.dtype == "fp8" else ""),
+                                      ("; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.fp8_forward_only else
+                                       "; fp8 forward QKV / FFN GEMMs (e4m3), fp8 data gradients of the FFN / attention-output Linears (e5m2 x e4m3), bf16 weight gradients")
+                                      if a.dtype == "fp8" else ""),
                           "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                           "global_loss": global_loss, "input": a.input, "host_enqueue_ms_per_step": host_ms,
                           "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None,

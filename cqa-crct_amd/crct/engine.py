@@ -100,6 +100,10 @@ class StepEngine(object):
         if f8 is not None:          # (flat e4m3 weight shadow, weight scales, activation scales, activation amax): device tensors
             c.fp8 = 1
             c.params_fp8, c.fp8_w_scale, c.fp8_act_scale, c.fp8_act_amax = (L.ptr(t) for t in f8)
+        f8b = step.get("fp8_bwd")
+        if f8b is not None and f8 is not None:      # (mode, transposed e4m3 weight shadow, gradient scales, gradient amax)
+            c.fp8_bwd = int(f8b[0])
+            c.params_fp8_t, c.fp8_grad_scale, c.fp8_grad_amax = (L.ptr(t) for t in f8b[1:])
         evs = step.get("seg_events")
         if evs is not None:
             arr = (C.c_void_p * len(evs))(*[ev.cuda_event for ev in evs])

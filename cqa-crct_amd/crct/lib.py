@@ -68,7 +68,8 @@ class LnFwdArgs(C.Structure):
 class LnBwdArgs(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("dx", vp), ("dx_lin", vp), ("partials", vp),
                 ("M", c_i32), ("H", c_i32), ("post_thr", c_u32), ("post_scale", c_f32), ("post_site", c_u32),
-                ("lin_thr", c_u32), ("lin_scale", c_f32), ("lin_site", c_u32), ("seed", c_u64)]
+                ("lin_thr", c_u32), ("lin_scale", c_f32), ("lin_site", c_u32), ("seed", c_u64),
+                ("q_out", vp), ("q_scale", vp), ("q_amax", vp)]
 
 
 class AmpState(C.Structure):
@@ -76,7 +77,7 @@ class AmpState(C.Structure):
 
 
 class Fp8Shadow(C.Structure):
-    _fields_ = [("q", vp), ("seg_slot", vp), ("scale", vp), ("amax", vp)]
+    _fields_ = [("q", vp), ("seg_slot", vp), ("scale", vp), ("amax", vp), ("qt", vp), ("seg_in", vp)]
 
 
 class StepCfg(C.Structure):
@@ -84,6 +85,7 @@ class StepCfg(C.Structure):
                 ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("g_loss_dev", vp),
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
+                ("fp8_bwd", c_i32), ("params_fp8_t", vp), ("fp8_grad_scale", vp), ("fp8_grad_amax", vp),
                 ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32)]
 
 
@@ -123,8 +125,10 @@ PROTOTYPES = {
     "crct_layernorm_fwd_q": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp, vp, vp, vp]),
     "crct_layernorm_fwd_pair": (C.c_int, [C.POINTER(LnFwdArgs), C.POINTER(LnFwdArgs), vp]),
     "crct_layernorm_bwd_rows_pair": (C.c_int, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), vp]),
+    "crct_layernorm_bwd_rows_args": (C.c_int, [C.POINTER(LnBwdArgs), vp]),
+    "crct_fp8_transpose_weights": (C.c_int, [vp] * 6 + [C.c_int, c_i64, C.c_int, vp]),
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
-    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, c_f32, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
     "crct_prefetch": (C.c_int, [vp, c_i64, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
@@ -161,6 +165,7 @@ PROTOTYPES = {
     "crct_engine_set_prefetch": (C.c_int, [vp, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_engine_fp8_sites": (C.c_int, [vp]),
+    "crct_engine_fp8_grad_sites": (C.c_int, [vp]),
     "crct_engine_fp8_weights": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_zero_runs": (C.c_int, [vp, vp, vp, vp, vp, c_i64, vp]),
     "crct_engine_tap": (c_i64, [vp, vp, C.c_char_p, C.c_int, C.c_int, C.c_int, vp, c_i64, vp]),

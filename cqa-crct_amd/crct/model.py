@@ -104,6 +104,9 @@ class CrctModel(nn.Module):
         self._const_zeros = None
         # fp8 forward (BASELINE configs[4], params['fp8']): e4m3 shadow of the QKV / FFN weights + per-tensor delayed scaling
         self.fp8 = bool(params.get("fp8", False)) if params else False
+        # ... and the data-gradient GEMMs of the FFN / attention-output Linears from e5m2 gradients and a transposed e4m3 weight
+        # shadow (params['fp8_backward'] = False keeps the round-2 behaviour: fp8 forward, bf16 backward)
+        self.fp8_backward = self.fp8 and bool(params.get("fp8_backward", True))
         self._fp8 = None
         self._entries = {e.name: e for e in self.table}
         self._build_tree()
@@ -206,6 +209,30 @@ class CrctModel(nn.Module):
             st["seg_len"] = torch.tensor(lens, dtype=torch.int64, device=dev)
             st["seg_slot"] = torch.arange(len(weights), dtype=torch.int32, device=dev)
             st["blk_seg"], st["blk_off"] = blk_seg.to(dev), blk_off.to(dev)
+            # fp8 backward: transposed shadow (same byte offsets, every weight stored [in][out]), gradient scale sites
+            by_off = {e.offset: e for e in self.table}
+            outs, ins, begins, nt, transposed = [], [], [], 0, []
+            for off, num in weights:
+                n_in = by_off[off].shape[1]
+                outs.append(num // n_in)
+                ins.append(n_in)
+                begins.append(nt)
+                # only the weights whose data gradient runs in fp8 (FFN, attention output: single parameter tensors); a fused
+                # QKV weight (three tensors) has a bf16 data gradient and no transposed copy
+                transposed.append(by_off[off].numel == num)
+                if transposed[-1]:
+                    nt += ((num // n_in + 63) // 64) * ((n_in + 63) // 64)
+            st["transposed"] = transposed
+            st["qt"] = torch.zeros(self.total, dtype=torch.uint8, device=dev) if self.fp8_backward else None
+            st["w_out"] = torch.tensor(outs, dtype=torch.int32, device=dev)
+            st["w_in"] = torch.tensor(ins, dtype=torch.int32, device=dev)
+            st["tile_begin"] = torch.tensor(begins, dtype=torch.int64, device=dev)
+            st["n_tiles"] = nt
+            n_g = eng.lib.crct_engine_fp8_grad_sites(eng.handle)
+            st["n_gsites"] = n_g
+            st["g_scale"] = torch.ones(max(n_g, 1), device=dev)
+            st["g_amax"] = torch.zeros(max(n_g, 1) * L.FP8_AMAX_LANES, device=dev)
+            st["bwd_calibrated"] = False
             self._fp8 = st
             self._fp8_requantize()
         return self._fp8
@@ -220,6 +247,29 @@ class CrctModel(nn.Module):
                                                    st["seg_len"].data_ptr(), st["seg_slot"].data_ptr(), st["blk_seg"].data_ptr(),
                                                    st["blk_off"].data_ptr(), st["blk_seg"].numel(), st["w_scale"].data_ptr(),
                                                    st["w_amax"].data_ptr(), len(st["weights"]), L.current_stream()), "fp8_quantize_weights")
+        self._fp8_transpose(L.current_stream())
+
+    def _fp8_update_grad_scales(self, stream):
+        """Gradient scales of the fp8 backward from the maxima the last backward pass collected (delayed scaling).  The fused
+        AdamW calls it on its own stream, off the critical path; without it the next backward pass does it first thing."""
+        st = self._fp8
+        if st is None or not self.fp8_backward or not st.get("bwd_calibrated") or st["n_gsites"] <= 0:
+            return
+        st["g_updates"] = st.get("g_updates", 0) + 1
+        L.check(L.load().crct_fp8_update_scales(st["g_scale"].data_ptr(), st["g_amax"].data_ptr(), st["n_gsites"],
+                                                int(st["g_updates"] % self.FP8_AMAX_WINDOW == 0), None, 57344.0, stream),
+                "fp8_update_scales (gradients)")
+        st["g_scales_fresh"] = True
+
+    def _fp8_transpose(self, stream, max_workgroups=0):
+        """The transposed e4m3 weight shadow the fp8 data-gradient GEMMs read, rebuilt from the shadow (one launch, 2 bytes per
+        shadowed weight element); called whenever the shadow has been rewritten -- here and by the fused AdamW, on its stream."""
+        st = self._fp8
+        if st is None or st.get("qt") is None or not st["weights"]:
+            return
+        L.check(L.load().crct_fp8_transpose_weights(st["q"].data_ptr(), st["qt"].data_ptr(), st["seg_off"].data_ptr(), st["w_out"].data_ptr(),
+                                                    st["w_in"].data_ptr(), st["tile_begin"].data_ptr(), len(st["weights"]), st["n_tiles"],
+                                                    int(max_workgroups), stream), "fp8_transpose_weights")
 
     def _fp8_step_args(self, eng):
         st = self._fp8_state(eng)
@@ -231,7 +281,7 @@ class CrctModel(nn.Module):
         st = self._fp8
         st["updates"] = st.get("updates", 0) + 1
         L.check(L.load().crct_fp8_update_scales(st["a_scale"].data_ptr(), st["a_amax"].data_ptr(), st["n_sites"],
-                                                int(st["updates"] % self.FP8_AMAX_WINDOW == 0), None, L.current_stream()), "fp8_update_scales")
+                                                int(st["updates"] % self.FP8_AMAX_WINDOW == 0), None, 448.0, L.current_stream()), "fp8_update_scales")
 
     def _apply(self, fn, recurse=True):
         probe = fn(torch.zeros(1, device=self._flat_p.device))
@@ -415,6 +465,16 @@ class CrctModel(nn.Module):
                 self._flat_g.zero_()                 # an engine with another owned set: nothing else has been accumulated yet
         self._wgrad_overwrite_next = False           # a further pass before the next clear accumulates
         self._backward_passes = getattr(self, "_backward_passes", 0) + 1
+        if self.fp8_backward and self._fp8 is not None and step.get("fp8") is not None and self._fp8["n_gsites"] > 0:
+            # fp8 data gradients: the first pass only collects the gradient maxima (its GEMMs run in bf16), from then on the e5m2
+            # copies are quantised with the scales of the previous passes (delayed scaling, running maxima over a window)
+            st = self._fp8
+            mode = 1 if st["bwd_calibrated"] else 2
+            if mode == 1 and not st.get("g_scales_fresh"):      # normally done by the optimizer on its stream (_fp8_update_grad_scales)
+                self._fp8_update_grad_scales(L.current_stream())
+            st["g_scales_fresh"] = False
+            st["bwd_calibrated"] = True
+            step = dict(step, fp8_bwd=(mode, st["qt"], st["g_scale"], st["g_amax"]))
         if self._ddp is None and self.record_segment_events:
             evs = self.segment_done_events()
             step = dict(step, seg_done_events=evs)

@@ -88,9 +88,10 @@ def gemm_grouped(problems):
 
 
 def gemm_fp8(Aq, Bq, scale_a, scale_b, M, N, K, bias=None, act="none", preact_out=None, addend=None, p_drop=0.0, site=0, seed=0,
-             out_f32=False, q_out=None, q_scale=None, q_amax=None):
+             out_f32=False, q_out=None, q_scale=None, q_amax=None, a_bf8=False, q_bf8=False, dact_src=None, dact="none"):
     """y = act((Aq / sa) (Bq / sb)^T + bias) from OCP e4m3 operands (uint8 / float8_e4m3fn tensors [M][K], [N][K]); scale_* are
-    device fp32 scalars.  q_out: e4m3 copy of y quantised with q_scale, max |y| max-ed into q_amax."""
+    device fp32 scalars.  q_out: e4m3 copy of y quantised with q_scale, max |y| max-ed into q_amax.  a_bf8: Aq holds OCP e5m2
+    (a gradient: the fp8 data-gradient GEMMs); q_bf8: the q_out copy is e5m2."""
     lib = L.load()
     out = torch.empty(M, N, device=Aq.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     g = L.GemmArgs()
@@ -101,7 +102,8 @@ def gemm_fp8(Aq, Bq, scale_a, scale_b, M, N, K, bias=None, act="none", preact_ou
     g.act, g.c_is_f32, g.tile, g.alpha = ACT[act], int(out_f32), -1, 1.0
     g.drop_thr, g.drop_scale, g.drop_site = _drop(p_drop, site)
     g.seed = seed
-    g.fp8, g.scale_a, g.scale_b = 1, L.ptr(scale_a), L.ptr(scale_b)
+    g.dact_src, g.dact = L.ptr(dact_src), ACT[dact]
+    g.fp8, g.scale_a, g.scale_b = 1 | (2 if a_bf8 else 0) | (4 if q_bf8 else 0), L.ptr(scale_a), L.ptr(scale_b)
     g.q_out, g.q_scale, g.q_amax, g.ld_q = L.ptr(q_out), L.ptr(q_scale), L.ptr(q_amax), N
     L.check(lib.crct_gemm_bf16(C.byref(g), L.current_stream()), "gemm_fp8")
     return out

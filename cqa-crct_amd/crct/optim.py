@@ -87,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
         self.overlap = False
         self.overlap_workgroups = 256        # throttle of the overlapped launches (one workgroup per CU), 0 = full width
+        self.fp8_transpose_workgroups = 256  # same for the transposed fp8 weight shadow that follows the update (fp8 backward)
         # the update zeroes every gradient element it has consumed; the zero_grad() that follows is then free.  Off by
         # default: torch optimizers leave .grad untouched in step() (a caller may still want to read it there)
         self.fuse_zero_grad = False
@@ -100,6 +101,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.early = False
         self._upload_done = None
         self._opt_stream = None
+        self._fp8_transposes = False
         self._seg_blocks = None
         self._events = None
         # expose the moments the way torch.optim.AdamW does (views of the flat buffers)
@@ -176,16 +178,32 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._fp8_keep is None or self._fp8_keep[0] is not st:
             import bisect
             import ctypes as C
-            starts = [o for o, _ in st["weights"]]
-            slots = []
+            by_start = sorted(range(len(st["weights"])), key=lambda i: st["weights"][i][0])      # the engine lists them in model order, not by offset
+            starts = [st["weights"][i][0] for i in by_start]
+            slots, t_in = [], []
+            w_in = st["w_in"].tolist()
             for e in self._segs:                         # AdamW segments are parameter tensors: a fused QKV weight spans three
                 k = bisect.bisect_right(starts, e.offset) - 1
+                k = by_start[k] if k >= 0 else -1
                 inside = k >= 0 and e.offset + e.numel <= st["weights"][k][0] + st["weights"][k][1]
                 slots.append(k if inside else -1)
-            seg_slot = torch.tensor(slots, dtype=torch.int32, device=core.flat_params.device)
+                # transposed shadow (fp8 backward): kept by the update itself where the segment IS the weight, in whole 64 x 64 tiles
+                whole = inside and st.get("qt") is not None and st["transposed"][k] and (e.offset, e.numel) == tuple(st["weights"][k])
+                t_in.append(w_in[k] if (whole and w_in[k] % 64 == 0 and (e.numel // w_in[k]) % 64 == 0) else 0)
+            dev = core.flat_params.device
+            seg_slot = torch.tensor(slots, dtype=torch.int32, device=dev)
+            seg_in = torch.tensor(t_in, dtype=torch.int32, device=dev)
             sh = L.Fp8Shadow()
             sh.q, sh.seg_slot, sh.scale, sh.amax = st["q"].data_ptr(), seg_slot.data_ptr(), st["w_scale"].data_ptr(), st["w_amax"].data_ptr()
-            self._fp8_keep = (st, seg_slot, sh, C.byref(sh))
+            # every weight that has a transposed copy must be covered, or the separate launch stays (crct_fp8_transpose_weights)
+            if set(s for s in slots if s >= 0) != set(range(len(st["weights"]))):
+                raise RuntimeError("fused AdamW: %d of the model's %d fp8-shadowed weights are not covered by optimizer segments; their "
+                                   "shadow would go stale" % (len(st["weights"]) - len(set(s for s in slots if s >= 0)), len(st["weights"])))
+            fused = st.get("qt") is not None and sum(1 for t in t_in if t > 0) == sum(1 for t in st["transposed"] if t)
+            if fused:
+                sh.qt, sh.seg_in = st["qt"].data_ptr(), seg_in.data_ptr()
+            self._fp8_transposes = fused
+            self._fp8_keep = (st, seg_slot, sh, C.byref(sh), seg_in)
         return self._fp8_keep[3]
 
     def _fp8_before_update(self, stream):
@@ -197,7 +215,7 @@ class FusedAdamW(torch.optim.Optimizer):
             st["w_updates"] = st.get("w_updates", 0) + 1
             found = self._amp_keep[1] if (self._amp_arg is not None and self._amp_keep is not None) else None
             L.check(L.load().crct_fp8_update_scales(st["w_scale"].data_ptr(), st["w_amax"].data_ptr(), len(st["weights"]),
-                                                    int(st["w_updates"] % self.core.FP8_AMAX_WINDOW == 0), L.ptr(found), stream),
+                                                    int(st["w_updates"] % self.core.FP8_AMAX_WINDOW == 0), L.ptr(found), 448.0, stream),
                     "fp8_update_scales")
 
     def _plan_overlap(self):
@@ -294,6 +312,13 @@ class FusedAdamW(torch.optim.Optimizer):
             self._upload_hyper()
             self._fp8_before_update(L.current_stream())
             self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
+        if getattr(core, "fp8_backward", False) and self._fp8_arg() is not None:
+            # the update rewrote the e4m3 weight shadow: its transposed copy (fp8 data gradients) follows on the same stream
+            beside = self.overlap and not amp and self._opt_stream is not None
+            side = self._opt_stream.cuda_stream if beside else L.current_stream()
+            if not self._fp8_transposes:                # normally the update kernel has written the transposed copy itself
+                core._fp8_transpose(side, self.fp8_transpose_workgroups if beside else 0)
+            core._fp8_update_grad_scales(side)          # the scales the NEXT backward pass quantises its gradients with
         core.note_params_updated_natively()
         # under GradScaler the kernel returns at once on a skipped step and zeroes nothing: only without it the clear is certain
         self._grads_cleared = bool(self.fuse_zero_grad) and not amp

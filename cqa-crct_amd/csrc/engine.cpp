@@ -95,11 +95,11 @@ struct SelfLayerP { LinearP qkv; ProjP proj; FfnP ffn; int H, heads; float p_att
 struct ConnLayerP { LinearP qkv1, qkv2; ProjP proj_v, proj_t; FfnP ffn_v, ffn_t; uint32_t site; };
 
 // ---- activation offsets (bytes into the workspace)
-struct FfnA { size_t u, h, s, y, mean, rstd, hq, yq; int site_h, site_y; };      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
-struct ProjA { size_t s, a, mean, rstd, aq; int site_a; };
+struct FfnA { size_t u, h, s, y, mean, rstd, hq, yq; int site_h, site_y; int g_dl, g_du; };      // g_*: gradient scale sites (fp8 backward)      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
+struct ProjA { size_t s, a, mean, rstd, aq; int site_a; int g_dl; };
 struct SelfLayerA { size_t qkv, ctx; ProjA proj; FfnA ffn; };
 struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
-struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b; };
+struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b, dlq_a, dlq_b, duq; };      // *q: e5m2 copies (fp8 backward)
 
 struct Step { char kind; int idx; };
 struct Tap { std::string name; size_t off; char stream; };
@@ -136,6 +136,7 @@ struct crct_engine {
   std::unordered_map<int64_t, int> wq_slot;
   std::vector<std::pair<int64_t, int64_t>> wq_list;      // slot -> (flat offset, numel)
   int n_sites = 0;
+  int n_gsites = 0;                    // gradient scale sites of the fp8 backward (CrctStepCfg.fp8_grad_scale / _amax)
   size_t ws_bytes = 0;
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
@@ -201,16 +202,18 @@ LinearP fused3(crct_engine* e, const std::string& a, const std::string& b, const
   return l;
 }
 
-FfnA ffn_a(Arena& ar, size_t M, int H, int I, int& sites) {
+FfnA ffn_a(Arena& ar, size_t M, int H, int I, int& sites, int& gsites) {
   FfnA a;
+  a.g_dl = gsites++; a.g_du = gsites++;
   a.u = ar.take(M * I * 2); a.h = ar.take(M * I * 2); a.s = ar.take(M * H * 2); a.y = ar.take(M * H * 2);
   a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
   a.hq = ar.take(M * I); a.yq = ar.take(M * H);
   a.site_h = sites++; a.site_y = sites++;
   return a;
 }
-ProjA proj_a(Arena& ar, size_t M, int H, int& sites) {
+ProjA proj_a(Arena& ar, size_t M, int H, int& sites, int& gsites) {
   ProjA a;
+  a.g_dl = gsites++;
   a.s = ar.take(M * H * 2); a.a = ar.take(M * H * 2); a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
   a.aq = ar.take(M * H);
   a.site_a = sites++;
@@ -225,6 +228,7 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
   s.dqkv = ar.take(M * (size_t)3 * Hm * 2);
   s.part_a = ar.take((size_t)3 * 4 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);   // [3][4 waves x blocks][H]      // LayerNorm-backward column partials of the layer's two norms
   s.part_b = ar.take((size_t)3 * 4 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);
+  s.dlq_a = ar.take(M * H); s.dlq_b = ar.take(M * H); s.duq = ar.take(M * (size_t)I);
   return s;
 }
 
@@ -325,6 +329,7 @@ struct Run {
     const float* bias = nullptr; void* preact = nullptr; const void* dact_src = nullptr; int dact = 0; int act = 0;
     const void* addend = nullptr; int64_t ld_aux = 0, ld_add = 0; Drop drop; bool f32 = false; bool acc = false;
     int site = 0;
+    void* q_out = nullptr; const float* q_scale = nullptr; float* q_amax = nullptr; int64_t ld_q = 0;      // e5m2 copy of the result (fp8 backward calibration)
   };
   void gemm(const void* Ap, int64_t lda, bool ta, const void* Bp, int64_t ldb, bool tb, void* C, int64_t ldc, int M, int N,
             int K, const Opt& o, hipStream_t st = nullptr) {
@@ -338,6 +343,7 @@ struct Run {
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
     g.site = o.site;
+    if (o.q_out) { g.q_out = o.q_out; g.q_scale = o.q_scale; g.q_amax = o.q_amax; g.ld_q = o.ld_q; g.fp8 = 4; }      // bf16 GEMM + e5m2 copy of its result
     if (!ta && st == s && o.site > 0 && o.site < CRCT_SITE_COUNT) {      // forward / data gradient on the data stream: the site's policy
       const crct_engine::SitePolicy& pol = e->policy[o.site][tb ? 1 : 0][phase];
       if (pol.cfg >= 0) g.tile = pol.cfg;
@@ -365,6 +371,37 @@ struct Run {
   // weight; optionally also emits the e4m3 copy of its own output (hq, site_out) for the next fp8 GEMM
   bool f8() const { return c->fp8 && c->params_fp8 && c->fp8_w_scale && c->fp8_act_scale && c->fp8_act_amax; }
   bool f8_lin(const LinearP& l) const { return f8() && e->wq_slot.count(l.w) != 0; }
+  // ---- fp8 backward (CrctStepCfg.fp8_bwd): data gradients dx = dy W of the FFN and attention-output Linears from the e5m2 copy
+  // of dy (written by the producing LayerNorm-backward / GELU' epilogue, scale site g) and the TRANSPOSED e4m3 weight shadow.
+  // fp8_bwd == 2 (calibration, the first backward pass): the producers collect the gradient maxima, the GEMMs still run in bf16.
+  int f8b() const { return (c->fp8 && c->fp8_bwd && c->params_fp8_t && c->fp8_w_scale && c->fp8_grad_scale && c->fp8_grad_amax) ? c->fp8_bwd : 0; }
+  bool f8b_lin(const LinearP& l) const { return f8b() && e->wq_slot.count(l.w) != 0; }
+  const float* gscale(int g) const { return c->fp8_grad_scale + g; }
+  float* gamax(int g) const { return c->fp8_grad_amax + (int64_t)g * CRCT_FP8_AMAX_LANES; }
+  // dx[M][in] = dyq[M][out] Wt[in][out]^T (+ epilogue); q_out / g_out: optional e5m2 copy of the result for the next data gradient
+  void lin_dgrad_f8(size_t dyq, int g_in, const void* dy_bf16, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, Opt o,
+                    size_t q_out = (size_t)-1, int g_out = -1) {
+    if (rc) return;
+    if (f8b() != 1) {          // calibration pass: the bf16 GEMM, which still emits the e5m2 copy / amax of its result
+      o.site = l.site;
+      if (g_out >= 0) { o.q_out = W<uint8_t>(q_out); o.q_scale = gscale(g_out); o.q_amax = gamax(g_out); o.ld_q = l.in; }
+      gemm(dy_bf16, lddy, false, PB(l.w), l.in, true, dx, lddx, M, l.in, l.out, o);
+      return;
+    }
+    ++tick;
+    CrctGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = W<uint8_t>(dyq); g.B = reinterpret_cast<const uint8_t*>(c->params_fp8_t) + l.w; g.C = dx;
+    g.preact_out = o.preact; g.dact_src = o.dact_src; g.addend = o.addend;
+    g.lda = l.out; g.ldb = l.out; g.ldc = lddx; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
+    g.M = M; g.N = l.in; g.K = l.out; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
+    g.tile = -1; g.alpha = 1.0f; g.seed = c->seed; g.site = l.site;
+    g.fp8 = 1 | 2 | 8;                                   // A = e5m2 gradient, B = e4m3 weight; labelled as a data gradient
+    g.scale_a = gscale(g_in); g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
+    if (g_out >= 0) { g.fp8 |= 4; g.q_out = W<uint8_t>(q_out); g.ld_q = l.in; g.q_scale = gscale(g_out); g.q_amax = gamax(g_out); }
+    if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
+    fail(crct_gemm_bf16(&g, s));
+  }
   void lin_fwd_f8(size_t xq, int site_in, const LinearP& l, int M, void* y, int64_t ldy, Opt o, size_t hq = (size_t)-1, int site_out = -1) {
     if (rc) return;
     ++tick;
@@ -448,19 +485,17 @@ struct Run {
                                              a.drop_site, a.seed, a.q_out, a.q_scale, a.q_amax, st);
     return crct_layernorm_fwd(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale, a.drop_site, a.seed, st);
   }
-  static int launch_ln_bwd(const CrctLnBwdArgs& a, hipStream_t st) {
-    return crct_layernorm_bwd_rows(a.dy, a.x, a.mean, a.rstd, a.gamma, a.dx, a.dx_lin, a.partials, a.M, a.H, a.post_thr, a.post_scale,
-                                   a.post_site, a.lin_thr, a.lin_scale, a.lin_site, a.seed, st);
-  }
+  static int launch_ln_bwd(const CrctLnBwdArgs& a, hipStream_t st) { return crct_layernorm_bwd_rows_args(&a, st); }
   // returns the buffer that holds the gradient of the producing Linear's output
   size_t ln_bwd(size_t dy, size_t x, size_t mean, size_t rstd, const LnP& ln, const LinearP& lin, size_t dres, size_t dlin,
-                size_t part, int M, int H, const Drop& dr) {
+                size_t part, int M, int H, const Drop& dr, size_t dlq = (size_t)-1, int g_site = -1) {
     if (rc) return dres;
     // rows pass on the data stream; the column pass (dgamma, dbeta, bias gradient of the producing Linear) joins the
     // weight-gradient work on the side stream -- `part` belongs to this layer's scratch set
     ++tick;
-    const CrctLnBwdArgs a = {A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
-                             0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed};
+    CrctLnBwdArgs a = {A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
+                       0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, nullptr, nullptr, nullptr};
+    if (g_site >= 0 && f8b() && f8b_lin(lin)) { a.q_out = W<uint8_t>(dlq); a.q_scale = gscale(g_site); a.q_amax = gamax(g_site); }
     if (defer) { QOp op; op.kind = Q_LNB; op.lb = a; q.push_back(op); }
     else fail(launch_ln_bwd(a, s));
     // the column pass is queued like the weight gradients: ONE ordering event per layer covers all of them
@@ -499,10 +534,12 @@ struct Run {
     ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out, a.aq, a.site_a);
   }
   // in: g = grad of a.  out: dres (residual gradient), dctx.  Parameter gradients accumulated.
-  void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, size_t part, int M, const Drop& dr) {
-    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.dense, dres, dlin, part, M, p.dense.out, dr);
+  void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, size_t part, int M, const Drop& dr,
+                size_t dlq) {
+    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.dense, dres, dlin, part, M, p.dense.out, dr, dlq, a.g_dl);
     lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M);
-    lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
+    if (f8b_lin(p.dense)) lin_dgrad_f8(dlq, a.g_dl, A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
+    else lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
   }
   // y = LN(dropout(down(gelu(up(x)))) + x)   vilbert.py:454-471 / :585-602 / :782-786
   // xq / site_x: the e4m3 copy of x and its scale site (the LayerNorm that produced x wrote both)
@@ -519,13 +556,16 @@ struct Run {
   // in: g = grad of a.y.  out: gx = grad of x.
   void ffn_bwd(const FfnP& p, const FfnA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc, int M, const Drop& dr) {
     const int H = p.down.out, I = p.up.out;
-    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.down, sc.dres_a, sc.dlin_a, sc.part_a, M, H, dr);
+    const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.down, sc.dres_a, sc.dlin_a, sc.part_a, M, H, dr, sc.dlq_a, a.g_dl);
     lin_wgrad(A(dl), H, A(a.h), I, p.down, M);
     Opt o; o.dact_src = A(a.u); o.dact = ACT_GELU; o.ld_aux = I;
-    lin_dgrad(A(dl), H, p.down, M, A(sc.du), I, o);
+    const bool q_dn = f8b_lin(p.down), q_up = f8b_lin(p.up);
+    if (q_dn) lin_dgrad_f8(sc.dlq_a, a.g_dl, A(dl), H, p.down, M, A(sc.du), I, o, sc.duq, q_up ? a.g_du : -1);
+    else lin_dgrad(A(dl), H, p.down, M, A(sc.du), I, o);
     lin_wgrad(A(sc.du), I, A(x), H, p.up, M, true);
     Opt o2; o2.addend = A(sc.dres_a); o2.ld_add = H;
-    lin_dgrad(A(sc.du), I, p.up, M, A(gx), H, o2);
+    if (q_dn && q_up) lin_dgrad_f8(sc.duq, a.g_du, A(sc.du), I, p.up, M, A(gx), H, o2);
+    else lin_dgrad(A(sc.du), I, p.up, M, A(gx), H, o2);
   }
 
   // ---------------------------------------------------------------- self-attention layer
@@ -542,7 +582,7 @@ struct Run {
     const int M = B * T, H = p.H, d = H / p.heads;
     const StreamScratch& sc = layer_begin();
     ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
-    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1));
+    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1), sc.dlq_b);
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
              A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
     lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M, true);
@@ -581,8 +621,8 @@ struct Run {
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
     V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
-    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2));   // dctx2 [Mv,Hb]
-    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3));       // dctx1 [Mt,Hb]
+    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2), sv.dlq_b);   // dctx2 [Mv,Hb]
+    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3), st.dlq_b);       // dctx1 [Mt,Hb]
     // each attention backward also writes into the OTHER stream's dqkv scratch, which the layer that used this scratch set
     // last (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading.  With side streams that
     // layer's end is marked by the set's free event (recorded on the side stream behind everything the layer enqueued):
@@ -959,13 +999,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     // fp8 forward: the QKV and FFN Linears whose input width is a whole number of 128-deep fp8 K tiles get an e4m3 weight
     // shadow and a scale slot (the attention-output / dense1 / dense2 projections read bf16 context rows and stay bf16)
     auto slot = [&](const LinearP& l) {
-      if (l.in % 128 != 0 || l.out % 8 != 0) return;
+      if (l.in % 128 != 0 || l.out % 128 != 0) return;      // forward contracts over `in`, the data gradient over `out`: whole fp8 K tiles both ways
       e->wq_slot[l.w] = (int)e->wq_list.size();
       e->wq_list.push_back({l.w, (int64_t)l.in * l.out});
     };
-    for (const SelfLayerP& l : e->tl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); }
-    for (const SelfLayerP& l : e->vl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); }
-    for (const ConnLayerP& l : e->cl) { slot(l.qkv1); slot(l.qkv2); slot(l.ffn_v.up); slot(l.ffn_v.down); slot(l.ffn_t.up); slot(l.ffn_t.down); }
+    // (the attention-output / biOutput projections read bf16 context rows in forward, but their DATA GRADIENT runs in fp8 too: they
+    // get a shadow as well)
+    for (const SelfLayerP& l : e->tl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); slot(l.proj.dense); }
+    for (const SelfLayerP& l : e->vl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); slot(l.proj.dense); }
+    for (const ConnLayerP& l : e->cl) {
+      slot(l.qkv1); slot(l.qkv2); slot(l.ffn_v.up); slot(l.ffn_v.down); slot(l.ffn_t.up); slot(l.ffn_t.down);
+      slot(l.proj_v.dense); slot(l.proj_t.dense);
+    }
   }
 
   // ---- workspace
@@ -981,18 +1026,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->tla.resize(D.L); e->vla.resize(D.Lv); e->cla.resize(D.n_conn);
   for (int i = 0; i < D.L; ++i) {
     SelfLayerA& a = e->tla[i];
-    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.proj = proj_a(ar, Mt, D.H, e->n_sites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites);
+    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.proj = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
   }
   for (int i = 0; i < D.Lv; ++i) {
     SelfLayerA& a = e->vla[i];
-    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.proj = proj_a(ar, Mv, D.Hv, e->n_sites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites);
+    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.proj = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites);
   }
   for (int i = 0; i < D.n_conn; ++i) {
     ConnLayerA& a = e->cla[i];
     a.qkv1 = ar.take(Mv * 3 * D.Hb * 2); a.qkv2 = ar.take(Mt * 3 * D.Hb * 2);
     a.ctx1 = ar.take(Mt * D.Hb * 2); a.ctx2 = ar.take(Mv * D.Hb * 2);
-    a.proj_v = proj_a(ar, Mv, D.Hv, e->n_sites); a.proj_t = proj_a(ar, Mt, D.H, e->n_sites);
-    a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites); a.ffn_t = ffn_a(ar, Mt, D.H, D.I, e->n_sites);
+    a.proj_v = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.proj_t = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites);
+    a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites); a.ffn_t = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
   }
   e->ha.pooled_t = ar.take(B * D.Hb * 2); e->ha.pooled_v = ar.take(B * D.Hb * 2);
   e->ha.t[0] = ar.take(B * D.H * 2); e->ha.t[1] = ar.take(B * 512 * 2); e->ha.t[2] = ar.take(B * 256 * 2);
@@ -1362,6 +1407,7 @@ extern "C" int crct_engine_wgrad_owned(crct_engine_t* e, int64_t* offsets, int64
 }
 
 extern "C" int crct_engine_fp8_sites(const crct_engine_t* e) { return e ? e->n_sites : 0; }
+extern "C" int crct_engine_fp8_grad_sites(const crct_engine_t* e) { return e ? e->n_gsites : 0; }
 extern "C" int crct_engine_fp8_weights(const crct_engine_t* e, int64_t* offsets, int64_t* numels, int cap) {
   if (!e) return -1;
   const int n = (int)e->wq_list.size();

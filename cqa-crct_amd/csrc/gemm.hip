@@ -473,10 +473,18 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
         uint32_t w0 = 0, w1 = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) q_amax = fmaxf(q_amax, fabsf(v[j]));
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[0] * qs), f8_clamp(v[1] * qs), w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[2] * qs), f8_clamp(v[3] * qs), w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[4] * qs), f8_clamp(v[5] * qs), w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[6] * qs), f8_clamp(v[7] * qs), w1, true);
+        if (g.fp8 & 4) {     // e5m2 copy: a gradient that the next data-gradient GEMM reads (largest finite value 57344)
+          auto c5 = [](float x) { return fminf(fmaxf(x, -57344.0f), 57344.0f); };
+          w0 = __builtin_amdgcn_cvt_pk_bf8_f32(c5(v[0] * qs), c5(v[1] * qs), w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_bf8_f32(c5(v[2] * qs), c5(v[3] * qs), w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_bf8_f32(c5(v[4] * qs), c5(v[5] * qs), w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_bf8_f32(c5(v[6] * qs), c5(v[7] * qs), w1, true);
+        } else {
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[0] * qs), f8_clamp(v[1] * qs), w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[2] * qs), f8_clamp(v[3] * qs), w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[4] * qs), f8_clamp(v[5] * qs), w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8_clamp(v[6] * qs), f8_clamp(v[7] * qs), w1, true);
+        }
         *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(g.q_out) + (long)m * g.ld_q + n) = make_uint2(w0, w1);
       }
       if (g.c_is_f32) {
@@ -862,7 +870,8 @@ __device__ __forceinline__ unsigned f8_src_offset(int slot, int r0, int R, long 
   return (r0 + r < R) ? (unsigned)(((long)(r0 + r)) * ld + ch * 16) : OOB_OFF;
 }
 
-template <int TM, int TN, int WM, int WN, int NS>
+// A_BF8: the A operand (a GRADIENT: the data-gradient GEMMs dx = dy W against the transposed e4m3 weight shadow) is OCP e5m2
+template <int TM, int TN, int WM, int WN, int NS, bool A_BF8 = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(const CrctGemmArgs g, const TileMap tmap) {
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
@@ -929,8 +938,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(const CrctGemmArg
 #pragma unroll
       for (int b = 0; b < WTM; ++b) {
         const l2_t am = __builtin_bit_cast(l2_t, fm[h][b]);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bn[0], am[0], acc[a][b], 0, 0, 0);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bn[1], am[1], acc[a][b], 0, 0, 0);
+        if constexpr (A_BF8) {      // first source = the weight fragment (e4m3), second = the gradient fragment (e5m2)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bn[0], am[0], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bn[1], am[1], acc[a][b], 0, 0, 0);
+        } else {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bn[0], am[0], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bn[1], am[1], acc[a][b], 0, 0, 0);
+        }
       }
     }
   };
@@ -965,14 +979,21 @@ hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
   int tiles = 0;
   const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
-  auto kern = gemm_f8_kernel<TM, TN, WM, WN, NS>;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_F8(BF8_)                                                                                               \
+  do {                                                                                                                     \
+    auto kern = gemm_f8_kernel<TM, TN, WM, WN, NS, BF8_>;                                                                  \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                                 \
+  } while (0)
+  if (g.fp8 & 2) CRCT_LAUNCH_F8(true);
+  else CRCT_LAUNCH_F8(false);
+#undef CRCT_LAUNCH_F8
   return hipGetLastError();
 }
 
@@ -1192,7 +1213,8 @@ struct Prof {
   std::vector<CrctLaunchRec> log;
 } g_prof;
 
-inline int kind_of(const CrctGemmArgs& g) { return g.ta ? CRCT_KIND_WGRAD : (g.tb ? CRCT_KIND_DGRAD : CRCT_KIND_FWD); }
+// (an fp8 data gradient reads a TRANSPOSED weight shadow, so it has the forward's operand layout: CrctGemmArgs.fp8 bit 3 says what it is)
+inline int kind_of(const CrctGemmArgs& g) { return g.ta ? CRCT_KIND_WGRAD : ((g.tb || (g.fp8 & 8)) ? CRCT_KIND_DGRAD : CRCT_KIND_FWD); }
 inline int site_of(const CrctGemmArgs& g) { return (g.site > 0 && g.site < CRCT_SITE_COUNT) ? g.site : 0; }
 
 ProfSlot* prof_begin(int variant, const CrctGemmArgs* gs, int n) {
@@ -1296,20 +1318,21 @@ extern "C" int64_t crct_gemm_splitk_ws_elems(int M, int N, int split_k) {
 }
 extern "C" int crct_gemm_splitk_tickets(int M, int N) { return ((M + 127) / 128) * ((N + 63) / 64); }
 static bool splitk_ok(const CrctGemmArgs& g) {
-  return g.split_k > 1 && g.split_k <= 8 && !g.ta && !g.fp8 && !g.rowsum_out && g.splitk_ws && g.splitk_cnt && g.K / BK >= 2 * g.split_k;
+  return g.split_k > 1 && g.split_k <= 8 && !g.ta && !(g.fp8 & 1) && !g.rowsum_out && g.splitk_ws && g.splitk_cnt && g.K / BK >= 2 * g.split_k;
 }
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
   CrctGemmArgs g = g_in;
-  if (g.fp8 && !f8_ok(g)) return hipErrorInvalidValue;
-  if (g.q_out && !g.fp8) return hipErrorInvalidValue;           // the e4m3 output copy exists in the fp8 kernel only
-  const bool pipe = g.fp8 || (pipe_ok(g) && !g_force_generic);
+  const bool is_f8 = (g.fp8 & 1) != 0;                         // bit 0: fp8 operands; bits 1 / 2 qualify the A operand / the q_out copy
+  if (is_f8 && !f8_ok(g)) return hipErrorInvalidValue;
+  const bool pipe = is_f8 || (pipe_ok(g) && !g_force_generic);
+  if (g.q_out && !(pipe && g.q_scale && g.ld_q % 8 == 0)) return hipErrorInvalidValue;      // the fp8 output copy lives in the staged epilogue
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 15 && !(t >= 22 && t <= 35 && pipe && !g.fp8)) t = 12;
+  if (t > 15 && !(t >= 22 && t <= 35 && pipe && !is_f8)) t = 12;
   // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21)
-  if (g.fp8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
+  if (is_f8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
   if (!pipe && t == 0) t = 1;      // the register-staged 128x128 instantiation is 4x slower than 128x64 (measured)
   // K-partitioned launch: the four configurations it is built for; anything else runs unsplit (same function, other summation order)
@@ -1318,7 +1341,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   prof_begin((pipe ? t : 16 + (t & 3)) * 3 + kind_of(g), &g, 1);
   hipError_t e;
   int grid = 0;
-  if (g.fp8) {
+  if (is_f8) {
     e = t == 21 ? launch_f8<4, 2, 4, 2, 3>(g, s) : launch_f8<4, 2, 4, 2, 2>(g, s);
   } else if (pipe && g.split_k) {
     switch (t) {
@@ -1383,7 +1406,7 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
   bool ok = n >= 2 && n <= GROUP_MAX && !g_force_generic;
   for (int i = 0; ok && i < n; ++i) {
     const CrctGemmArgs& g = gs[i];
-    ok = pipe_ok(g) && g.ta == gs[0].ta && g.tb == gs[0].tb && !g.fp8 && !g.q_out && g.M > 96 && (g.ta || !g.rowsum_out);
+    ok = pipe_ok(g) && g.ta == gs[0].ta && g.tb == gs[0].tb && !(g.fp8 & 1) && !g.q_out && g.M > 96 && (g.ta || !g.rowsum_out);
   }
   if (!ok) {
     for (int i = 0; i < n; ++i) {

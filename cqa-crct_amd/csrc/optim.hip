@@ -34,12 +34,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
    inv_bc1 = 1.0f / (1.0f - powf(beta1, st));
    inv_sqrt_bc2 = 1.0f / sqrtf(1.0f - powf(beta2, st));
  }
+ __shared__ uint32_t tile[64][17];          // e4m3 bytes of one 64 x 64 weight tile (transposed shadow), 68-byte rows
  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
   const int sgi = blk_seg[blk];
   const int64_t off = blk_off[blk];
-  const int64_t base = seg_off[sgi] + off;
+  int64_t base = seg_off[sgi] + off;
   int64_t n = seg_len[sgi] - off;
   if (n > ADAMW_CHUNK) n = ADAMW_CHUNK;
+  // A weight [out][in] that also keeps a TRANSPOSED e4m3 shadow (fp8 data gradients) is walked tile by tile instead of chunk by
+  // chunk: chunk number c of the tensor is the 64 x 64 tile (c / (in / 64), c % (in / 64)), so that the workgroup holds whole
+  // columns of the tile and can write them as 16-byte runs of the transposed copy.  Everything else in the update is elementwise.
+  const int tin = (f8.qt && f8.seg_in) ? f8.seg_in[sgi] : 0;
+  int64_t row_stride = 64, t_base = 0;
+  int t_out = 0;
+  if (tin > 0) {
+    const int tiles_in = tin >> 6;
+    const int64_t c = off / ADAMW_CHUNK;
+    const int tr = (int)(c / tiles_in), tc = (int)(c % tiles_in);
+    t_out = (int)(seg_len[sgi] / tin);
+    base = seg_off[sgi] + (int64_t)tr * 64 * tin + (int64_t)tc * 64;
+    row_stride = tin;
+    t_base = seg_off[sgi] + (int64_t)tc * 64 * t_out + (int64_t)tr * 64;
+  }
   const float lr = seg_lr[sgi], wd = seg_wd[sgi];
   const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
   float gsc = inv_scale_dev ? inv_scale_dev[0] : 1.0f;
@@ -50,7 +66,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float qs = qslot >= 0 ? f8.scale[qslot] : 0.f;
   float qmax = 0.f;
   for (int64_t i = (int64_t)threadIdx.x * 4; i < n; i += 1024) {
-    const int64_t e = base + i;
+    const int64_t e = base + (i >> 6) * row_stride + (i & 63);      // row_stride == 64: the plain chunk, e = base + i
     if (i + 4 <= n) {
 #if CRCT_ADAMW_NT      // streamed once per step: non-temporal, so the 7 GB do not evict the forward's operands from L2 / MALL
       const f4_t pv = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p + e));
@@ -94,6 +110,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(pa[0] * qs, -448.f), 448.f), fminf(fmaxf(pa[1] * qs, -448.f), 448.f), w, false);
         w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(pa[2] * qs, -448.f), 448.f), fminf(fmaxf(pa[3] * qs, -448.f), 448.f), w, true);
         *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(f8.q) + e) = w;
+        if (tin > 0) tile[i >> 6][(i & 63) >> 2] = w;
       }
       if (zero_g) __builtin_nontemporal_store(f4_t{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4_t*>(g + e));
     } else {
@@ -113,6 +130,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   if (qslot >= 0) {          // fp8-shadowed tensors are multiples of 4 elements (Linear weights): the scalar tail never holds them
     qmax = wave_max(qmax);
     if ((threadIdx.x & 63) == 0) amax_update(f8.amax + (long)qslot * CRCT_FP8_AMAX_LANES, qmax);
+  }
+  if (tin > 0) {             // uniform over the workgroup (one tensor per chunk)
+    __syncthreads();
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+    const int c = threadIdx.x >> 2, ch = (threadIdx.x & 3) * 16;      // transposed row = in index c, 16 consecutive out indices
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      w[k] = (uint32_t)tb[(ch + 4 * k) * 68 + c] | ((uint32_t)tb[(ch + 4 * k + 1) * 68 + c] << 8) |
+             ((uint32_t)tb[(ch + 4 * k + 2) * 68 + c] << 16) | ((uint32_t)tb[(ch + 4 * k + 3) * 68 + c] << 24);
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(f8.qt) + t_base + (int64_t)c * t_out + ch) = make_uint4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
   }
  }
 }
@@ -167,7 +196,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   CRCT_REQUIRE(step >= 1, "adamw: step must be >= 1 (got %d)", step);
   CrctAmpState amp = {nullptr, nullptr, nullptr};
   if (amp_state) amp = *amp_state;
-  CrctFp8Shadow f8 = {nullptr, nullptr, nullptr, nullptr};
+  CrctFp8Shadow f8 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (fp8_shadow) f8 = *fp8_shadow;
   CRCT_REQUIRE(!f8.q || (f8.seg_slot && f8.scale && f8.amax), "adamw: incomplete fp8 shadow description");
   if (n_blk <= 0) return 0;

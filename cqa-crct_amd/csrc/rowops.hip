@@ -93,6 +93,31 @@ __device__ __forceinline__ float row_store_fp8(const Row<NCH>& r, uint8_t* p, in
   }
   return amax;
 }
+// OCP e5m2 copy of a row (a GRADIENT that the next data-gradient GEMM reads as its fp8 A operand): q = clamp(x * qs, +-57344)
+__device__ __forceinline__ float bf8_clamp(float x) { return fminf(fmaxf(x, -57344.0f), 57344.0f); }
+__device__ __forceinline__ uint2 pack8_bf8(const float (&v)[8], float qs) {
+  uint32_t w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_bf8_f32(bf8_clamp(v[0] * qs), bf8_clamp(v[1] * qs), w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_bf8_f32(bf8_clamp(v[2] * qs), bf8_clamp(v[3] * qs), w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_bf8_f32(bf8_clamp(v[4] * qs), bf8_clamp(v[5] * qs), w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_bf8_f32(bf8_clamp(v[6] * qs), bf8_clamp(v[7] * qs), w1, true);
+  return make_uint2(w0, w1);
+}
+template <int NCH>
+__device__ __forceinline__ float row_store_bf8(const Row<NCH>& r, uint8_t* p, int H, int lane, float qs) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      float v[8];      // the bf16-rounded value, as in row_store_fp8: the bf16 copy (weight gradients) and this one agree
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = bf2f(f2bf(r.v[i][j])); amax = fmaxf(amax, fabsf(v[j])); }
+      *reinterpret_cast<uint2*>(p + c) = pack8_bf8(v, qs);
+    }
+  }
+  return amax;
+}
 template <int NCH>
 __device__ __forceinline__ void row_load_f32(Row<NCH>& r, const float* p, int H, int lane) {
   float4 a[NCH], b[NCH];
@@ -541,6 +566,7 @@ struct LnBwdP {
   const bf16_t* dy; const bf16_t* x; const float* mean; const float* rstd; const float* gamma; bf16_t* dx; bf16_t* dxl;
   float* partials; int M, H; uint32_t post_thr; float post_scale; uint32_t post_site; uint32_t lin_thr; float lin_scale;
   uint32_t lin_site; uint64_t seed;
+  uint8_t* q_out; const float* q_scale; float* q_amax;       // optional e5m2 copy of the gradient the producing Linear's dgrad reads (dxl if given, else dx)
 };
 template <int NCH, bool COMBINE>
 __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, const int nblk) {
@@ -555,6 +581,8 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, cons
   Row<NCH> adg, adb, adl, g;
   row_zero(adg); row_zero(adb); row_zero(adl);
   row_load_f32(g, gamma, H, lane);
+  const float qs = a.q_out ? a.q_scale[0] : 0.f;
+  float q_amax = 0.f;
   // M / (4 x grid) is 1.6 rows per wave at the CRCT sizes: the second row's loads are issued before the first row is worked on
   const long stride = (long)nblk * ROWS_PER_BLOCK;
   long row = (long)blk * ROWS_PER_BLOCK + wave;
@@ -582,7 +610,12 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, cons
       row_apply_dropmask(dy, H, lane, row, lin_thr, lin_scale, lin_site, seed);
       row_store_bf16(dy, dxl_p + row * H, H, lane);
     }
+    if (a.q_out) q_amax = fmaxf(q_amax, row_store_bf8(dy, a.q_out + row * H, H, lane, qs));
     row_acc(adl, dy);
+  }
+  if (a.q_out && a.q_amax) {
+    q_amax = wave_max(q_amax);
+    if (lane == 0) amax_update(a.q_amax, q_amax);
   }
   if constexpr (COMBINE) {
     extern __shared__ __attribute__((aligned(16))) float ln_lds[];      // [3][4][H]
@@ -1048,7 +1081,8 @@ static bool ln_bwd_combines(int H) {
 }
 static LnBwdP ln_bwd_problem(const CrctLnBwdArgs& a) {
   return LnBwdP{(const bf16_t*)a.dy, (const bf16_t*)a.x, a.mean, a.rstd, a.gamma, (bf16_t*)a.dx, (bf16_t*)a.dx_lin, a.partials,
-                a.M, a.H, a.post_thr, a.post_scale, a.post_site, a.lin_thr, a.lin_scale, a.lin_site, a.seed};
+                a.M, a.H, a.post_thr, a.post_scale, a.post_site, a.lin_thr, a.lin_scale, a.lin_site, a.seed,
+                (uint8_t*)a.q_out, a.q_scale, a.q_amax};
 }
 static int ln_bwd_launch(const CrctLnBwdArgs& a, hipStream_t s) {
   CRCT_REQUIRE(a.H % 8 == 0 && a.H > 0, "layernorm_bwd: H=%d must be a positive multiple of 8", a.H);
@@ -1068,8 +1102,12 @@ int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, co
                             uint32_t post_site, uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
                             crct_stream_t stream) {
   const CrctLnBwdArgs a = {dy, x, mean, rstd, gamma, dx, dx_lin, partials, M, H, post_thr, post_scale, post_site, lin_thr, lin_scale,
-                           lin_site, seed};
+                           lin_site, seed, nullptr, nullptr, nullptr};
   return ln_bwd_launch(a, (hipStream_t)stream);
+}
+int crct_layernorm_bwd_rows_args(const CrctLnBwdArgs* a, crct_stream_t stream) {
+  CRCT_REQUIRE(a && (!a->q_out || a->q_scale), "layernorm_bwd_rows_args: bad arguments");
+  return ln_bwd_launch(*a, (hipStream_t)stream);
 }
 // The rows passes of two independent LayerNorm backwards in ONE launch (see crct_layernorm_fwd_pair); every problem keeps
 // the partial-row geometry of its own single launch, so crct_layernorm_bwd_finalize is unchanged.
@@ -1233,18 +1271,62 @@ __global__ __launch_bounds__(256) void fp8_weights_kernel(const float* __restric
     }
   }
 }
+// Transposed e4m3 weight shadow for the fp8 DATA-GRADIENT GEMMs: dx = dy W contracts over W's rows, and the fp8 kernel wants the
+// contraction index contiguous in both operands, so every shadowed weight [out][in] is also kept as [in][out].  One workgroup per
+// 64 x 64 byte tile through LDS (16-byte global accesses on both sides); run once per optimizer step behind the update.
+__global__ __launch_bounds__(256) void fp8_transpose_kernel(const uint8_t* __restrict__ q, uint8_t* __restrict__ qt,
+                                                            const int64_t* __restrict__ w_off, const int32_t* __restrict__ w_out,
+                                                            const int32_t* __restrict__ w_in, const int64_t* __restrict__ tile_begin, int n_w,
+                                                            long n_tiles) {
+  __shared__ uint8_t t[64][80];
+  // persistent grid: behind an overlapped AdamW the launch is capped (max_workgroups) so that it does not take the CUs from the
+  // forward pass that is starting beside it -- uncapped, its 51k workgroups cost the step 0.33 ms (EXPERIMENTS.md, round 3)
+  for (long bid = blockIdx.x; bid < n_tiles; bid += gridDim.x) {
+  int lo = 0, hi = n_w - 1;                        // the weight this tile belongs to: last i with tile_begin[i] <= bid
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_begin[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int wi = lo;
+  const int out = w_out[wi], in = w_in[wi];
+  const int tiles_in = (in + 63) / 64;
+  const long tl = bid - tile_begin[wi];
+  const int r0 = (int)(tl / tiles_in) * 64, c0 = (int)(tl % tiles_in) * 64;       // rows = out index, columns = in index
+  const uint8_t* src = q + w_off[wi];
+  uint8_t* dst = qt + w_off[wi];
+  {
+    const int r = threadIdx.x >> 2, ch = (threadIdx.x & 3) * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < out && c0 + ch < in) v = *reinterpret_cast<const uint4*>(src + (long)(r0 + r) * in + c0 + ch);
+    *reinterpret_cast<uint4*>(&t[r][ch]) = v;
+  }
+  __syncthreads();
+  {
+    const int c = threadIdx.x >> 2, ch = (threadIdx.x & 3) * 16;       // output row = in index c0 + c, 16 consecutive out indices
+    if (c0 + c < in && r0 + ch < out) {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        w[k] = (uint32_t)t[ch + 4 * k][c] | ((uint32_t)t[ch + 4 * k + 1][c] << 8) | ((uint32_t)t[ch + 4 * k + 2][c] << 16) | ((uint32_t)t[ch + 4 * k + 3][c] << 24);
+      *reinterpret_cast<uint4*>(dst + (long)(c0 + c) * out + r0 + ch) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  __syncthreads();
+  }
+}
+
 // delayed scaling: scale[i] = 448 / max(amax[i][0 .. LANES)) for the entries that saw data.  The maxima are RUNNING maxima
 // (reset != 0 clears them: the caller does that every few hundred steps, the "max over a history window" of the usual fp8
 // recipes): a wave only issues an atomic when it raises the word it reports into, so after the first steps of a window the
 // kernels issue none at all -- resetting every step cost 2.4 ms per step in atomic storms (round-2 measurement).
-__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n, int reset, const float* __restrict__ skip_if) {
+__global__ void fp8_update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, int n, int reset, const float* __restrict__ skip_if, float fmax) {
   if (skip_if && skip_if[0] != 0.f) return;      // a skipped optimizer step (GradScaler found inf / nan) leaves the shadow, hence its scales, alone
   const int i = blockIdx.x * (blockDim.x / CRCT_FP8_AMAX_LANES) + threadIdx.x / CRCT_FP8_AMAX_LANES, l = threadIdx.x % CRCT_FP8_AMAX_LANES;
   if (i < n) {          // one wave (64 lanes = LANES) per entry
     float* w = amax + (long)i * CRCT_FP8_AMAX_LANES + l;
     const float a = wave_max(*w);
     if (reset) *w = 0.f;
-    if (l == 0 && a > 0.f) scale[i] = 448.0f / a;
+    if (l == 0 && a > 0.f) scale[i] = fmax / a;
   }
 }
 
@@ -1261,10 +1343,11 @@ int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* am
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, crct_stream_t stream) {
+int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, float fmax, crct_stream_t stream) {
   CRCT_REQUIRE(scale && amax && n >= 0, "fp8_update_scales: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset, skip_if);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset, skip_if,
+                     fmax > 0.f ? fmax : 448.0f);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1278,9 +1361,21 @@ int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, c
   CRCT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)n_slots * CRCT_FP8_AMAX_LANES * 4, s));
   hipLaunchKernelGGL(fp8_weights_kernel<0>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0, (const float*)nullptr);
+  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0, (const float*)nullptr, 448.0f);
   hipLaunchKernelGGL(fp8_weights_kernel<1>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_fp8_transpose_weights(const void* q, void* qt, const int64_t* w_off, const int32_t* w_out, const int32_t* w_in,
+                               const int64_t* tile_begin, int n_w, int64_t n_tiles, int max_workgroups, crct_stream_t stream) {
+  CRCT_REQUIRE(q && qt && w_off && w_out && w_in && tile_begin, "fp8_transpose_weights: null argument");
+  if (n_w <= 0 || n_tiles <= 0) return 0;
+  long grid = n_tiles < 1048576 ? n_tiles : 1048576;
+  if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
+  hipLaunchKernelGGL(fp8_transpose_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)q, (uint8_t*)qt,
+                     w_off, w_out, w_in, tile_begin, n_w, (long)n_tiles);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

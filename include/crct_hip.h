@@ -62,7 +62,8 @@ typedef struct CrctGemmArgs {
    * lda / ldb % 16 == 0), quantised per tensor as q = x * scale; the fp32 product is divided by (*scale_a) * (*scale_b)
    * (device scalars: delayed scaling never syncs the host).  q_out: optional e4m3 copy of the epilogue's result
    * [M][ld_q], quantised with *q_scale, while max |result| is max-ed into *q_amax (fp32 bits, >= 0) for the next step's scale. */
-  int32_t fp8;
+  int32_t fp8;              /* bit 0: fp8 GEMM; bit 1 (2): A is OCP e5m2 (a gradient) instead of e4m3; bit 2 (4): q_out is e5m2;
+                               bit 3 (8): a data gradient (profiling label only: its operand layout is the forward's) */
   const float* scale_a; const float* scale_b;
   void* q_out; const float* q_scale; float* q_amax; int64_t ld_q;
   /* Which Linear of the model this launch belongs to (CRCT_SITE_*; 0 = untagged): only read by the live profile
@@ -163,7 +164,8 @@ int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct
 #define CRCT_FP8_AMAX_LANES 64
 /* fp8 (OCP e4m3, per-tensor delayed scaling) helpers.  All scales / amax values are device fp32.
  *  crct_fp8_quantize_bf16   q[i] = e4m3(x[i] * *scale), *amax = max(*amax, max |x|)            (n % 8 == 0)
- *  crct_fp8_update_scales   scale[i] = 448 / amax[i] where amax[i] > 0; reset != 0 also clears amax[i]; skip_if (device fp32,
+ *  crct_fp8_update_scales   scale[i] = fmax / amax[i] where amax[i] > 0 (fmax = 448 for e4m3 tensors, 57344 for the e5m2
+ *                           gradient copies of the fp8 backward; <= 0 means 448); reset != 0 also clears amax[i]; skip_if (device fp32,
  *                           may be NULL) != 0 leaves everything untouched (GradScaler's found_inf: a skipped optimizer step
  *                           does not requantise the weight shadow, so its scales must stay too).  The amax values are
  *                           RUNNING maxima: call it once per step with reset = 0 and every few hundred steps with reset = 1
@@ -173,10 +175,17 @@ int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct
  *                           (blk_seg, blk_off) from crct_adamw_plan; writes scale[slot] = 448 / max |w|.  Used at start-up
  *                           and after a load_state_dict; the optimizer keeps the shadow current afterwards (CrctFp8Shadow). */
 int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* amax, int64_t n, crct_stream_t stream);
-int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, crct_stream_t stream);
+int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, float fmax, crct_stream_t stream);
 int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, const int64_t* seg_len, const int32_t* seg_slot,
                               const int32_t* blk_seg, const int64_t* blk_off, int64_t n_blk, float* scale, float* amax, int n_slots,
                               crct_stream_t stream);
+/* Transposed copy of the e4m3 weight shadow for the fp8 data-gradient GEMMs (dx = dy W contracts over W's rows): weight i lies
+ * at byte offset w_off[i] of q as [w_out[i]][w_in[i]] and is written to the same offset of qt as [w_in[i]][w_out[i]]
+ * (w_out, w_in multiples of 16).  tile_begin[i] = first 64 x 64 tile of weight i in the launch grid, n_tiles = their total.
+ * All arrays device memory.  Run once per optimizer step behind the update that rewrote q.  max_workgroups > 0 caps the launch
+ * (a persistent grid): beside a forward pass that is starting on another stream the full grid would take its CUs. */
+int crct_fp8_transpose_weights(const void* q, void* qt, const int64_t* w_off, const int32_t* w_out, const int32_t* w_in,
+                               const int64_t* tile_begin, int n_w, int64_t n_tiles, int max_workgroups, crct_stream_t stream);
 
 /* LayerNorm backward.  dy bf16 [M][H] (gradient w.r.t. y, or w.r.t. post-norm-dropout output when
  * post_* is set), x = saved pre-norm rows.  Writes
@@ -210,7 +219,12 @@ typedef struct CrctLnBwdArgs {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* gamma; void* dx; void* dx_lin; float* partials;
   int32_t M, H; uint32_t post_thr; float post_scale; uint32_t post_site; uint32_t lin_thr; float lin_scale; uint32_t lin_site;
   uint64_t seed;
+  /* fp8 backward (BASELINE configs[4]): optional OCP e5m2 copy [M][H] of the gradient that leaves towards the producing Linear
+   * (dx_lin when given, else dx), quantised as q = g * *q_scale (saturating at +-57344), max |g| max-ed into *q_amax
+   * (CRCT_FP8_AMAX_LANES words): the A operand of that Linear's fp8 data-gradient GEMM. */
+  void* q_out; const float* q_scale; float* q_amax;
 } CrctLnBwdArgs;
+int crct_layernorm_bwd_rows_args(const CrctLnBwdArgs* a, crct_stream_t stream);      /* crct_layernorm_bwd_rows from the struct (incl. q_out) */
 int crct_layernorm_bwd_rows_pair(const CrctLnBwdArgs* a, const CrctLnBwdArgs* b, crct_stream_t stream);
 int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin,
                                 int M, int H, int accumulate, crct_stream_t stream);
@@ -385,8 +399,13 @@ int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_strea
  * seg_slot[s] = scale slot of AdamW segment s (-1: tensor has no fp8 shadow), scale = device fp32 [n_slots], amax = device fp32
  * [n_slots * CRCT_FP8_AMAX_LANES].  The update
  * quantises the NEW weights with scale[slot] and max-es max |w| into amax[slot]; the caller runs crct_fp8_update_scales on
- * (scale, amax) before the NEXT update (delayed scaling).  All pointers device memory; q == NULL switches it off. */
-typedef struct CrctFp8Shadow { void* q; const int32_t* seg_slot; const float* scale; float* amax; } CrctFp8Shadow;
+ * (scale, amax) before the NEXT update (delayed scaling).  All pointers device memory; q == NULL switches it off.
+ * qt / seg_in (both or neither; may be NULL): the TRANSPOSED shadow of the fp8 data-gradient GEMMs (crct_fp8_transpose_weights'
+ * layout) kept current by the update itself: seg_in[s] > 0 = segment s is a whole weight [seg_len / seg_in][seg_in] (both
+ * multiples of 64) whose bytes are also written to qt as [seg_in][seg_len / seg_in]; 0 = no transposed copy of that segment.
+ * The update then walks such a weight in 64 x 64 tiles, which costs one extra byte written per element and no extra launch
+ * (a separate transposing launch beside the next forward pass cost the step 0.12-0.33 ms: EXPERIMENTS.md, round 3). */
+typedef struct CrctFp8Shadow { void* q; const int32_t* seg_slot; const float* scale; float* amax; void* qt; const int32_t* seg_in; } CrctFp8Shadow;
 int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap);
 int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
                     const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
@@ -463,6 +482,13 @@ typedef struct CrctStepCfg {
    *   fp8_act_amax    device fp32 [same]: max |activation| seen by this pass, for the caller's crct_fp8_update_scales */
   int32_t fp8;
   const void* params_fp8; const float* fp8_w_scale; const float* fp8_act_scale; float* fp8_act_amax;
+  /* fp8 backward (configs[4], backward only; needs fp8 != 0).  fp8_bwd = 1: the data-gradient GEMMs of the FFN and attention-output
+   * Linears (dx = dy W) read an OCP e5m2 copy of dy -- written by the producing LayerNorm-backward kernel / GELU' epilogue with the
+   * per-site scales fp8_grad_scale[crct_engine_fp8_grad_sites()], maxima into fp8_grad_amax -- and the TRANSPOSED e4m3 weight
+   * shadow params_fp8_t (crct_fp8_transpose_weights of params_fp8; weight scales = fp8_w_scale).  fp8_bwd = 2: calibration -- the
+   * maxima are collected, the GEMMs run in bf16 (the first backward pass).  Weight gradients and the QKV data gradient stay bf16. */
+  int32_t fp8_bwd;
+  const void* params_fp8_t; const float* fp8_grad_scale; float* fp8_grad_amax;
   /* Host callback of crct_engine_backward(seg < 0): invoked on the calling thread, INSIDE the call, right after the four
    * seg_done_events of segment s have been recorded -- i.e. while the host is still enqueuing the rest of backward.  A
    * data-parallel caller launches the gradient all-reduce of the bucket that segment s completes from here (behind those
@@ -530,6 +556,7 @@ int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const in
 /* fp8 forward: number of activation scale sites, and the (flat offset, element count) of every weight that has an e4m3 shadow
  * (index = its slot in CrctStepCfg.fp8_w_scale).  Both are fixed at crct_engine_create. */
 int crct_engine_fp8_sites(const crct_engine_t*);
+int crct_engine_fp8_grad_sites(const crct_engine_t*);      /* gradient scale sites of the fp8 backward (CrctStepCfg.fp8_grad_scale) */
 int crct_engine_fp8_weights(const crct_engine_t*, int64_t* offsets, int64_t* numels, int cap);
 /* Ordering events for same-device stream dependencies of the host-side glue (optimizer overlap, data-parallel buckets, the
  * CrctStepCfg event arrays): created without timing and without the system-scope fence a default HIP / torch event carries in

@@ -40,6 +40,11 @@ def gelu_erf(x):
 # (per-tensor scale 448 / max |.|), the backward uses the UNquantised operands -- what the HIP path does (bf16 backward from
 # the saved activations).  Switched on by ``FP8_EMULATION = True``.
 FP8_EMULATION = False
+# ... and of its fp8 BACKWARD (round 3): the data gradients dx = dy W of the FFN Linears and of the attention-output / biOutput
+# projections multiply an OCP e5m2 rounding of dy (per-tensor scale 57344 / max |dy|) with the e4m3 rounding of the weight; the QKV
+# data gradients and every weight gradient use the unquantised operands.  Switched on by ``FP8_BWD_EMULATION = True`` (with
+# FP8_EMULATION).
+FP8_BWD_EMULATION = False
 _FP8_SUFFIXES = ("self.query", "self.key", "self.value", "query1", "key1", "value1", "query2", "key2", "value2",
                  "intermediate.dense", "v_intermediate.dense", "t_intermediate.dense")
 
@@ -49,18 +54,27 @@ def _fp8_round(t):
     return (t * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype) / s
 
 
+def _bf8_round(t):
+    s = 57344.0 / float(t.detach().abs().max().clamp_min(1e-30))
+    return (t * s).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(t.dtype) / s
+
+
 class _Fp8Linear(torch.autograd.Function):
+    """fwd_q: the forward multiplies e4m3 roundings of x and w; bwd_q: the data gradient multiplies an e5m2 rounding of gy with the
+    e4m3 rounding of w.  The weight / bias gradients always use the unquantised operands."""
+
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, fwd_q=True, bwd_q=False):
         ctx.save_for_backward(x, w)
-        return F.linear(_fp8_round(x), _fp8_round(w), b)
+        ctx.bwd_q = bwd_q
+        return F.linear(_fp8_round(x), _fp8_round(w), b) if fwd_q else F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = gy @ w
+        gx = (_bf8_round(gy) @ _fp8_round(w)) if ctx.bwd_q else gy @ w
         gw = gy.reshape(-1, gy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
-        return gx, gw, gy.reshape(-1, gy.shape[-1]).sum(0)
+        return gx, gw, gy.reshape(-1, gy.shape[-1]).sum(0), None, None
 
 
 def _fp8_linear_site(prefix, in_features):
@@ -72,10 +86,24 @@ def _fp8_linear_site(prefix, in_features):
         prefix.endswith("t_output.dense")
 
 
+_FP8_QKV = ("self.query", "self.key", "self.value", "query1", "key1", "value1", "query2", "key2", "value2")
+
+
+def _fp8_dgrad_site(prefix, w):
+    """Linears whose DATA gradient the product computes in fp8: FFN up / down and the attention-output / biOutput projections
+    (both weight dimensions whole 128-deep fp8 K tiles); not the QKV projections."""
+    if w.shape[0] % 128 != 0 or w.shape[1] % 128 != 0 or prefix.endswith(_FP8_QKV):
+        return False
+    return prefix.endswith(("intermediate.dense", "output.dense", "biOutput.dense1", "biOutput.dense2"))
+
+
 def linear(sd, prefix, x):
     w = sd[prefix + ".weight"]
-    if FP8_EMULATION and ".encoder." in prefix and _fp8_linear_site(prefix, w.shape[1]):
-        return _Fp8Linear.apply(x, w, sd[prefix + ".bias"])
+    if FP8_EMULATION and ".encoder." in prefix:
+        fwd_q = _fp8_linear_site(prefix, w.shape[1])
+        bwd_q = FP8_BWD_EMULATION and _fp8_dgrad_site(prefix, w)
+        if fwd_q or bwd_q:
+            return _Fp8Linear.apply(x, w, sd[prefix + ".bias"], fwd_q, bwd_q)
     return F.linear(x, w, sd[prefix + ".bias"])
 
 

@@ -6,6 +6,7 @@ fp32 reference evaluated on the SAME bf16-rounded operands the only differences 
 order and the final bf16 rounding of the output: |err| <= 1e-2 * max|ref| for bf16 outputs,
 <= 2e-3 * max|ref| for fp32 outputs.
 """
+import ctypes as C
 import math
 
 import pytest
@@ -450,6 +451,63 @@ def test_gemm_fp8_forward(M, N, K):
     assert float(((deq - href).abs() - tol).max()) <= 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(1600, 3072, 768), (1600, 768, 3072), (2880, 1024, 1024), (300, 1024, 768)])
+def test_gemm_fp8_data_gradient(M, N, K):
+    """The fp8 BACKWARD GEMM: dx[M][N = in] = dy[M][K = out] W[out][in] as e5m2(dy) x e4m3(W^T) -- the A operand is OCP e5m2, the B
+    operand the transposed e4m3 weight shadow [in][out] -- with the GELU' epilogue and an e5m2 copy of the result (what the
+    FFN-down data gradient hands to the FFN-up one).  Against fp32 matmul of the same dequantised operands."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 1)
+    dy = torch.randn(M, K, generator=g) * 3e-3
+    wt = torch.randn(N, K, generator=g) * 0.05                  # = W^T: [in][out]
+    u = (torch.randn(M, N, generator=g)).to(torch.bfloat16).to(DEV)
+    sa, sb = 57344.0 / float(dy.abs().max()), 448.0 / float(wt.abs().max())
+    dyq = (dy * sa).clamp(-57344, 57344).to(torch.float8_e5m2).to(DEV)
+    wq = _q8(wt, sb).to(DEV)
+    sa_d, sb_d = torch.tensor([sa], device=DEV), torch.tensor([sb], device=DEV)
+    ref = (dyq.float() / sa) @ (wq.float() / sb).t()
+    dx = ops.gemm_fp8(dyq, wq, sa_d, sb_d, M, N, K, out_f32=True, a_bf8=True)
+    assert float((dx - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    # x gelu'(u), e5m2 copy of the result + its amax
+    uf = u.float()
+    gprime = 0.5 * (1 + torch.erf(uf / math.sqrt(2))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2 * math.pi)
+    ref2 = ref * gprime
+    q_out = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+    qs = torch.tensor([57344.0 / float(ref2.abs().max()) * 0.5], device=DEV)
+    amax = torch.zeros(L.FP8_AMAX_LANES, device=DEV)
+    du = ops.gemm_fp8(dyq, wq, sa_d, sb_d, M, N, K, a_bf8=True, q_bf8=True, dact_src=u, dact="gelu", q_out=q_out, q_scale=qs, q_amax=amax)
+    assert float((du.float() - ref2).abs().max()) <= 1e-2 * float(ref2.abs().max())
+    assert abs(float(amax.max()) - float(ref2.abs().max())) <= 1e-2 * float(ref2.abs().max())
+    deq = q_out.view(torch.float8_e5m2).float() / float(qs)
+    tol = 0.125 * ref2.abs() + 1e-2 * float(ref2.abs().max())          # e5m2: 2 mantissa bits -> half an ulp = 2^-3 relative
+    assert float(((deq - ref2).abs() - tol).max()) <= 0.0
+
+
+def test_layernorm_bwd_emits_the_e5m2_gradient_copy():
+    """CrctLnBwdArgs.q_out: the gradient that leaves the LayerNorm-backward kernel towards the producing Linear, also as OCP e5m2
+    (the A operand of that Linear's fp8 data gradient), quantised from the bf16-rounded value; its maximum in q_amax."""
+    lib = L.load()
+    M, H = 1600, 768
+    dy, x = bf(rand(M, H, scale=2e-3, seed=1)), bf(rand(M, H, seed=2))
+    gamma = rand(H, seed=3)
+    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-12)
+    dx_ref, dxl_ref, _, _, _ = ops.layernorm_bwd(dy, x, mean, rstd, gamma, want_lin=True, p_lin=0.1, lin_site=7, seed=5)
+    a = L.LnBwdArgs()
+    dx, dxl = torch.empty_like(x), torch.empty_like(x)
+    nb = lib.crct_layernorm_bwd_blocks(M)
+    part = torch.empty(3 * 4 * nb * H, device=DEV)
+    q = torch.zeros(M, H, dtype=torch.uint8, device=DEV)
+    qs, am = torch.tensor([4096.0], device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV)
+    a.dy, a.x, a.mean, a.rstd, a.gamma, a.dx, a.dx_lin, a.partials = (L.ptr(t) for t in (dy, x, mean, rstd, gamma, dx, dxl, part))
+    a.M, a.H, a.post_thr, a.post_scale, a.post_site = M, H, 0, 1.0, 0
+    a.lin_thr, a.lin_scale, a.lin_site, a.seed = L.drop_threshold(0.1), 1.0 / 0.9, 7, 5
+    a.q_out, a.q_scale, a.q_amax = L.ptr(q), L.ptr(qs), L.ptr(am)
+    L.check(lib.crct_layernorm_bwd_rows_args(C.byref(a), L.current_stream()), "layernorm_bwd_rows_args")
+    assert torch.equal(dx, dx_ref) and torch.equal(dxl, dxl_ref)
+    want = (dxl_ref.float() * 4096.0).clamp(-57344, 57344).to(torch.float8_e5m2)
+    assert torch.equal(q.view(torch.float8_e5m2).float(), want.float())
+    assert float(am.max()) == float(dxl_ref.float().abs().max())
+
+
 def test_fp8_quantisers_and_layernorm_copy():
     lib = L.load()
     # bf16 -> e4m3 pass
@@ -461,10 +519,10 @@ def test_fp8_quantisers_and_layernorm_copy():
     assert float(am.max()) == float(x.float().abs().max())
     # skip_if != 0 (GradScaler's found_inf): the call must leave scale AND amax untouched
     skip = torch.ones(1, device=DEV)
-    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, skip.data_ptr(), L.current_stream()))
+    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, skip.data_ptr(), 448.0, L.current_stream()))
     assert float(sc) == 17.0 and float(am.max()) == float(x.float().abs().max())
     skip.zero_()
-    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, skip.data_ptr(), L.current_stream()))
+    L.check(lib.crct_fp8_update_scales(sc.data_ptr(), am.data_ptr(), 1, 1, skip.data_ptr(), 448.0, L.current_stream()))
     assert abs(float(sc) - 448.0 / float(x.float().abs().max())) < 1e-4 * float(sc) and float(am.abs().max()) == 0.0
     # LayerNorm with the e4m3 copy: the copy is the quantisation of the bf16 output the kernel stores
     xs = (torch.randn(1600, 768, device=DEV)).to(torch.bfloat16)
