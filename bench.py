@@ -55,7 +55,8 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               10: "dma128x64w8s3", 11: "dma64x128w8s3", 12: "dma128x64w8s2", 13: "dma128x64w8s4", 14: "dma128x64w8s6", 15: "dma128x64w8s3", 16: "reg128x128", 17: "reg128x64",
               18: "reg64x128", 19: "reg64x64", 20: "f8e4m3_128x64w8s2", 21: "f8e4m3_128x64w8s3", 22: "dma160x128w4s2", 23: "dma160x128w4s3",
               24: "dma160x96w4s3", 25: "dma160x96w4s2", 26: "dma96x64w4s3", 27: "dma96x64w4s4", 28: "dma160x64w4s3", 29: "dma64x96w4s4", 30: "dma160x128w4s3p", 31: "dma160x128w4s2p",
-              32: "dma128x128w4s3p", 33: "dma128x128w8s3p", 34: "dma256x128w8s3p", 35: "dma160x96w4s3p"}
+              32: "dma128x128w4s3p", 33: "dma128x128w8s3p", 34: "dma256x128w8s3p", 35: "dma160x96w4s3p",
+              36: "f8t_128x128w8s3", 37: "f8t_128x128w8s2"}
 KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
@@ -97,6 +98,7 @@ def parse():
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
+    ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
     ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
                     "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
@@ -279,6 +281,8 @@ def main():
     params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0, fp8=a.dtype == "fp8")
     if a.fp8_forward_only:
         params["fp8_backward"] = False
+    if a.fp8_bf16_wgrad:
+        params["fp8_wgrad"] = False
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)

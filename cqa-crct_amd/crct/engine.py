@@ -103,7 +103,8 @@ class StepEngine(object):
         f8b = step.get("fp8_bwd")
         if f8b is not None and f8 is not None:      # (mode, transposed e4m3 weight shadow, gradient scales, gradient amax)
             c.fp8_bwd = int(f8b[0])
-            c.params_fp8_t, c.fp8_grad_scale, c.fp8_grad_amax = (L.ptr(t) for t in f8b[1:])
+            c.params_fp8_t, c.fp8_grad_scale, c.fp8_grad_amax = (L.ptr(t) for t in f8b[1:4])
+            c.fp8_wgrad = int(bool(f8b[4])) if len(f8b) > 4 else 0
         evs = step.get("seg_events")
         if evs is not None:
             arr = (C.c_void_p * len(evs))(*[ev.cuda_event for ev in evs])

@@ -85,7 +85,7 @@ class StepCfg(C.Structure):
                 ("reg_coeff", c_f32), ("grad_scale", c_f32), ("seed", c_u64), ("g_nsp_dev", vp), ("g_reg_dev", vp), ("g_loss_dev", vp),
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
-                ("fp8_bwd", c_i32), ("params_fp8_t", vp), ("fp8_grad_scale", vp), ("fp8_grad_amax", vp),
+                ("fp8_bwd", c_i32), ("fp8_wgrad", c_i32), ("params_fp8_t", vp), ("fp8_grad_scale", vp), ("fp8_grad_amax", vp),
                 ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32)]
 
 

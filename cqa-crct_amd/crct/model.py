@@ -107,6 +107,8 @@ class CrctModel(nn.Module):
         # ... and the data-gradient GEMMs of the FFN / attention-output Linears from e5m2 gradients and a transposed e4m3 weight
         # shadow (params['fp8_backward'] = False keeps the round-2 behaviour: fp8 forward, bf16 backward)
         self.fp8_backward = self.fp8 and bool(params.get("fp8_backward", True))
+        # ... and the FFN weight gradients from the same fp8 copies (params['fp8_wgrad'] = False: bf16 weight gradients)
+        self.fp8_wgrad = self.fp8_backward and bool(params.get("fp8_wgrad", True))
         self._fp8 = None
         self._entries = {e.name: e for e in self.table}
         self._build_tree()
@@ -474,7 +476,7 @@ class CrctModel(nn.Module):
                 self._fp8_update_grad_scales(L.current_stream())
             st["g_scales_fresh"] = False
             st["bwd_calibrated"] = True
-            step = dict(step, fp8_bwd=(mode, st["qt"], st["g_scale"], st["g_amax"]))
+            step = dict(step, fp8_bwd=(mode, st["qt"], st["g_scale"], st["g_amax"], self.fp8_wgrad))
         if self._ddp is None and self.record_segment_events:
             evs = self.segment_done_events()
             step = dict(step, seg_done_events=evs)

@@ -126,6 +126,28 @@ def gemm_wgrad_grouped(problems):
     L.check(lib.crct_gemm_bf16_grouped(arr, len(problems), L.current_stream()), "gemm_grouped")
 
 
+def gemm_wgrad_fp8(problems, accumulate=True, tile=-1):
+    """fp8 weight gradients: ``problems`` = [(dyq[R][N] e5m2, xq[R][K] e4m3, scale_dy, scale_x, out[N][K] fp32)]:
+    out (+)= (dyq / s_dy)^T (xq / s_x) with fp32 accumulation; one launch for two or more problems, R (tokens) arbitrary,
+    N and K multiples of 16."""
+    lib = L.load()
+    arr = (L.GemmArgs * len(problems))()
+    for g, (dyq, xq, s_dy, s_x, out) in zip(arr, problems):
+        _chk(out, torch.float32)
+        R, N = dyq.shape
+        K = xq.shape[1]
+        assert xq.shape[0] == R and out.shape == (N, K) and dyq.element_size() == 1 and xq.element_size() == 1
+        g.A, g.B, g.C = L.ptr(dyq), L.ptr(xq), L.ptr(out)
+        g.lda, g.ldb, g.ldc, g.ld_aux, g.ld_add = N, K, K, K, K
+        g.M, g.N, g.K, g.ta, g.tb = N, K, R, 1, 1
+        g.c_is_f32, g.accumulate, g.tile, g.alpha = 1, int(accumulate), tile, 1.0
+        g.fp8, g.scale_a, g.scale_b = 1 | 2, L.ptr(s_dy), L.ptr(s_x)
+    if len(problems) == 1:
+        L.check(lib.crct_gemm_bf16(C.byref(arr[0]), L.current_stream()), "gemm_wgrad_fp8")
+    else:
+        L.check(lib.crct_gemm_bf16_grouped(arr, len(problems), L.current_stream()), "gemm_wgrad_fp8 (grouped)")
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-12, p_drop=0.0, site=0, seed=0):
     lib = L.load()
     M, H = x.shape

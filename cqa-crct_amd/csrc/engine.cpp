@@ -255,6 +255,9 @@ int order_streams(crct_engine* e, hipStream_t from, hipStream_t to) {
   return 0;
 }
 
+// fp8 copies of a weight gradient's operands (Run::lin_wgrad)
+struct WgQ8 { size_t dyq = (size_t)-1; int g_dy = -1; size_t xq = (size_t)-1; int site_x = -1; };
+
 struct Run {
   crct_engine* e;
   const float* p32; const bf16_t* p16; float* g32; char* ws; hipStream_t s;
@@ -420,9 +423,14 @@ struct Run {
   // dW[out][in] += dy^T x
   // with_bias: also db[out] += column sums of dy.  When the contraction length qualifies for the LDS-DMA kernel the
   // sums come out of the weight-gradient kernel itself (CrctGemmArgs.rowsum_out); otherwise a column-sum launch.
-  void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M, bool with_bias = false) {
+  // q8: the fp8 copies of both operands where the other passes left them (fp8 backward, CrctStepCfg.fp8_wgrad): dy as OCP e5m2
+  // with gradient scale site g_dy, x as e4m3 with activation scale site site_x -- the weight gradient then reads half the bytes
+  // (gemm.hip, fp8 weight gradients); the bias gradient still sums the bf16 dy.
+  void lin_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const LinearP& l, int M, bool with_bias = false, WgQ8 q8 = WgQ8()) {
     if (rc) return;
-    const bool fold = with_bias && M % 64 == 0 && l.in % 8 == 0 && l.out % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0;
+    const bool f8w = f8b() == 1 && c->fp8_wgrad && defer_wgrad && q8.g_dy >= 0 && q8.site_x >= 0 && q8.dyq != (size_t)-1 && q8.xq != (size_t)-1 &&
+                     l.in % 16 == 0 && l.out % 16 == 0 && lddy % 16 == 0 && ldx % 16 == 0;
+    const bool fold = !f8w && with_bias && M % 64 == 0 && l.in % 8 == 0 && l.out % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0;
     if (with_bias && !fold) bias_grad(dy, lddy, l, M);
     if (rc) return;
     CrctGemmArgs g;
@@ -435,6 +443,12 @@ struct Run {
       g.accumulate = 0;               // the only producer of this gradient: write it, whatever the buffer held
     }
     if (fold) g.rowsum_out = G(l.b);
+    if (f8w) {
+      g.A = W<uint8_t>(q8.dyq); g.B = W<uint8_t>(q8.xq); g.fp8 = 1 | 2; g.tile = 37;
+      g.scale_a = gscale(q8.g_dy); g.scale_b = c->fp8_act_scale + q8.site_x;
+      pending_f8.push_back(g);
+      return;
+    }
     if (!defer_wgrad) { ++tick; fail(crct_gemm_bf16(&g, s)); return; }     // head chain: in order, right now
     // queued also without a side stream (sw == s): the same groups, hence the same kernels and summation orders,
     // in every stream mode -- results stay bit-identical across modes
@@ -447,8 +461,9 @@ struct Run {
     gemm(dy, lddy, false, PB(l.w), l.in, true, dx, lddx, M, l.in, l.out, o);
   }
   // launch the queued weight-gradient GEMMs on the side stream, ordered after everything enqueued on s so far
+  std::vector<CrctGemmArgs> pending_f8;      // the layer's fp8 weight gradients: one grouped launch of their own
   void flush_wgrads() {
-    if (rc || (pending.empty() && pending_fin.empty() && pending_bias.empty())) return;
+    if (rc || (pending.empty() && pending_f8.empty() && pending_fin.empty() && pending_bias.empty())) return;
     if (sw == s) ++tick;
     wgrad_after_main();
     for (const BiasJob& j : pending_bias)
@@ -460,6 +475,9 @@ struct Run {
     for (size_t i = 0; i < pending.size() && !rc; i += 8)
       fail(crct_gemm_bf16_grouped(pending.data() + i, (int)std::min<size_t>(8, pending.size() - i), sw));
     pending.clear();
+    for (size_t i = 0; i < pending_f8.size() && !rc; i += 8)
+      fail(crct_gemm_bf16_grouped(pending_f8.data() + i, (int)std::min<size_t>(8, pending_f8.size() - i), sw));
+    pending_f8.clear();
   }
   // db[out] += column sums of dy: queued like the weight gradients (dy stays valid until the layer's flush), so the data
   // stream carries no ordering event per call -- the head chain alone had 13 of them between its 13 small data-gradient GEMMs
@@ -554,15 +572,19 @@ struct Run {
     ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out, a.yq, a.site_y);
   }
   // in: g = grad of a.y.  out: gx = grad of x.
-  void ffn_bwd(const FfnP& p, const FfnA& a, size_t x, size_t g, size_t gx, const StreamScratch& sc, int M, const Drop& dr) {
+  // xq / site_x: the e4m3 copy of x the forward pass read (fp8 weight gradient of the up projection)
+  void ffn_bwd(const FfnP& p, const FfnA& a, size_t x, size_t xq, int site_x, size_t g, size_t gx, const StreamScratch& sc, int M, const Drop& dr) {
     const int H = p.down.out, I = p.up.out;
     const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.down, sc.dres_a, sc.dlin_a, sc.part_a, M, H, dr, sc.dlq_a, a.g_dl);
-    lin_wgrad(A(dl), H, A(a.h), I, p.down, M);
-    Opt o; o.dact_src = A(a.u); o.dact = ACT_GELU; o.ld_aux = I;
     const bool q_dn = f8b_lin(p.down), q_up = f8b_lin(p.up);
+    WgQ8 w_dn, w_up;
+    if (q_dn && f8_lin(p.up) && f8_lin(p.down)) { w_dn.dyq = sc.dlq_a; w_dn.g_dy = a.g_dl; w_dn.xq = a.hq; w_dn.site_x = a.site_h; }      // hq exists when both forward GEMMs ran in fp8
+    if (q_dn && q_up && f8_lin(p.up)) { w_up.dyq = sc.duq; w_up.g_dy = a.g_du; w_up.xq = xq; w_up.site_x = site_x; }
+    lin_wgrad(A(dl), H, A(a.h), I, p.down, M, false, w_dn);
+    Opt o; o.dact_src = A(a.u); o.dact = ACT_GELU; o.ld_aux = I;
     if (q_dn) lin_dgrad_f8(sc.dlq_a, a.g_dl, A(dl), H, p.down, M, A(sc.du), I, o, sc.duq, q_up ? a.g_du : -1);
     else lin_dgrad(A(dl), H, p.down, M, A(sc.du), I, o);
-    lin_wgrad(A(sc.du), I, A(x), H, p.up, M, true);
+    lin_wgrad(A(sc.du), I, A(x), H, p.up, M, true, w_up);
     Opt o2; o2.addend = A(sc.dres_a); o2.ld_add = H;
     if (q_dn && q_up) lin_dgrad_f8(sc.duq, a.g_du, A(sc.du), I, p.up, M, A(gx), H, o2);
     else lin_dgrad(A(sc.du), I, p.up, M, A(gx), H, o2);
@@ -581,7 +603,7 @@ struct Run {
     // (paired mode: the launches are only queued here, so the layer's weight-gradient flush waits for pair_flush -- end_pending)
     const int M = B * T, H = p.H, d = H / p.heads;
     const StreamScratch& sc = layer_begin();
-    ffn_bwd(p.ffn, a.ffn, a.proj.a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
+    ffn_bwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
     proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1), sc.dlq_b);
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
              A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
@@ -619,8 +641,8 @@ struct Run {
     hipEvent_t free_v = V.set_free[V.parity], free_t = set_free[parity];      // "the last readers of this scratch set are done"
     const StreamScratch& sv = V.layer_begin(); const StreamScratch& st = layer_begin();
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
-    V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
-    ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
+    V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, a.proj_v.aq, a.proj_v.site_a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
+    ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, a.proj_t.aq, a.proj_t.site_a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
     V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2), sv.dlq_b);   // dctx2 [Mv,Hb]
     proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3), st.dlq_b);       // dctx1 [Mt,Hb]
     // each attention backward also writes into the OTHER stream's dqkv scratch, which the layer that used this scratch set

@@ -1007,6 +1007,176 @@ inline bool f8_ok(const CrctGemmArgs& g) {
   return (long)g.M * g.lda < 0x7f000000L && (long)g.N * g.ldb < 0x7f000000L;
 }
 
+
+// ====================================================================================== fp8 weight gradients (BASELINE configs[4])
+// dW[out][in] = dy^T x with the operands AS THE FORWARD / DATA-GRADIENT PASSES LEFT THEM: dy [tokens][out] OCP e5m2 (the copy the
+// LayerNorm-backward kernel / the GELU' epilogue wrote for the fp8 data gradient), x [tokens][in] e4m3 (the copy the forward GEMM
+// read).  Both are stored with the CONTRACTION index (tokens) as the row index, so a 128-token K tile of an operand is an image of
+// 128 rows x BM bytes, and an MFMA operand -- 8 consecutive tokens of one column per lane -- is one ds_read_b64_tr_b8: lane 2q + p
+// of a 16-lane group addresses row q, bytes 8p .. 8p + 7 of an 8-row x 16-byte block, lane i receives column i (measured layout,
+// tools/lab/tr8_probe.hip).  Image layout in 16-byte slots (row k, 16-byte column chunk ch, W64 = BM / 64):
+//   slot = 32 * ((k >> 3) * W64 + (ch >> 2)) + 4 * (k & 7) + ((ch & 3) ^ ((k >> 2) & 1) ^ 2 * ((k >> 3) & 1))
+// i.e. 512-byte blocks of 8 rows x 64 bytes; the XOR spreads the 16 rows a 32-lane half reads in one instruction over the 16
+// slots of a 256-byte bank row.  Half the operand bytes of the bf16 kernel travel L2 -> LDS per token; the K tail (tokens % 128)
+// is zero-filled by the buffer range check, rows beyond the tensor likewise.
+template <int W64>
+__device__ __forceinline__ int f8t_slot(int k, int ch) {
+  return 32 * ((k >> 3) * W64 + (ch >> 2)) + 4 * (k & 7) + ((ch & 3) ^ ((k >> 2) & 1) ^ (2 * ((k >> 3) & 1)));
+}
+template <int W64>
+__device__ __forceinline__ unsigned f8t_src_offset(int slot, int c0, int C, long ld, int k_lim) {
+  const int blk = slot >> 5, sb = slot & 31, kb = blk / W64, cb = blk % W64, kq = sb >> 2;
+  const int k = 8 * kb + kq, ch = 4 * cb + ((sb & 3) ^ ((kq >> 2) & 1) ^ (2 * (kb & 1)));
+  return (k < k_lim && c0 + 16 * ch < C) ? (unsigned)((long)k * ld + c0 + 16 * ch) : OOB_OFF;
+}
+template <int OFF>
+__device__ __forceinline__ long lds_read_tr8_imm(uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  long v;
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void frag_async_use(long& f) { asm volatile("" : "+v"(f)); }
+
+template <int TM, int TN, int WM, int WN, int NS>
+__device__ __forceinline__ void gemm_f8t_body(const CrctGemmArgs& g, int tile_m, int tile_n) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN, KT = 128;
+  constexpr int A_BYTES = KT * BM, B_BYTES = KT * BN, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW, L = PA + PB;
+  constexpr int WTM = BM / WM / 16, WTN = BN / WN / 16;
+  constexpr int AW = BM / 64, BW = BN / 64;
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "64-byte image blocks");
+  static_assert(PA >= 1 && PB >= 1 && PA * NW * 1024 == A_BYTES && PB * NW * 1024 == B_BYTES, "tile / wave-grid mismatch");
+  static_assert(WTM <= 4 && WTN <= 4 && (BM / WM) % (16 * WTM) == 0, "a wave's columns stay inside one 64-byte block row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)OOB_OFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)OOB_OFF, 0x00020000);
+  const int nk = (g.K + KT - 1) / KT, k_tail = g.K - (nk - 1) * KT;       // tokens in the last K tile: 1 .. 128
+  unsigned offA[PA], offB[PB], offAt[PA], offBt[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    offA[i] = f8t_src_offset<AW>((i * NW + wave) * 64 + lane, m0, g.M, g.lda, KT);
+    offAt[i] = f8t_src_offset<AW>((i * NW + wave) * 64 + lane, m0, g.M, g.lda, k_tail);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    offB[i] = f8t_src_offset<BW>((i * NW + wave) * 64 + lane, n0, g.N, g.ldb, KT);
+    offBt[i] = f8t_src_offset<BW>((i * NW + wave) * 64 + lane, n0, g.N, g.ldb, k_tail);
+  }
+  f4_t acc[WTN][WTM];
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int kt, int st) {
+    char* base = smem + st * STAGE + wave * 1024;
+    const bool tail = kt == nk - 1;
+    const int sa = kt * KT * (int)g.lda, sb = kt * KT * (int)g.ldb;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + i * NW * 1024), 16, (int)(tail ? offAt[i] : offA[i]), sa, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NW * 1024), 16, (int)(tail ? offBt[i] : offB[i]), sb, 0, 0);
+  };
+  const int npre = nk < NS - 1 ? nk : NS - 1;
+  for (int t = 0; t < npre; ++t) issue(t, t);
+
+  // per-lane fragment bases (K step h = 0; step h adds 2048 * W64 bytes: four 8-row blocks further down, same parities)
+  const int fg = lane >> 4, fq = (lane & 15) >> 1, fp = lane & 1;
+  uint32_t bA[WTM], bB[WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) bA[i] = 16 * f8t_slot<AW>(8 * fg + fq, (wm * (BM / WM)) / 16 + i) + 8 * fp;
+#pragma unroll
+  for (int i = 0; i < WTN; ++i) bB[i] = A_BYTES + 16 * f8t_slot<BW>(8 * fg + fq, (wn * (BN / WN)) / 16 + i) + 8 * fp;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+  constexpr int NR = WTM + WTN;
+  static_assert(2 * NR <= 15, "two K steps of fragment reads in flight");
+  auto wait_tile = [&](int t) {
+    const int ahead = (nk - 1 < t + NS - 2 ? nk - 1 : t + NS - 2) - t;
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+  };
+  int st = 0, st_next = NS - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_tile(kt);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
+    const uint32_t stage = smem_base + st * STAGE;
+    long fa[4][WTM], fb[4][WTN];
+    static_for<4>([&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      static_for<WTM>([&](auto ic) { constexpr int i = decltype(ic)::value; fa[h][i] = lds_read_tr8_imm<h * 2048 * AW>(stage + bA[i]); });
+      static_for<WTN>([&](auto ic) { constexpr int i = decltype(ic)::value; fb[h][i] = lds_read_tr8_imm<h * 2048 * BW>(stage + bB[i]); });
+      if constexpr (h >= 1) {             // multiply step h - 1 while step h's reads are in flight
+        frag_async_wait<NR>();
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fa[h - 1][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fb[h - 1][i]);
+#pragma unroll
+        for (int a = 0; a < WTN; ++a)
+#pragma unroll
+          for (int b = 0; b < WTM; ++b)     // first source = the activation fragment (e4m3), second = the gradient fragment (e5m2)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb[h - 1][a], fa[h - 1][b], acc[a][b], 0, 0, 0);
+        asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));
+      }
+    });
+    frag_async_wait<0>();
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) frag_async_use(fa[3][i]);
+#pragma unroll
+    for (int i = 0; i < WTN; ++i) frag_async_use(fb[3][i]);
+#pragma unroll
+    for (int a = 0; a < WTN; ++a)
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb[3][a], fa[3][b], acc[a][b], 0, 0, 0);
+    st_next = st;
+    st = st + 1 == NS ? 0 : st + 1;
+  }
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  int tile_m, tile_n;
+  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
+  gemm_f8t_body<TM, TN, WM, WN, NS>(g, tile_m, tile_n);
+}
+
+template <int TM, int TN, int WM, int WN, int NS>
+hipError_t launch_f8t(const CrctGemmArgs& g, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  int tiles = 0;
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  auto kern = gemm_f8t_kernel<TM, TN, WM, WN, NS>;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);
+  return hipGetLastError();
+}
+
+// the fp8 weight-gradient kernel: both operands token-major bytes with 16-byte aligned rows, fp32 or bf16 result, no fused row sums
+inline bool f8t_ok(const CrctGemmArgs& g) {
+  if (!g.ta || !g.tb || !(g.fp8 & 2) || g.K < 1 || g.lda % 16 != 0 || g.ldb % 16 != 0 || g.M % 16 != 0 || g.N % 16 != 0) return false;
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || g.ldc % 8 != 0 || !g.scale_a || !g.scale_b || g.rowsum_out || g.q_out) return false;
+  if (g.preact_out || g.dact_src || g.addend || g.drop_thr || g.bias) return false;
+  return (long)g.K * g.lda < 0x7f000000L && (long)g.K * g.ldb < 0x7f000000L;
+}
+
 // ---- grouped launch: up to 8 independent GEMMs of the same mode in ONE grid (the weight gradients of one
 // layer: 4-6 small problems that individually leave most CUs idle).  Block -> (problem, tile) by prefix table.
 constexpr int GROUP_MAX = 8;
@@ -1075,6 +1245,47 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   else if (!gs[0].ta && !gs[0].tb) CRCT_LAUNCH_GROUP(false, false);
   else return hipErrorInvalidValue;
 #undef CRCT_LAUNCH_GROUP
+  return hipGetLastError();
+}
+
+// the fp8 weight gradients of a layer in one grid (same block -> (problem, tile) table, gemm_f8t_body per tile)
+template <int TM, int TN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_group_kernel(const GroupArgs ga) {
+  const int total = ga.tile_begin[ga.n];
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+      if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
+    int tm, tn;
+    if (map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) gemm_f8t_body<TM, TN, WM, WN, NS>(ga.p[pi], tm, tn);
+    if (bid + (int)gridDim.x < total) __syncthreads();
+  }
+}
+template <int TM, int TN, int WM, int WN, int NS>
+hipError_t launch_group_f8t(const CrctGemmArgs* gs, int n, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  GroupArgs ga = {};
+  ga.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    ga.tile_begin[i] = total;
+    int grid = 0;
+    ga.map[i] = make_tile_map(gs[i].M, gs[i].N, BM, BN, &grid);
+    ga.map[i].dbg = 0;
+    total += grid;
+    ga.p[i] = gs[i];
+  }
+  ga.tile_begin[n] = total;
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  auto kern = gemm_f8t_group_kernel<TM, TN, WM, WN, NS>;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3(WM * WN * 64), lds, s, ga);
   return hipGetLastError();
 }
 
@@ -1325,6 +1536,15 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
   CrctGemmArgs g = g_in;
   const bool is_f8 = (g.fp8 & 1) != 0;                         // bit 0: fp8 operands; bits 1 / 2 qualify the A operand / the q_out copy
+  if (is_f8 && g.ta) {                                         // fp8 weight gradient (token-major operands): ids 36 (3 stages) / 37 (2 stages)
+    if (!f8t_ok(g)) return hipErrorInvalidValue;
+    const int t8 = g.tile == 37 ? 37 : 36;
+    prof_begin(t8 * 3 + kind_of(g), &g, 1);
+    const hipError_t e8 = t8 == 37 ? launch_f8t<4, 4, 2, 4, 2>(g, s) : launch_f8t<4, 4, 2, 4, 3>(g, s);
+    g_time_start = g_time_stop = nullptr;
+    log_launch(&g, 1, t8, 0);
+    return e8;
+  }
   if (is_f8 && !f8_ok(g)) return hipErrorInvalidValue;
   const bool pipe = is_f8 || (pipe_ok(g) && !g_force_generic);
   if (g.q_out && !(pipe && g.q_scale && g.ld_q % 8 == 0)) return hipErrorInvalidValue;      // the fp8 output copy lives in the staged epilogue
@@ -1403,6 +1623,16 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
 // forward / data-gradient GEMMs of the text and the visual side of a co-attention layer or of two independent layers
 // (n = 2): one grid, one ramp, the tiles of both problems packed over the CUs.
 hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s) {
+  bool all_f8t = n >= 2 && n <= GROUP_MAX;
+  for (int i = 0; all_f8t && i < n; ++i) all_f8t = (gs[i].fp8 & 1) && gs[i].ta && f8t_ok(gs[i]);
+  if (all_f8t) {                    // the fp8 weight gradients of a layer
+    const int t8 = gs[0].tile == 37 ? 37 : 36;
+    prof_begin(t8 * 3 + CRCT_KIND_WGRAD, gs, n);
+    const hipError_t e8 = t8 == 37 ? launch_group_f8t<4, 4, 2, 4, 2>(gs, n, s) : launch_group_f8t<4, 4, 2, 4, 3>(gs, n, s);
+    g_time_start = g_time_stop = nullptr;
+    log_launch(gs, n, t8, 0);
+    return e8;
+  }
   bool ok = n >= 2 && n <= GROUP_MAX && !g_force_generic;
   for (int i = 0; ok && i < n; ++i) {
     const CrctGemmArgs& g = gs[i];

@@ -486,8 +486,11 @@ typedef struct CrctStepCfg {
    * Linears (dx = dy W) read an OCP e5m2 copy of dy -- written by the producing LayerNorm-backward kernel / GELU' epilogue with the
    * per-site scales fp8_grad_scale[crct_engine_fp8_grad_sites()], maxima into fp8_grad_amax -- and the TRANSPOSED e4m3 weight
    * shadow params_fp8_t (crct_fp8_transpose_weights of params_fp8; weight scales = fp8_w_scale).  fp8_bwd = 2: calibration -- the
-   * maxima are collected, the GEMMs run in bf16 (the first backward pass).  Weight gradients and the QKV data gradient stay bf16. */
-  int32_t fp8_bwd;
+   * maxima are collected, the GEMMs run in bf16 (the first backward pass).  The QKV data gradient stays bf16.
+   * fp8_wgrad != 0 (with fp8_bwd = 1): the WEIGHT gradients of the FFN Linears dW = dy^T x also read fp8 operands -- the same e5m2
+   * copy of dy and the e4m3 copy of x the forward GEMM read, both token-major, through the transposing LDS load (gemm.hip); their
+   * bias gradients and every other weight gradient stay bf16. */
+  int32_t fp8_bwd; int32_t fp8_wgrad;
   const void* params_fp8_t; const float* fp8_grad_scale; float* fp8_grad_amax;
   /* Host callback of crct_engine_backward(seg < 0): invoked on the calling thread, INSIDE the call, right after the four
    * seg_done_events of segment s have been recorded -- i.e. while the host is still enqueuing the rest of backward.  A

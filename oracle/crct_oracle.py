@@ -45,6 +45,10 @@ FP8_EMULATION = False
 # data gradients and every weight gradient use the unquantised operands.  Switched on by ``FP8_BWD_EMULATION = True`` (with
 # FP8_EMULATION).
 FP8_BWD_EMULATION = False
+# ... and of the fp8 WEIGHT gradients of the FFN Linears: dW = dy^T x from the same e5m2 rounding of dy and the e4m3 rounding of x the
+# forward GEMM read; their bias gradients, and the weight gradients of every other Linear, use the unquantised operands.
+# Switched on by ``FP8_WGRAD_EMULATION = True`` (with the two above).
+FP8_WGRAD_EMULATION = False
 _FP8_SUFFIXES = ("self.query", "self.key", "self.value", "query1", "key1", "value1", "query2", "key2", "value2",
                  "intermediate.dense", "v_intermediate.dense", "t_intermediate.dense")
 
@@ -61,20 +65,25 @@ def _bf8_round(t):
 
 class _Fp8Linear(torch.autograd.Function):
     """fwd_q: the forward multiplies e4m3 roundings of x and w; bwd_q: the data gradient multiplies an e5m2 rounding of gy with the
-    e4m3 rounding of w.  The weight / bias gradients always use the unquantised operands."""
+    e4m3 rounding of w; wg_q: the weight gradient multiplies the e5m2 rounding of gy with the e4m3 rounding of x.  The bias
+    gradient always sums the unquantised gy."""
 
     @staticmethod
-    def forward(ctx, x, w, b, fwd_q=True, bwd_q=False):
+    def forward(ctx, x, w, b, fwd_q=True, bwd_q=False, wg_q=False):
         ctx.save_for_backward(x, w)
-        ctx.bwd_q = bwd_q
+        ctx.bwd_q, ctx.wg_q = bwd_q, wg_q
         return F.linear(_fp8_round(x), _fp8_round(w), b) if fwd_q else F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = (_bf8_round(gy) @ _fp8_round(w)) if ctx.bwd_q else gy @ w
-        gw = gy.reshape(-1, gy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
-        return gx, gw, gy.reshape(-1, gy.shape[-1]).sum(0), None, None
+        gq = _bf8_round(gy) if (ctx.bwd_q or ctx.wg_q) else None
+        gx = (gq @ _fp8_round(w)) if ctx.bwd_q else gy @ w
+        if ctx.wg_q:
+            gw = gq.reshape(-1, gy.shape[-1]).t() @ _fp8_round(x).reshape(-1, x.shape[-1])
+        else:
+            gw = gy.reshape(-1, gy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+        return gx, gw, gy.reshape(-1, gy.shape[-1]).sum(0), None, None, None
 
 
 def _fp8_linear_site(prefix, in_features):
@@ -102,8 +111,10 @@ def linear(sd, prefix, x):
     if FP8_EMULATION and ".encoder." in prefix:
         fwd_q = _fp8_linear_site(prefix, w.shape[1])
         bwd_q = FP8_BWD_EMULATION and _fp8_dgrad_site(prefix, w)
+        # the FFN Linears: forward and data gradient both in fp8, not a QKV / attention-output / biOutput projection
+        wg_q = FP8_WGRAD_EMULATION and fwd_q and bwd_q and not prefix.endswith(_FP8_QKV) and not prefix.endswith(("biOutput.dense1", "biOutput.dense2"))
         if fwd_q or bwd_q:
-            return _Fp8Linear.apply(x, w, sd[prefix + ".bias"], fwd_q, bwd_q)
+            return _Fp8Linear.apply(x, w, sd[prefix + ".bias"], fwd_q, bwd_q, wg_q)
     return F.linear(x, w, sd[prefix + ".bias"])
 
 

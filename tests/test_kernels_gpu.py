@@ -482,6 +482,59 @@ def test_gemm_fp8_data_gradient(M, N, K):
     assert float(((deq - ref2).abs() - tol).max()) <= 0.0
 
 
+@pytest.mark.parametrize("R,N,K", [(1600, 3072, 768), (1600, 768, 3072), (2880, 1024, 1024), (80, 1024, 1024), (1, 64, 48), (257, 208, 80), (768, 768, 1024)])
+def test_gemm_fp8_weight_gradient(R, N, K):
+    """The fp8 WEIGHT-GRADIENT GEMM: dW[N = out][K = in] = dy^T x from the token-major copies the other passes left behind --
+    dy [R tokens][out] OCP e5m2, x [R][in] e4m3 -- read through the transposing LDS load; R is the contraction length (any
+    value: the tail of the last 128-token tile is zero-filled), N / K need not fill a tile.  Against fp32 matmul of the same
+    dequantised operands: overwrite, accumulate onto an existing gradient, and the identity check with an ASYMMETRIC x that
+    catches a transposed result (cdna_hip_programming.md section 3)."""
+    g = torch.Generator(device="cpu").manual_seed(R + N + K + 3)
+    dy = torch.randn(R, N, generator=g) * 3e-3
+    x = torch.randn(R, K, generator=g)
+    s_dy, s_x = 57344.0 / float(dy.abs().max()), 448.0 / float(x.abs().max())
+    dyq = (dy * s_dy).clamp(-57344, 57344).to(torch.float8_e5m2).to(DEV)
+    xq = _q8(x, s_x).to(DEV)
+    sd, sx = torch.tensor([s_dy], device=DEV), torch.tensor([s_x], device=DEV)
+    ref = (dyq.float() / s_dy).t() @ (xq.float() / s_x)
+    bound = 2e-3 * float(ref.abs().max()) + 1e-9
+    for tile in (36, 37):
+        out = torch.full((N, K), 7.0, device=DEV)
+        ops.gemm_wgrad_fp8([(dyq, xq, sd, sx, out)], accumulate=False, tile=tile)
+        assert float((out - ref).abs().max()) <= bound, tile
+        ops.gemm_wgrad_fp8([(dyq, xq, sd, sx, out)], accumulate=True, tile=tile)
+        assert float((out - 2 * ref).abs().max()) <= 2 * bound, tile
+    if R == N:           # dy = identity: dW must be x itself (quantised), not its transpose
+        eye = torch.eye(R).to(torch.float8_e5m2).to(DEV)
+        one = torch.ones(1, device=DEV)
+        out = torch.zeros(N, K, device=DEV)
+        ops.gemm_wgrad_fp8([(eye, xq, one, sx, out)], accumulate=False)
+        assert torch.equal(out, xq.float() / s_x)
+
+
+def test_gemm_fp8_weight_gradients_grouped():
+    """The fp8 weight gradients of a text layer in ONE launch (FFN-up, FFN-down, attention output, QKV), bit-identical to the
+    single launches."""
+    R = 1600
+    shapes = [(3072, 768), (768, 3072), (768, 768), (2304, 768)]
+    g = torch.Generator(device="cpu").manual_seed(9)
+    probs, singles = [], []
+    for N, K in shapes:
+        dy, x = torch.randn(R, N, generator=g) * 2e-3, torch.randn(R, K, generator=g)
+        s_dy, s_x = 57344.0 / float(dy.abs().max()), 448.0 / float(x.abs().max())
+        dyq, xq = (dy * s_dy).to(torch.float8_e5m2).to(DEV), _q8(x, s_x).to(DEV)
+        sd, sx = torch.tensor([s_dy], device=DEV), torch.tensor([s_x], device=DEV)
+        probs.append((dyq, xq, sd, sx, torch.zeros(N, K, device=DEV)))
+        singles.append((dyq, xq, sd, sx, torch.zeros(N, K, device=DEV)))
+    ops.gemm_wgrad_fp8(probs, accumulate=False)
+    for p in singles:
+        ops.gemm_wgrad_fp8([p], accumulate=False)
+    for a, b in zip(probs, singles):
+        assert torch.equal(a[4], b[4])
+        ref = (a[0].float() / float(a[2])).t() @ (a[1].float() / float(a[3]))
+        assert float((a[4] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 def test_layernorm_bwd_emits_the_e5m2_gradient_copy():
     """CrctLnBwdArgs.q_out: the gradient that leaves the LayerNorm-backward kernel towards the producing Linear, also as OCP e5m2
     (the A operand of that Linear's fp8 data gradient), quantised from the bf16-rounded value; its maximum in q_amax."""
