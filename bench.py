@@ -459,8 +459,9 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
-                                      ("; fp8 (e4m3) forward QKV / FFN GEMMs, bf16 backward" if a.fp8_forward_only else
-                                       "; fp8 forward QKV / FFN GEMMs (e4m3), fp8 data gradients of the FFN / attention-output Linears (e5m2 x e4m3), bf16 weight gradients")
+                                      ("; fp8 (e4m3) forward GEMMs of every encoder Linear, bf16 backward" if a.fp8_forward_only else
+                                       "; every encoder Linear in fp8: forward e4m3 x e4m3, data gradient e5m2 x e4m3" +
+                                       (", bf16 weight gradients" if a.fp8_bf16_wgrad else ", weight gradient e5m2 x e4m3"))
                                       if a.dtype == "fp8" else ""),
                           "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                           "global_loss": global_loss, "input": a.input, "host_enqueue_ms_per_step": host_ms,

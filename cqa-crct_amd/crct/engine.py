@@ -98,7 +98,7 @@ class StepEngine(object):
         c.g_nsp_dev, c.g_reg_dev, c.g_loss_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg")), L.ptr(step.get("g_loss"))
         f8 = step.get("fp8")
         if f8 is not None:          # (flat e4m3 weight shadow, weight scales, activation scales, activation amax): device tensors
-            c.fp8 = 1
+            c.fp8 = int(step.get("fp8_mode", 1))
             c.params_fp8, c.fp8_w_scale, c.fp8_act_scale, c.fp8_act_amax = (L.ptr(t) for t in f8)
         f8b = step.get("fp8_bwd")
         if f8b is not None and f8 is not None:      # (mode, transposed e4m3 weight shadow, gradient scales, gradient amax)

@@ -76,8 +76,13 @@ class AmpState(C.Structure):
     _fields_ = [("grad_scale", vp), ("found_inf", vp), ("step", vp)]
 
 
+class AttnQuant(C.Structure):
+    _fields_ = [("ctx_q", vp), ("ctx_scale", vp), ("ctx_amax", vp), ("dq_q", vp), ("dk_q", vp), ("dv_q", vp),
+                ("dq_scale", vp), ("dq_amax", vp), ("dkv_scale", vp), ("dkv_amax", vp)]
+
+
 class Fp8Shadow(C.Structure):
-    _fields_ = [("q", vp), ("seg_slot", vp), ("scale", vp), ("amax", vp), ("qt", vp), ("seg_in", vp)]
+    _fields_ = [("q", vp), ("seg_slot", vp), ("scale", vp), ("amax", vp), ("qt", vp), ("seg_in", vp), ("seg_t_base", vp), ("seg_t_ld", vp)]
 
 
 class StepCfg(C.Structure):
@@ -135,6 +140,9 @@ PROTOTYPES = {
     "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
+    "crct_attention_fwd_q": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp, vp]),
+    "crct_attention_bwd_q": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp, vp]),
+    "crct_attention_quant_ok": (C.c_int, [C.c_int] * 3),
     "crct_attention_force_valu": (None, [C.c_int]),
     "crct_attention_force_split": (None, [C.c_int]),
     "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),

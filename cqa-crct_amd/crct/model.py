@@ -219,9 +219,8 @@ class CrctModel(nn.Module):
                 outs.append(num // n_in)
                 ins.append(n_in)
                 begins.append(nt)
-                # only the weights whose data gradient runs in fp8 (FFN, attention output: single parameter tensors); a fused
-                # QKV weight (three tensors) has a bf16 data gradient and no transposed copy
-                transposed.append(by_off[off].numel == num)
+                # every shadowed weight has a transposed copy (the fp8 data gradients; a fused QKV weight [3H][H] is one of them)
+                transposed.append(True)
                 if transposed[-1]:
                     nt += ((num // n_in + 63) // 64) * ((n_in + 63) // 64)
             st["transposed"] = transposed
@@ -554,7 +553,7 @@ class CrctModel(nn.Module):
         if self.fp8:
             step["fp8"] = self._fp8_step_args(eng)
             if not self._fp8["calibrated"]:            # first fp8 forward: one dry pass collects every activation amax
-                eng.forward(self._flat_p, self._flat_b16, tensors, dict(step, seg_events=None))
+                eng.forward(self._flat_p, self._flat_b16, tensors, dict(step, seg_events=None, fp8_mode=2))      # bf16 GEMMs, maxima only
                 self._fp8["calibrated"] = True
             if self.training or not self._fp8.get("scaled"):
                 self._fp8_update_act_scales()          # delayed scaling: this pass quantises with the previous pass's amax

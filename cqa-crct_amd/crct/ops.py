@@ -217,6 +217,41 @@ def attention_fwd(q, k, v, keymask, heads, d, p_drop=0.0, site=0, seed=0):
     return ctx
 
 
+def attention_fwd_q(q, k, v, keymask, heads, d, q_scale, q_amax, p_drop=0.0, site=0, seed=0):
+    """attention_fwd that also returns the e4m3 copy of ctx (uint8, same shape), quantised with the device scalar q_scale."""
+    lib = L.load()
+    B, Tq = q.shape[0], q.shape[1]
+    Tk = k.shape[1]
+    ctx = torch.empty(B, Tq, heads * d, device=q.device, dtype=torch.bfloat16)
+    ctx_q = torch.zeros(B, Tq, heads * d, device=q.device, dtype=torch.uint8)
+    qz = L.AttnQuant()
+    qz.ctx_q, qz.ctx_scale, qz.ctx_amax = L.ptr(ctx_q), L.ptr(q_scale), L.ptr(q_amax)
+    thr, sc, st = _drop(p_drop, site)
+    L.check(lib.crct_attention_fwd_q(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(_chk(keymask, torch.uint8)), L.ptr(ctx), B, heads, Tq, Tk, d,
+                                     q.stride(1), k.stride(1), v.stride(1), heads * d, thr, sc, st, seed, C.byref(qz), L.current_stream()),
+            "attention_fwd_q")
+    return ctx, ctx_q
+
+
+def attention_bwd_q(q, k, v, keymask, dctx, heads, d, dq_scale, dq_amax, dkv_scale, dkv_amax, p_drop=0.0, site=0, seed=0):
+    """attention_bwd that also returns the e5m2 copies of dq, dk, dv (uint8)."""
+    lib = L.load()
+    B, Tq = q.shape[0], q.shape[1]
+    Tk = k.shape[1]
+    dq = torch.empty(B, Tq, heads * d, device=q.device, dtype=torch.bfloat16)
+    dk = torch.empty(B, Tk, heads * d, device=q.device, dtype=torch.bfloat16)
+    dv = torch.empty_like(dk)
+    dq8, dk8, dv8 = (torch.zeros(t.shape, device=q.device, dtype=torch.uint8) for t in (dq, dk, dv))
+    qz = L.AttnQuant()
+    qz.dq_q, qz.dk_q, qz.dv_q = L.ptr(dq8), L.ptr(dk8), L.ptr(dv8)
+    qz.dq_scale, qz.dq_amax, qz.dkv_scale, qz.dkv_amax = L.ptr(dq_scale), L.ptr(dq_amax), L.ptr(dkv_scale), L.ptr(dkv_amax)
+    thr, sc, st = _drop(p_drop, site)
+    L.check(lib.crct_attention_bwd_q(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(keymask), L.ptr(_chk(dctx, torch.bfloat16)), L.ptr(dq), L.ptr(dk), L.ptr(dv),
+                                     B, heads, Tq, Tk, d, q.stride(1), k.stride(1), v.stride(1), dctx.stride(1),
+                                     heads * d, heads * d, heads * d, thr, sc, st, seed, C.byref(qz), L.current_stream()), "attention_bwd_q")
+    return (dq, dk, dv), (dq8, dk8, dv8)
+
+
 def attention_bwd(q, k, v, keymask, dctx, heads, d, p_drop=0.0, site=0, seed=0):
     lib = L.load()
     B, Tq = q.shape[0], q.shape[1]

@@ -180,30 +180,43 @@ class FusedAdamW(torch.optim.Optimizer):
             import ctypes as C
             by_start = sorted(range(len(st["weights"])), key=lambda i: st["weights"][i][0])      # the engine lists them in model order, not by offset
             starts = [st["weights"][i][0] for i in by_start]
-            slots, t_in = [], []
+            slots, t_in, t_base, t_ld = [], [], [], []
             w_in = st["w_in"].tolist()
             for e in self._segs:                         # AdamW segments are parameter tensors: a fused QKV weight spans three
                 k = bisect.bisect_right(starts, e.offset) - 1
                 k = by_start[k] if k >= 0 else -1
                 inside = k >= 0 and e.offset + e.numel <= st["weights"][k][0] + st["weights"][k][1]
                 slots.append(k if inside else -1)
-                # transposed shadow (fp8 backward): kept by the update itself where the segment IS the weight, in whole 64 x 64 tiles
-                whole = inside and st.get("qt") is not None and st["transposed"][k] and (e.offset, e.numel) == tuple(st["weights"][k])
-                t_in.append(w_in[k] if (whole and w_in[k] % 64 == 0 and (e.numel // w_in[k]) % 64 == 0) else 0)
+                # transposed shadow (fp8 backward): kept by the update itself, in whole 64 x 64 tiles, where the segment is a band
+                # of whole rows of the weight (the weight itself, or the Q / K / V part of a fused QKV weight)
+                ok = inside and st.get("qt") is not None and st["transposed"][k]
+                if ok:
+                    w_off, w_num = st["weights"][k]
+                    n_in = w_in[k]
+                    ok = n_in % 64 == 0 and (e.offset - w_off) % n_in == 0 and e.numel % (64 * n_in) == 0 and ((e.offset - w_off) // n_in) % 16 == 0
+                t_in.append(w_in[k] if ok else 0)
+                t_base.append(st["weights"][k][0] + (e.offset - st["weights"][k][0]) // w_in[k] if ok else 0)
+                t_ld.append(st["weights"][k][1] // w_in[k] if ok else 0)
             dev = core.flat_params.device
             seg_slot = torch.tensor(slots, dtype=torch.int32, device=dev)
             seg_in = torch.tensor(t_in, dtype=torch.int32, device=dev)
+            seg_t_base = torch.tensor(t_base, dtype=torch.int64, device=dev)
+            seg_t_ld = torch.tensor(t_ld, dtype=torch.int32, device=dev)
             sh = L.Fp8Shadow()
             sh.q, sh.seg_slot, sh.scale, sh.amax = st["q"].data_ptr(), seg_slot.data_ptr(), st["w_scale"].data_ptr(), st["w_amax"].data_ptr()
             # every weight that has a transposed copy must be covered, or the separate launch stays (crct_fp8_transpose_weights)
             if set(s for s in slots if s >= 0) != set(range(len(st["weights"]))):
                 raise RuntimeError("fused AdamW: %d of the model's %d fp8-shadowed weights are not covered by optimizer segments; their "
                                    "shadow would go stale" % (len(st["weights"]) - len(set(s for s in slots if s >= 0)), len(st["weights"])))
-            fused = st.get("qt") is not None and sum(1 for t in t_in if t > 0) == sum(1 for t in st["transposed"] if t)
+            covered = [0] * len(st["weights"])
+            for s, t, e in zip(slots, t_in, self._segs):
+                if s >= 0 and t > 0:
+                    covered[s] += e.numel
+            fused = st.get("qt") is not None and all(covered[k] == st["weights"][k][1] for k in range(len(covered)) if st["transposed"][k])
             if fused:
-                sh.qt, sh.seg_in = st["qt"].data_ptr(), seg_in.data_ptr()
+                sh.qt, sh.seg_in, sh.seg_t_base, sh.seg_t_ld = st["qt"].data_ptr(), seg_in.data_ptr(), seg_t_base.data_ptr(), seg_t_ld.data_ptr()
             self._fp8_transposes = fused
-            self._fp8_keep = (st, seg_slot, sh, C.byref(sh), seg_in)
+            self._fp8_keep = (st, seg_slot, sh, C.byref(sh), seg_in, seg_t_base, seg_t_ld)
         return self._fp8_keep[3]
 
     def _fp8_before_update(self, stream):

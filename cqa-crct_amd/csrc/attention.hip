@@ -402,13 +402,20 @@ bool use_mfma(int Tq, int Tk, int d) { return !g_force_valu && crct_attention_mf
 
 extern "C" void crct_attention_force_valu(int on) { g_force_valu = on ? 1 : 0; }
 
-extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx, int B,
-                                  int heads, int Tq, int Tk, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                                  uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
-                                  crct_stream_t stream) {
+extern "C" int crct_attention_quant_ok(int Tq, int Tk, int d) { return use_mfma(Tq, Tk, d) ? 1 : 0; }
+
+static int attention_fwd_impl(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx, int B,
+                              int heads, int Tq, int Tk, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                              uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed, const CrctAttnQuant* qz,
+                              crct_stream_t stream) {
   if (int e = check_args(Tq, Tk, d)) return e;
   if (B * heads <= 0) return 0;
   AttnArgs a = {};
+  if (qz && qz->ctx_q) {
+    CRCT_REQUIRE(use_mfma(Tq, Tk, d), "attention_fwd_q: the fp8 copy exists in the MFMA kernels only (Tq=%d Tk=%d d=%d)", Tq, Tk, d);
+    CRCT_REQUIRE(qz->ctx_scale && qz->ctx_amax && ldo % 8 == 0, "attention_fwd_q: scale / amax missing or ldo %% 8 != 0");
+    a.ctx_q = (uint8_t*)qz->ctx_q; a.ctx_qscale = qz->ctx_scale; a.ctx_qamax = qz->ctx_amax;
+  }
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.keymask = keymask; a.ctx = (bf16_t*)ctx;
   a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -427,15 +434,35 @@ extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, c
   CRCT_CHECK_HIP(dispatch<false>(a, lds, (hipStream_t)stream));
   return 0;
 }
-
-extern "C" int crct_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* keymask, const void* dctx,
-                                  void* dq, void* dk, void* dv, int B, int heads, int Tq, int Tk, int d, int64_t ldq,
-                                  int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+extern "C" int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx, int B,
+                                  int heads, int Tq, int Tk, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                                   uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                                   crct_stream_t stream) {
+  return attention_fwd_impl(q, k, v, keymask, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldv, ldo, drop_thr, drop_scale, drop_site, seed, nullptr, stream);
+}
+extern "C" int crct_attention_fwd_q(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx, int B,
+                                    int heads, int Tq, int Tk, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                    uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed, const CrctAttnQuant* qz,
+                                    crct_stream_t stream) {
+  return attention_fwd_impl(q, k, v, keymask, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldv, ldo, drop_thr, drop_scale, drop_site, seed, qz, stream);
+}
+
+static int attention_bwd_impl(const void* q, const void* k, const void* v, const uint8_t* keymask, const void* dctx,
+                              void* dq, void* dk, void* dv, int B, int heads, int Tq, int Tk, int d, int64_t ldq,
+                              int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                              uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed, const CrctAttnQuant* qz,
+                              crct_stream_t stream) {
   if (int e = check_args(Tq, Tk, d)) return e;
   if (B * heads <= 0) return 0;
   AttnArgs a = {};
+  if (qz && (qz->dq_q || qz->dk_q || qz->dv_q)) {
+    CRCT_REQUIRE(use_mfma(Tq, Tk, d), "attention_bwd_q: the fp8 copies exist in the MFMA kernels only (Tq=%d Tk=%d d=%d)", Tq, Tk, d);
+    CRCT_REQUIRE((!qz->dq_q || (qz->dq_scale && qz->dq_amax)) && ((!qz->dk_q && !qz->dv_q) || (qz->dkv_scale && qz->dkv_amax)),
+                 "attention_bwd_q: scale / amax missing");
+    CRCT_REQUIRE(lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0, "attention_bwd_q: gradient leading dimensions must be multiples of 8");
+    a.dq_q = (uint8_t*)qz->dq_q; a.dk_q = (uint8_t*)qz->dk_q; a.dv_q = (uint8_t*)qz->dv_q;
+    a.dq_qscale = qz->dq_scale; a.dq_qamax = qz->dq_amax; a.dkv_qscale = qz->dkv_scale; a.dkv_qamax = qz->dkv_amax;
+  }
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.keymask = keymask;
   a.dctx = (const bf16_t*)dctx; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.B = B; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d;
@@ -451,4 +478,20 @@ extern "C" int crct_attention_bwd(const void* q, const void* k, const void* v, c
   CRCT_REQUIRE(lds <= 160 * 1024, "attention_bwd: Tq=%d Tk=%d d=%d needs %zu B of LDS (> 160 KiB)", Tq, Tk, d, lds);
   CRCT_CHECK_HIP(dispatch<true>(a, lds, (hipStream_t)stream));
   return 0;
+}
+extern "C" int crct_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* keymask, const void* dctx,
+                                  void* dq, void* dk, void* dv, int B, int heads, int Tq, int Tk, int d, int64_t ldq,
+                                  int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                                  uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                                  crct_stream_t stream) {
+  return attention_bwd_impl(q, k, v, keymask, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldv, ldo, lddq, lddk, lddv, drop_thr, drop_scale,
+                            drop_site, seed, nullptr, stream);
+}
+extern "C" int crct_attention_bwd_q(const void* q, const void* k, const void* v, const uint8_t* keymask, const void* dctx,
+                                    void* dq, void* dk, void* dv, int B, int heads, int Tq, int Tk, int d, int64_t ldq,
+                                    int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                                    uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed, const CrctAttnQuant* qz,
+                                    crct_stream_t stream) {
+  return attention_bwd_impl(q, k, v, keymask, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldv, ldo, lddq, lddk, lddv, drop_thr, drop_scale,
+                            drop_site, seed, qz, stream);
 }

@@ -14,6 +14,11 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   uint32_t thr; float dscale; uint32_t site; uint64_t seed;
   float scale;
+  // fp8 copies of the results (MFMA kernels only; include/crct_hip.h CrctAttnQuant): ctx as e4m3, dq / dk / dv as e5m2, each with
+  // the leading dimension of its bf16 twin (in bytes), quantised with *scale, max |.| into *amax (CRCT_FP8_AMAX_LANES words)
+  uint8_t* ctx_q; const float* ctx_qscale; float* ctx_qamax;
+  uint8_t* dq_q; uint8_t* dk_q; uint8_t* dv_q;
+  const float* dq_qscale; float* dq_qamax; const float* dkv_qscale; float* dkv_qamax;
   int dbg;      // ablation bits, read only by -DCRCT_ATTN_LAB builds (tools/attn_lab); always 0 in the shipped library
 };
 

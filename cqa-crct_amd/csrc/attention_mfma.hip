@@ -87,6 +87,40 @@ __device__ __forceinline__ void store_rows(bf16_t* dst, long ld, const char* img
     *reinterpret_cast<uint4*>(dst + (long)r * ld + cc) = *reinterpret_cast<const uint4*>(img + r * STB + cc * 2);
   }
 }
+// ... and an fp8 copy of the same rows (BF8: OCP e5m2, else e4m3; saturating) with their maximum into amax_dst
+template <int ND, int SP, bool BF8>
+__device__ __forceinline__ void store_rows_q(bf16_t* dst, uint8_t* qdst, long ld, const char* img, int T, int lane, int part, float qs,
+                                             float* amax_dst) {
+  constexpr int CPR = 2 * ND, STB = 32 * ND + 16;
+  constexpr float LIM = BF8 ? 57344.f : 448.f;
+  float am = 0.f;
+  for (int c = lane + 64 * part; c < T * CPR; c += 64 * SP) {
+    const int r = c / CPR, cc = (c - r * CPR) << 3;
+    const uint4 u = *reinterpret_cast<const uint4*>(img + r * STB + cc * 2);
+    *reinterpret_cast<uint4*>(dst + (long)r * ld + cc) = u;
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); f[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+    uint32_t o[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { am = fmaxf(am, fabsf(f[j])); f[j] = fminf(fmaxf(f[j] * qs, -LIM), LIM); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (BF8) {
+        o[j] = __builtin_amdgcn_cvt_pk_bf8_f32(f[4 * j], f[4 * j + 1], o[j], false);
+        o[j] = __builtin_amdgcn_cvt_pk_bf8_f32(f[4 * j + 2], f[4 * j + 3], o[j], true);
+      } else {
+        o[j] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * j], f[4 * j + 1], o[j], false);
+        o[j] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * j + 2], f[4 * j + 3], o[j], true);
+      }
+    }
+    *reinterpret_cast<uint2*>(qdst + (long)r * ld + cc) = make_uint2(o[0], o[1]);
+  }
+  am = fmaxf(am, __shfl_xor(am, 32, 64)); am = fmaxf(am, __shfl_xor(am, 16, 64)); am = fmaxf(am, __shfl_xor(am, 8, 64));
+  am = fmaxf(am, __shfl_xor(am, 4, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64)); am = fmaxf(am, __shfl_xor(am, 1, 64));
+  if (lane == 0) amax_update(amax_dst, am);
+}
 // fragment X[r0 + (lane & 15)][c0 + 4 (lane >> 4) + e]: contraction along the image's columns
 __device__ __forceinline__ s4_t frag_rows(const char* img, int stb, int r0, int c0, int lane) {
   return *reinterpret_cast<const s4_t*>(img + (r0 + (lane & 15)) * stb + (c0 + 4 * (lane >> 4)) * 2);
@@ -268,7 +302,11 @@ __global__ __launch_bounds__(64 * W * SP) void attn_fwd_mfma(const AttnArgs a) {
     }
   }
   group_sync<SP>();
-  if (live) store_rows<ND, SP>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq, lane, part);
+  if (live) {
+    if (a.ctx_q) store_rows_q<ND, SP, false>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ctx_q + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq,
+                                             lane, part, a.ctx_qscale[0], a.ctx_qamax);
+    else store_rows<ND, SP>(a.ctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, Qs, a.Tq, lane, part);
+  }
 }
 
 // SP cooperating waves per (batch, head): phase 1 (scores, softmax, dS, dq) by QUERY tiles it = part, part + SP, ...; the two
@@ -320,6 +358,7 @@ __global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
   constexpr bool LOWREG = NQ * NK >= 21;
   constexpr bool DQ_DIRECT = LOWREG || SP > 1;
   f4_t dq[DQ_DIRECT ? 1 : ND][DQ_DIRECT ? 1 : NQ];
+  float dq_am = 0.f;                    // max |dq| of this wave's direct stores (fp8 copy)
   s4_t dsb[NQL][NK];                    // dS^T tiles (bf16) of this wave's query tiles: B operand of dq now, written to the image for dk later
   {
     s4_t kf[LOWREG ? 1 : NK][LOWREG ? 1 : ND];
@@ -385,12 +424,28 @@ __global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
             const int i = 16 * it + n;
             if (live && i < a.Tq) {
               t = t * a.scale;
-              *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Tq + i) * a.lddq + h * d + 16 * ct + 4 * (lane >> 4)) =
-                  make_uint2(pack2bf(t[0], t[1]), pack2bf(t[2], t[3]));
+              const uint2 pk = make_uint2(pack2bf(t[0], t[1]), pack2bf(t[2], t[3]));
+              *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Tq + i) * a.lddq + h * d + 16 * ct + 4 * (lane >> 4)) = pk;
+              if (a.dq_q) {                 // e5m2 copy of the bf16-rounded values
+                const float f0 = bf2f((bf16_t)(pk.x & 0xffff)), f1 = bf2f((bf16_t)(pk.x >> 16)), f2 = bf2f((bf16_t)(pk.y & 0xffff)), f3 = bf2f((bf16_t)(pk.y >> 16));
+                dq_am = fmaxf(fmaxf(dq_am, fmaxf(fabsf(f0), fabsf(f1))), fmaxf(fabsf(f2), fabsf(f3)));
+                const float qs = a.dq_qscale[0];
+                uint32_t o = 0u;
+                o = __builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(f0 * qs, -57344.f), 57344.f), fminf(fmaxf(f1 * qs, -57344.f), 57344.f), o, false);
+                o = __builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(f2 * qs, -57344.f), 57344.f), fminf(fmaxf(f3 * qs, -57344.f), 57344.f), o, true);
+                *reinterpret_cast<uint32_t*>(a.dq_q + ((long)b * a.Tq + i) * a.lddq + h * d + 16 * ct + 4 * (lane >> 4)) = o;
+              }
             }
           } else dq[ct][it] = t;
         }
       }
+    }
+  }
+  if constexpr (DQ_DIRECT) {
+    if (a.dq_q) {
+      dq_am = fmaxf(dq_am, __shfl_xor(dq_am, 32, 64)); dq_am = fmaxf(dq_am, __shfl_xor(dq_am, 16, 64)); dq_am = fmaxf(dq_am, __shfl_xor(dq_am, 8, 64));
+      dq_am = fmaxf(dq_am, __shfl_xor(dq_am, 4, 64)); dq_am = fmaxf(dq_am, __shfl_xor(dq_am, 2, 64)); dq_am = fmaxf(dq_am, __shfl_xor(dq_am, 1, 64));
+      if (lane == 0) amax_update(a.dq_qamax, dq_am);
     }
   }
   group_sync<SP>();                     // K is consumed (its image becomes the staging tile); the P image is complete
@@ -400,7 +455,9 @@ __global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
 #pragma unroll
       for (int ct = 0; ct < ND; ++ct) put_tile_t(Ks, STB, 16 * it, 16 * ct, dq[ct][it] * a.scale, lane);
     wave_sync();
-    store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane);
+    if (a.dq_q) store_rows_q<ND, 1, true>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.dq_q + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane, 0,
+                                          a.dq_qscale[0], a.dq_qamax);
+    else store_rows<ND>(a.dq + (long)b * a.Tq * a.lddq + h * d, a.lddq, Ks, a.Tq, lane);
   }
   // dv^T[c][j] = sum_i dO[i][c] Pd[i][j]     (this wave's key tiles)
   f4_t acc[ND][NKL];
@@ -438,7 +495,11 @@ __global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
     }
   }
   group_sync<SP>();
-  if (live) store_rows<ND, SP>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, Ks, a.Tk, lane, part);
+  if (live) {
+    if (a.dv_q) store_rows_q<ND, SP, true>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.dv_q + (long)b * a.Tk * a.lddv + h * d, a.lddv, Ks, a.Tk, lane,
+                                           part, a.dkv_qscale[0], a.dkv_qamax);
+    else store_rows<ND, SP>(a.dv + (long)b * a.Tk * a.lddv + h * d, a.lddv, Ks, a.Tk, lane, part);
+  }
   // dk^T[c][j] = sum_i q[i][c] dS[i][j]      (this wave's key tiles)
 #pragma unroll
   for (int lj = 0; lj < NKL; ++lj) {
@@ -465,7 +526,11 @@ __global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
     }
   }
   group_sync<SP>();
-  if (live) store_rows<ND, SP>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, Ks, a.Tk, lane, part);
+  if (live) {
+    if (a.dk_q) store_rows_q<ND, SP, true>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.dk_q + (long)b * a.Tk * a.lddk + h * d, a.lddk, Ks, a.Tk, lane,
+                                           part, a.dkv_qscale[0], a.dkv_qamax);
+    else store_rows<ND, SP>(a.dk + (long)b * a.Tk * a.lddk + h * d, a.lddk, Ks, a.Tk, lane, part);
+  }
 }
 
 // waves per workgroup: the largest of 4 / 2 / 1 that does not lower the number of waves a CU's LDS can hold

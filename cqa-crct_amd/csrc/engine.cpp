@@ -97,9 +97,10 @@ struct ConnLayerP { LinearP qkv1, qkv2; ProjP proj_v, proj_t; FfnP ffn_v, ffn_t;
 // ---- activation offsets (bytes into the workspace)
 struct FfnA { size_t u, h, s, y, mean, rstd, hq, yq; int site_h, site_y; int g_dl, g_du; };      // g_*: gradient scale sites (fp8 backward)      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
 struct ProjA { size_t s, a, mean, rstd, aq; int site_a; int g_dl; };
-struct SelfLayerA { size_t qkv, ctx; ProjA proj; FfnA ffn; };
-struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
-struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b, dlq_a, dlq_b, duq; };      // *q: e5m2 copies (fp8 backward)
+// ctxq / site_ctx: e4m3 copy of the attention context and its activation scale site; g_dqkv: gradient scale site of the fused dqkv buffer
+struct SelfLayerA { size_t qkv, ctx, ctxq; int site_ctx, g_dqkv; ProjA proj; FfnA ffn; };
+struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2, ctx1q, ctx2q; int site_ctx1, site_ctx2, g_dqkv1, g_dqkv2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
+struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b, dlq_a, dlq_b, duq, dqkvq; };      // *q: e5m2 copies (fp8 backward)
 
 struct Step { char kind; int idx; };
 struct Tap { std::string name; size_t off; char stream; };
@@ -229,6 +230,7 @@ StreamScratch scratch_a(Arena& ar, size_t M, int H, int I, int Hb) {
   s.part_a = ar.take((size_t)3 * 4 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);   // [3][4 waves x blocks][H]      // LayerNorm-backward column partials of the layer's two norms
   s.part_b = ar.take((size_t)3 * 4 * CRCT_LN_BWD_MAX_BLOCKS * H * 4);
   s.dlq_a = ar.take(M * H); s.dlq_b = ar.take(M * H); s.duq = ar.take(M * (size_t)I);
+  s.dqkvq = ar.take(M * (size_t)3 * Hm);
   return s;
 }
 
@@ -332,7 +334,8 @@ struct Run {
     const float* bias = nullptr; void* preact = nullptr; const void* dact_src = nullptr; int dact = 0; int act = 0;
     const void* addend = nullptr; int64_t ld_aux = 0, ld_add = 0; Drop drop; bool f32 = false; bool acc = false;
     int site = 0;
-    void* q_out = nullptr; const float* q_scale = nullptr; float* q_amax = nullptr; int64_t ld_q = 0;      // e5m2 copy of the result (fp8 backward calibration)
+    void* q_out = nullptr; const float* q_scale = nullptr; float* q_amax = nullptr; int64_t ld_q = 0;      // fp8 copy of the result (calibration passes):
+    bool q_e4m3 = false;                                                                                   // e5m2 (a gradient) unless q_e4m3 (an activation)
   };
   void gemm(const void* Ap, int64_t lda, bool ta, const void* Bp, int64_t ldb, bool tb, void* C, int64_t ldc, int M, int N,
             int K, const Opt& o, hipStream_t st = nullptr) {
@@ -346,7 +349,7 @@ struct Run {
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
     g.site = o.site;
-    if (o.q_out) { g.q_out = o.q_out; g.q_scale = o.q_scale; g.q_amax = o.q_amax; g.ld_q = o.ld_q; g.fp8 = 4; }      // bf16 GEMM + e5m2 copy of its result
+    if (o.q_out) { g.q_out = o.q_out; g.q_scale = o.q_scale; g.q_amax = o.q_amax; g.ld_q = o.ld_q; g.fp8 = o.q_e4m3 ? 0 : 4; }      // bf16 GEMM + fp8 copy of its result
     if (!ta && st == s && o.site > 0 && o.site < CRCT_SITE_COUNT) {      // forward / data gradient on the data stream: the site's policy
       const crct_engine::SitePolicy& pol = e->policy[o.site][tb ? 1 : 0][phase];
       if (pol.cfg >= 0) g.tile = pol.cfg;
@@ -372,7 +375,10 @@ struct Run {
   }
   // ---- fp8 forward (CrctStepCfg.fp8): the same Linear from the e4m3 copies of its input (scale site `site_in`) and of its
   // weight; optionally also emits the e4m3 copy of its own output (hq, site_out) for the next fp8 GEMM
-  bool f8() const { return c->fp8 && c->params_fp8 && c->fp8_w_scale && c->fp8_act_scale && c->fp8_act_amax; }
+  // CrctStepCfg.fp8 == 2 (calibration, the dry pass before the first fp8 forward): every producer writes its copy and collects its
+  // maximum, the GEMMs themselves still read the bf16 operands -- the maxima are then those of the bf16 forward, not of a forward
+  // whose GEMMs ran on unscaled (scale 1) e4m3 inputs
+  int f8() const { return (c->fp8 && c->params_fp8 && c->fp8_w_scale && c->fp8_act_scale && c->fp8_act_amax) ? c->fp8 : 0; }
   bool f8_lin(const LinearP& l) const { return f8() && e->wq_slot.count(l.w) != 0; }
   // ---- fp8 backward (CrctStepCfg.fp8_bwd): data gradients dx = dy W of the FFN and attention-output Linears from the e5m2 copy
   // of dy (written by the producing LayerNorm-backward / GELU' epilogue, scale site g) and the TRANSPOSED e4m3 weight shadow.
@@ -405,8 +411,17 @@ struct Run {
     if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
     fail(crct_gemm_bf16(&g, s));
   }
-  void lin_fwd_f8(size_t xq, int site_in, const LinearP& l, int M, void* y, int64_t ldy, Opt o, size_t hq = (size_t)-1, int site_out = -1) {
+  // x: the bf16 input (leading dimension l.in), read instead of xq by the calibration pass
+  void lin_fwd_f8(const void* x, size_t xq, int site_in, const LinearP& l, int M, void* y, int64_t ldy, Opt o, size_t hq = (size_t)-1, int site_out = -1) {
     if (rc) return;
+    if (f8() != 1) {           // calibration: the bf16 GEMM, which still emits the e4m3 copy / maximum of its result
+      if (site_out >= 0) {
+        o.q_out = W<uint8_t>(hq); o.ld_q = l.out; o.q_scale = c->fp8_act_scale + site_out;
+        o.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; o.q_e4m3 = true;
+      }
+      lin_fwd(x, l.in, l, M, y, ldy, o);
+      return;
+    }
     ++tick;
     CrctGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -521,41 +536,61 @@ struct Run {
     else { wgrad_after_main(); if (!rc) fail(crct_layernorm_bwd_finalize(F(part), G(ln.g), G(ln.b), G(lin.b), M, H, 1, sw)); }
     return dr.thr ? dlin : dres;
   }
+  // ctxq / site_ctx: also the e4m3 copy of ctx (the fp8 forward GEMM and weight gradient of the attention-output projection read it)
   void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
-                int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr) {
+                int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr, size_t ctxq = (size_t)-1, int site_ctx = -1) {
     if (rc) return;
     ++tick;
     const uint64_t seed = c->seed;
-    auto f = [=](hipStream_t st) { return crct_attention_fwd(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, seed, st); };
-    if (defer) queue_call(f);
-    else fail(f(s));
-  }
-  void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
-                const bf16_t* dctx, int64_t ldo, bf16_t* dq, int64_t lddq, bf16_t* dk, bf16_t* dv, int64_t lddk, int B,
-                int heads, int Tq, int Tk, int d, const Drop& dr) {
-    if (rc) return;
-    ++tick;
-    const uint64_t seed = c->seed;
+    CrctAttnQuant qz;
+    memset(&qz, 0, sizeof(qz));
+    if (ctxq != (size_t)-1 && site_ctx >= 0) {
+      qz.ctx_q = W<uint8_t>(ctxq); qz.ctx_scale = c->fp8_act_scale + site_ctx; qz.ctx_amax = c->fp8_act_amax + (int64_t)site_ctx * CRCT_FP8_AMAX_LANES;
+    }
     auto f = [=](hipStream_t st) {
-      return crct_attention_bwd(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr, dr.scale,
-                                dr.site, seed, st);
+      return crct_attention_fwd_q(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, seed, &qz, st);
     };
     if (defer) queue_call(f);
     else fail(f(s));
   }
+  // dqq / g_dq, dkq / dvq / g_dkv: also e5m2 copies of dq and of dk / dv (columns of fused dqkv buffers: one scale site per buffer)
+  void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
+                const bf16_t* dctx, int64_t ldo, bf16_t* dq, int64_t lddq, bf16_t* dk, bf16_t* dv, int64_t lddk, int B,
+                int heads, int Tq, int Tk, int d, const Drop& dr, uint8_t* dqq = nullptr, int g_dq = -1, uint8_t* dkq = nullptr,
+                uint8_t* dvq = nullptr, int g_dkv = -1) {
+    if (rc) return;
+    ++tick;
+    const uint64_t seed = c->seed;
+    CrctAttnQuant qz;
+    memset(&qz, 0, sizeof(qz));
+    if (dqq && g_dq >= 0) { qz.dq_q = dqq; qz.dq_scale = gscale(g_dq); qz.dq_amax = gamax(g_dq); }
+    if (dkq && dvq && g_dkv >= 0) { qz.dk_q = dkq; qz.dv_q = dvq; qz.dkv_scale = gscale(g_dkv); qz.dkv_amax = gamax(g_dkv); }
+    auto f = [=](hipStream_t st) {
+      return crct_attention_bwd_q(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr, dr.scale,
+                                  dr.site, seed, &qz, st);
+    };
+    if (defer) queue_call(f);
+    else fail(f(s));
+  }
+  // the attention kernels that write fp8 copies cover this shape (MFMA kernels: include/crct_hip.h, CrctAttnQuant)
+  static bool attn_q_ok(int Tq, int Tk, int d) { return crct_attention_quant_ok(Tq, Tk, d) != 0; }
 
   // ---------------------------------------------------------------- sub-blocks
   // a = LN(dropout(dense(ctx)) + x)          vilbert.py:424-428 / :555-559 / :749-756
-  void proj_fwd(const ProjP& p, const ProjA& a, size_t ctx, size_t x, int M, const Drop& dr) {
+  // ctxq / site_ctx: the e4m3 copy of ctx the attention kernel wrote (-1: none, the projection runs in bf16)
+  void proj_fwd(const ProjP& p, const ProjA& a, size_t ctx, size_t x, int M, const Drop& dr, size_t ctxq = (size_t)-1, int site_ctx = -1) {
     Opt o; o.drop = dr; o.addend = A(x); o.ld_add = p.dense.out;
-    lin_fwd(A(ctx), p.dense.in, p.dense, M, A(a.s), p.dense.out, o);
+    if (site_ctx >= 0 && f8_lin(p.dense)) lin_fwd_f8(A(ctx), ctxq, site_ctx, p.dense, M, A(a.s), p.dense.out, o);
+    else lin_fwd(A(ctx), p.dense.in, p.dense, M, A(a.s), p.dense.out, o);
     ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out, a.aq, a.site_a);
   }
   // in: g = grad of a.  out: dres (residual gradient), dctx.  Parameter gradients accumulated.
   void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, size_t part, int M, const Drop& dr,
-                size_t dlq) {
+                size_t dlq, size_t ctxq = (size_t)-1, int site_ctx = -1) {
     const size_t dl = ln_bwd(g, a.s, a.mean, a.rstd, p.ln, p.dense, dres, dlin, part, M, p.dense.out, dr, dlq, a.g_dl);
-    lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M);
+    WgQ8 w8;
+    if (site_ctx >= 0 && f8b_lin(p.dense)) { w8.dyq = dlq; w8.g_dy = a.g_dl; w8.xq = ctxq; w8.site_x = site_ctx; }
+    lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M, false, w8);
     if (f8b_lin(p.dense)) lin_dgrad_f8(dlq, a.g_dl, A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
     else lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
   }
@@ -564,10 +599,10 @@ struct Run {
   void ffn_fwd(const FfnP& p, const FfnA& a, size_t x, size_t xq, int site_x, int M, const Drop& dr) {
     Opt o; o.preact = A(a.u); o.ld_aux = p.up.out; o.act = ACT_GELU;
     const bool q_up = f8_lin(p.up), q_dn = f8_lin(p.down);
-    if (q_up) lin_fwd_f8(xq, site_x, p.up, M, A(a.h), p.up.out, o, a.hq, q_dn ? a.site_h : -1);
+    if (q_up) lin_fwd_f8(A(x), xq, site_x, p.up, M, A(a.h), p.up.out, o, a.hq, q_dn ? a.site_h : -1);
     else lin_fwd(A(x), p.up.in, p.up, M, A(a.h), p.up.out, o);
     Opt o2; o2.drop = dr; o2.addend = A(x); o2.ld_add = p.down.out;
-    if (q_up && q_dn) lin_fwd_f8(a.hq, a.site_h, p.down, M, A(a.s), p.down.out, o2);
+    if (q_up && q_dn) lin_fwd_f8(A(a.h), a.hq, a.site_h, p.down, M, A(a.s), p.down.out, o2);
     else lin_fwd(A(a.h), p.down.in, p.down, M, A(a.s), p.down.out, o2);
     ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out, a.yq, a.site_y);
   }
@@ -593,23 +628,34 @@ struct Run {
   // ---------------------------------------------------------------- self-attention layer
   void self_fwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t xq, int site_x, const uint8_t* km, int B, int T) {
     const int M = B * T, H = p.H, d = H / p.heads;
-    if (f8_lin(p.qkv)) lin_fwd_f8(xq, site_x, p.qkv, M, A(a.qkv), 3 * H, Opt());
+    if (f8_lin(p.qkv)) lin_fwd_f8(A(x), xq, site_x, p.qkv, M, A(a.qkv), 3 * H, Opt());
     else lin_fwd(A(x), H, p.qkv, M, A(a.qkv), 3 * H, Opt());
-    attn_fwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(a.ctx), H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
-    proj_fwd(p.proj, a.proj, a.ctx, x, M, drop(p.p_hid, p.site + 1));
+    const bool cq = f8_lin(p.proj.dense) && attn_q_ok(T, T, d);
+    attn_fwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(a.ctx), H, B, p.heads, T, T, d, drop(p.p_attn, p.site),
+             cq ? a.ctxq : (size_t)-1, cq ? a.site_ctx : -1);
+    proj_fwd(p.proj, a.proj, a.ctx, x, M, drop(p.p_hid, p.site + 1), a.ctxq, cq ? a.site_ctx : -1);
     ffn_fwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, M, drop(p.p_hid, p.site + 2));
   }
-  void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t g, size_t gx, const uint8_t* km, int B, int T) {
+  // xq / site_x: the e4m3 copy of the layer input (fp8 weight gradient of the QKV projection)
+  void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t xq, int site_x, size_t g, size_t gx, const uint8_t* km, int B, int T) {
     // (paired mode: the launches are only queued here, so the layer's weight-gradient flush waits for pair_flush -- end_pending)
     const int M = B * T, H = p.H, d = H / p.heads;
     const StreamScratch& sc = layer_begin();
     ffn_bwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
-    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1), sc.dlq_b);
+    const bool aq = attn_q_ok(T, T, d);
+    const bool cq = aq && f8_lin(p.proj.dense);                 // the forward pass wrote ctxq
+    const bool gq = aq && f8b_lin(p.qkv) && f8_lin(p.qkv);      // e5m2 copy of dqkv: fp8 data and weight gradient of the QKV projection
+    proj_bwd(p.proj, a.proj, a.ctx, sc.gc, sc.dres_b, sc.dlin_b, sc.dctx, sc.part_b, M, drop(p.p_hid, p.site + 1), sc.dlq_b, a.ctxq, cq ? a.site_ctx : -1);
+    uint8_t* dq8 = gq ? W<uint8_t>(sc.dqkvq) : nullptr;
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
-             A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site));
-    lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M, true);
+             A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site), dq8, a.g_dqkv, gq ? dq8 + H : nullptr,
+             gq ? dq8 + 2 * H : nullptr, a.g_dqkv);
+    WgQ8 w8;
+    if (gq) { w8.dyq = sc.dqkvq; w8.g_dy = a.g_dqkv; w8.xq = xq; w8.site_x = site_x; }
+    lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M, true, w8);
     Opt o; o.addend = A(sc.dres_b); o.ld_add = H;
-    lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
+    if (gq) lin_dgrad_f8(sc.dqkvq, a.g_dqkv, A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
+    else lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
     if (defer) end_pending = true;
     else layer_end();
   }
@@ -619,32 +665,43 @@ struct Run {
   void conn_fwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xvq, int site_v, size_t xt, size_t xtq, int site_t) {
     const CrctModelDims& D = e->d;
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
-    if (V.f8_lin(p.qkv1)) V.lin_fwd_f8(xvq, site_v, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());
+    if (V.f8_lin(p.qkv1)) V.lin_fwd_f8(V.A(xv), xvq, site_v, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());
     else V.lin_fwd(V.A(xv), D.Hv, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());     // query1/key1/value1  :662-664
-    if (f8_lin(p.qkv2)) lin_fwd_f8(xtq, site_t, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());
+    if (f8_lin(p.qkv2)) lin_fwd_f8(A(xt), xtq, site_t, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());
     else lin_fwd(A(xt), D.H, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());            // query2/key2/value2  :673-675
     cross_sync(V);                                    // text needs k1, v1; visual needs k2, v2
     // text queries over visual keys/values -> ctx1 [B,T,Hb]  :684-701 (dropout1 = v_attention prob)
+    const bool aq = attn_q_ok(b->T, b->V, d) && attn_q_ok(b->V, b->T, d);
+    const bool cq1 = aq && f8_lin(p.proj_t.dense), cq2 = aq && V.f8_lin(p.proj_v.dense);
     attn_fwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(a.ctx1), Hb, B, D.b_heads,
-             b->T, b->V, d, drop(D.p_v_attn, p.site));
+             b->T, b->V, d, drop(D.p_v_attn, p.site), cq1 ? a.ctx1q : (size_t)-1, cq1 ? a.site_ctx1 : -1);
     // visual queries over text keys/values -> ctx2 [B,V,Hb]  :704-723
     V.attn_fwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(a.ctx2), Hb, B, D.b_heads,
-               b->V, b->T, d, drop(D.p_attn, p.site + 1));
+               b->V, b->T, d, drop(D.p_attn, p.site + 1), cq2 ? a.ctx2q : (size_t)-1, cq2 ? a.site_ctx2 : -1);
     // cross wiring :780 -- visual stream takes ctx2, text stream takes ctx1
-    V.proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2));
-    proj_fwd(p.proj_t, a.proj_t, a.ctx1, xt, Mt, drop(D.p_hidden, p.site + 3));
+    V.proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2), a.ctx2q, cq2 ? a.site_ctx2 : -1);
+    proj_fwd(p.proj_t, a.proj_t, a.ctx1, xt, Mt, drop(D.p_hidden, p.site + 3), a.ctx1q, cq1 ? a.site_ctx1 : -1);
     V.ffn_fwd(p.ffn_v, a.ffn_v, a.proj_v.a, a.proj_v.aq, a.proj_v.site_a, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_fwd(p.ffn_t, a.ffn_t, a.proj_t.a, a.proj_t.aq, a.proj_t.site_a, Mt, drop(D.p_hidden, p.site + 5));
   }
-  void conn_bwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xt, size_t gv, size_t gt, size_t gxv, size_t gxt) {
+  // x*q / site_*: the e4m3 copies of the two layer inputs (fp8 weight gradients of the QKV projections)
+  void conn_bwd(Run& V, const ConnLayerP& p, const ConnLayerA& a, size_t xv, size_t xvq, int site_v, size_t xt, size_t xtq, int site_t, size_t gv,
+                size_t gt, size_t gxv, size_t gxt) {
     const CrctModelDims& D = e->d;
     hipEvent_t free_v = V.set_free[V.parity], free_t = set_free[parity];      // "the last readers of this scratch set are done"
     const StreamScratch& sv = V.layer_begin(); const StreamScratch& st = layer_begin();
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
     V.ffn_bwd(p.ffn_v, a.ffn_v, a.proj_v.a, a.proj_v.aq, a.proj_v.site_a, gv, sv.gc, sv, Mv, drop(D.p_v_hidden, p.site + 4));
     ffn_bwd(p.ffn_t, a.ffn_t, a.proj_t.a, a.proj_t.aq, a.proj_t.site_a, gt, st.gc, st, Mt, drop(D.p_hidden, p.site + 5));
-    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2), sv.dlq_b);   // dctx2 [Mv,Hb]
-    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3), st.dlq_b);       // dctx1 [Mt,Hb]
+    const bool aq = attn_q_ok(b->T, b->V, d) && attn_q_ok(b->V, b->T, d);
+    const bool cq1 = aq && f8_lin(p.proj_t.dense), cq2 = aq && V.f8_lin(p.proj_v.dense);
+    // e5m2 copies of the two fused dqkv buffers: only when BOTH QKV projections run their gradients in fp8 (each buffer is written by
+    // both attention kernels)
+    const bool gq = aq && f8b_lin(p.qkv1) && f8b_lin(p.qkv2) && f8_lin(p.qkv1) && f8_lin(p.qkv2);
+    V.proj_bwd(p.proj_v, a.proj_v, a.ctx2, sv.gc, sv.dres_b, sv.dlin_b, sv.dctx, sv.part_b, Mv, drop(D.p_v_hidden, p.site + 2), sv.dlq_b, a.ctx2q,
+               cq2 ? a.site_ctx2 : -1);   // dctx2 [Mv,Hb]
+    proj_bwd(p.proj_t, a.proj_t, a.ctx1, st.gc, st.dres_b, st.dlin_b, st.dctx, st.part_b, Mt, drop(D.p_hidden, p.site + 3), st.dlq_b, a.ctx1q,
+             cq1 ? a.site_ctx1 : -1);       // dctx1 [Mt,Hb]
     // each attention backward also writes into the OTHER stream's dqkv scratch, which the layer that used this scratch set
     // last (its dgrad, and its weight-gradient GEMMs on the side stream) may still be reading.  With side streams that
     // layer's end is marked by the set's free event (recorded on the side stream behind everything the layer enqueued):
@@ -655,19 +712,27 @@ struct Run {
       if (free_t && !V.rc && hipStreamWaitEvent(V.s, free_t, 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); V.rc = 1; }
     } else cross_sync(V);
     // ctx1 = attn(q2, k1, v1): dq2 -> dqkv2[:, 0:Hb], dk1/dv1 -> dqkv1[:, Hb:3Hb]            (text stream)
+    uint8_t* tq8 = gq ? W<uint8_t>(st.dqkvq) : nullptr;      // text buffer (site g_dqkv2), visual buffer (site g_dqkv1)
+    uint8_t* vq8 = gq ? W<uint8_t>(sv.dqkvq) : nullptr;
     attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
-             3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site));
+             3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site),
+             tq8, a.g_dqkv2, gq ? vq8 + Hb : nullptr, gq ? vq8 + 2 * Hb : nullptr, a.g_dqkv1);
     // ctx2 = attn(q1, k2, v2): dq1 -> dqkv1[:, 0:Hb], dk2/dv2 -> dqkv2[:, Hb:3Hb]            (visual stream)
     V.attn_bwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(sv.dctx), Hb, A(sv.dqkv),
-               3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1));
+               3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1),
+               vq8, a.g_dqkv1, gq ? tq8 + Hb : nullptr, gq ? tq8 + 2 * Hb : nullptr, a.g_dqkv2);
     // each stream's dqkv buffer has been written by BOTH attention backward kernels
     cross_sync(V);
-    V.lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv, true);
+    WgQ8 wv, wt;
+    if (gq) { wv.dyq = sv.dqkvq; wv.g_dy = a.g_dqkv1; wv.xq = xvq; wv.site_x = site_v; wt.dyq = st.dqkvq; wt.g_dy = a.g_dqkv2; wt.xq = xtq; wt.site_x = site_t; }
+    V.lin_wgrad(A(sv.dqkv), 3 * Hb, A(xv), D.Hv, p.qkv1, Mv, true, wv);
     Opt ov; ov.addend = A(sv.dres_b); ov.ld_add = D.Hv;
-    V.lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
-    lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt, true);
+    if (gq) V.lin_dgrad_f8(sv.dqkvq, a.g_dqkv1, A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
+    else V.lin_dgrad(A(sv.dqkv), 3 * Hb, p.qkv1, Mv, A(gxv), D.Hv, ov);
+    lin_wgrad(A(st.dqkv), 3 * Hb, A(xt), D.H, p.qkv2, Mt, true, wt);
     Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
-    lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
+    if (gq) lin_dgrad_f8(st.dqkvq, a.g_dqkv2, A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
+    else lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
     if (defer) { end_pending = true; V.end_pending = true; return; }
     V.layer_end();
     layer_end();
@@ -1018,15 +1083,13 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     for (int j = 0; j < 3; ++j) own(e->fu[j]);     // fusion.6 (fu[3]) and bi_seq_relationship are produced by the head kernel: accumulate-only
   }
   {
-    // fp8 forward: the QKV and FFN Linears whose input width is a whole number of 128-deep fp8 K tiles get an e4m3 weight
-    // shadow and a scale slot (the attention-output / dense1 / dense2 projections read bf16 context rows and stay bf16)
+    // fp8: every Linear of the encoder whose two dimensions are whole numbers of 128-deep fp8 K tiles gets an e4m3 weight shadow
+    // and a scale slot
     auto slot = [&](const LinearP& l) {
       if (l.in % 128 != 0 || l.out % 128 != 0) return;      // forward contracts over `in`, the data gradient over `out`: whole fp8 K tiles both ways
       e->wq_slot[l.w] = (int)e->wq_list.size();
       e->wq_list.push_back({l.w, (int64_t)l.in * l.out});
     };
-    // (the attention-output / biOutput projections read bf16 context rows in forward, but their DATA GRADIENT runs in fp8 too: they
-    // get a shadow as well)
     for (const SelfLayerP& l : e->tl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); slot(l.proj.dense); }
     for (const SelfLayerP& l : e->vl) { slot(l.qkv); slot(l.ffn.up); slot(l.ffn.down); slot(l.proj.dense); }
     for (const ConnLayerP& l : e->cl) {
@@ -1048,16 +1111,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->tla.resize(D.L); e->vla.resize(D.Lv); e->cla.resize(D.n_conn);
   for (int i = 0; i < D.L; ++i) {
     SelfLayerA& a = e->tla[i];
-    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.proj = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
+    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.ctxq = ar.take(Mt * D.H); a.site_ctx = e->n_sites++; a.g_dqkv = e->n_gsites++; a.proj = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
   }
   for (int i = 0; i < D.Lv; ++i) {
     SelfLayerA& a = e->vla[i];
-    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.proj = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites);
+    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.ctxq = ar.take(Mv * D.Hv); a.site_ctx = e->n_sites++; a.g_dqkv = e->n_gsites++; a.proj = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites);
   }
   for (int i = 0; i < D.n_conn; ++i) {
     ConnLayerA& a = e->cla[i];
     a.qkv1 = ar.take(Mv * 3 * D.Hb * 2); a.qkv2 = ar.take(Mt * 3 * D.Hb * 2);
     a.ctx1 = ar.take(Mt * D.Hb * 2); a.ctx2 = ar.take(Mv * D.Hb * 2);
+    a.ctx1q = ar.take(Mt * D.Hb); a.ctx2q = ar.take(Mv * D.Hb);
+    a.site_ctx1 = e->n_sites++; a.site_ctx2 = e->n_sites++; a.g_dqkv1 = e->n_gsites++; a.g_dqkv2 = e->n_gsites++;
     a.proj_v = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.proj_t = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites);
     a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites); a.ffn_t = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
   }
@@ -1327,15 +1392,21 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   CRCT_REQUIRE(s1 <= nseg, "engine_backward: bad segment %d", seg);
   if (s0 == 0) e->wgrad_pass_begin();
   // inputs of every schedule step (outputs of the previous step of that stream)
-  std::vector<size_t> in_t(e->sched.size()), in_v(e->sched.size());
+  // ... with their e4m3 copies and activation scale sites (fp8 weight gradients of the QKV projections)
+  std::vector<size_t> in_t(e->sched.size()), in_v(e->sched.size()), inq_t(e->sched.size()), inq_v(e->sched.size());
+  std::vector<int> ins_t(e->sched.size()), ins_v(e->sched.size());
   {
-    size_t xt = e->eta.y, xv = e->eva.y;
+    size_t xt = e->eta.y, xv = e->eva.y, xtq = e->eta.yq, xvq = e->eva.yq;
+    int site_t = e->eta.site, site_v = e->eva.site;
     for (size_t i = 0; i < e->sched.size(); ++i) {
-      in_t[i] = xt; in_v[i] = xv;
+      in_t[i] = xt; in_v[i] = xv; inq_t[i] = xtq; inq_v[i] = xvq; ins_t[i] = site_t; ins_v[i] = site_v;
       const Step& st = e->sched[i];
-      if (st.kind == 't') xt = e->tla[st.idx].ffn.y;
-      else if (st.kind == 'v') xv = e->vla[st.idx].ffn.y;
-      else { xv = e->cla[st.idx].ffn_v.y; xt = e->cla[st.idx].ffn_t.y; }
+      if (st.kind == 't') { const FfnA& f = e->tla[st.idx].ffn; xt = f.y; xtq = f.yq; site_t = f.site_y; }
+      else if (st.kind == 'v') { const FfnA& f = e->vla[st.idx].ffn; xv = f.y; xvq = f.yq; site_v = f.site_y; }
+      else {
+        const FfnA& fv = e->cla[st.idx].ffn_v; const FfnA& ft = e->cla[st.idx].ffn_t;
+        xv = fv.y; xvq = fv.yq; site_v = fv.site_y; xt = ft.y; xtq = ft.yq; site_t = ft.site_y;
+      }
     }
   }
   if (int r = reset_tickets(e, workspace, (hipStream_t)stream)) return r;
@@ -1360,13 +1431,13 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
       const size_t i = e->sched.size() - (size_t)sgi;
       const Step& st = e->sched[i];
       if (st.kind == 't') {
-        Rt.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], batch->text_keymask, batch->B, batch->T);
+        Rt.self_bwd(e->tl[st.idx], e->tla[st.idx], in_t[i], inq_t[i], ins_t[i], e->st.dy[e->cur_t], e->st.dy[e->cur_t ^ 1], batch->text_keymask, batch->B, batch->T);
         e->cur_t ^= 1;
       } else if (st.kind == 'v') {
-        Rv.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], batch->image_keymask, batch->B, batch->V);
+        Rv.self_bwd(e->vl[st.idx], e->vla[st.idx], in_v[i], inq_v[i], ins_v[i], e->sv.dy[e->cur_v], e->sv.dy[e->cur_v ^ 1], batch->image_keymask, batch->B, batch->V);
         e->cur_v ^= 1;
       } else {
-        Rt.conn_bwd(Rv, e->cl[st.idx], e->cla[st.idx], in_v[i], in_t[i], e->sv.dy[e->cur_v], e->st.dy[e->cur_t], e->sv.dy[e->cur_v ^ 1], e->st.dy[e->cur_t ^ 1]);
+        Rt.conn_bwd(Rv, e->cl[st.idx], e->cla[st.idx], in_v[i], inq_v[i], ins_v[i], in_t[i], inq_t[i], ins_t[i], e->sv.dy[e->cur_v], e->st.dy[e->cur_t], e->sv.dy[e->cur_v ^ 1], e->st.dy[e->cur_t ^ 1]);
         e->cur_t ^= 1; e->cur_v ^= 1;
       }
     }

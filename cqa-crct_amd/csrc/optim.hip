@@ -44,17 +44,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   // A weight [out][in] that also keeps a TRANSPOSED e4m3 shadow (fp8 data gradients) is walked tile by tile instead of chunk by
   // chunk: chunk number c of the tensor is the 64 x 64 tile (c / (in / 64), c % (in / 64)), so that the workgroup holds whole
   // columns of the tile and can write them as 16-byte runs of the transposed copy.  Everything else in the update is elementwise.
-  const int tin = (f8.qt && f8.seg_in) ? f8.seg_in[sgi] : 0;
+  const int tin = (f8.qt && f8.seg_in && f8.seg_t_base && f8.seg_t_ld) ? f8.seg_in[sgi] : 0;
   int64_t row_stride = 64, t_base = 0;
   int t_out = 0;
   if (tin > 0) {
     const int tiles_in = tin >> 6;
     const int64_t c = off / ADAMW_CHUNK;
     const int tr = (int)(c / tiles_in), tc = (int)(c % tiles_in);
-    t_out = (int)(seg_len[sgi] / tin);
+    t_out = f8.seg_t_ld[sgi];                      // rows of the whole (possibly fused) weight = row length of its transposed copy
     base = seg_off[sgi] + (int64_t)tr * 64 * tin + (int64_t)tc * 64;
     row_stride = tin;
-    t_base = seg_off[sgi] + (int64_t)tc * 64 * t_out + (int64_t)tr * 64;
+    t_base = f8.seg_t_base[sgi] + (int64_t)tc * 64 * t_out + (int64_t)tr * 64;
   }
   const float lr = seg_lr[sgi], wd = seg_wd[sgi];
   const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
@@ -196,7 +196,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   CRCT_REQUIRE(step >= 1, "adamw: step must be >= 1 (got %d)", step);
   CrctAmpState amp = {nullptr, nullptr, nullptr};
   if (amp_state) amp = *amp_state;
-  CrctFp8Shadow f8 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  CrctFp8Shadow f8 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (fp8_shadow) f8 = *fp8_shadow;
   CRCT_REQUIRE(!f8.q || (f8.seg_slot && f8.scale && f8.amax), "adamw: incomplete fp8 shadow description");
   if (n_blk <= 0) return 0;

@@ -400,12 +400,17 @@ int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_strea
  * [n_slots * CRCT_FP8_AMAX_LANES].  The update
  * quantises the NEW weights with scale[slot] and max-es max |w| into amax[slot]; the caller runs crct_fp8_update_scales on
  * (scale, amax) before the NEXT update (delayed scaling).  All pointers device memory; q == NULL switches it off.
- * qt / seg_in (both or neither; may be NULL): the TRANSPOSED shadow of the fp8 data-gradient GEMMs (crct_fp8_transpose_weights'
- * layout) kept current by the update itself: seg_in[s] > 0 = segment s is a whole weight [seg_len / seg_in][seg_in] (both
- * multiples of 64) whose bytes are also written to qt as [seg_in][seg_len / seg_in]; 0 = no transposed copy of that segment.
- * The update then walks such a weight in 64 x 64 tiles, which costs one extra byte written per element and no extra launch
- * (a separate transposing launch beside the next forward pass cost the step 0.12-0.33 ms: EXPERIMENTS.md, round 3). */
-typedef struct CrctFp8Shadow { void* q; const int32_t* seg_slot; const float* scale; float* amax; void* qt; const int32_t* seg_in; } CrctFp8Shadow;
+ * qt / seg_in / seg_t_base / seg_t_ld (all or none; may be NULL): the TRANSPOSED shadow of the fp8 data-gradient GEMMs
+ * (crct_fp8_transpose_weights' layout) kept current by the update itself.  seg_in[s] > 0: segment s is a band of whole rows
+ * [seg_len / seg_in][seg_in] (both multiples of 64) of a weight [seg_t_ld[s]][seg_in] -- the weight itself, or one of the three
+ * parameter tensors of a fused QKV weight -- and its bytes are also written to qt, transposed: element (r, c) of the band goes to
+ * byte seg_t_base[s] + c * seg_t_ld[s] + r (seg_t_base = the weight's byte offset + the band's first row).  0 = no transposed
+ * copy of that segment.  The update walks such a band in 64 x 64 tiles, which costs one extra byte written per element and
+ * no extra launch (a separate transposing launch beside the next forward pass cost the step 0.12-0.33 ms: EXPERIMENTS.md). */
+typedef struct CrctFp8Shadow {
+  void* q; const int32_t* seg_slot; const float* scale; float* amax;
+  void* qt; const int32_t* seg_in; const int64_t* seg_t_base; const int32_t* seg_t_ld;
+} CrctFp8Shadow;
 int64_t crct_adamw_plan(const int64_t* seg_len, int n_seg, int32_t* blk_seg, int64_t* blk_off, int64_t cap);
 int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
                     const int64_t* seg_off, const int64_t* seg_len, const float* seg_lr, const float* seg_wd,
@@ -415,6 +420,29 @@ int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16,
 /* g_bf16 (may be NULL): bf16 gradient buffer with the element offsets of g -- the data-parallel exchange's payload
  * (crct/ddp.py: each bucket is packed to bf16, all-reduced, and consumed here as it lies: 2 B instead of 4 B per parameter on
  * the wire and in this kernel's reads).  When set, every gradient element is read from it; g is only written (zero_grads). */
+
+/* fp8 copies of the attention results (BASELINE configs[4]): ctx also as OCP e4m3 (the input of the attention-output
+ * projection's fp8 forward GEMM and weight gradient), dq / dk / dv also as OCP e5m2 (the input of the QKV projections' fp8
+ * data and weight gradients).  Every copy has the shape and leading dimension of its bf16 twin (one byte per element), is
+ * quantised from the bf16-rounded value with *scale (saturating) and max-es max |.| into *amax (CRCT_FP8_AMAX_LANES words);
+ * dk and dv share one scale (they are columns of one fused gradient buffer).  NULL pointers = no copy.  Only the MFMA kernels
+ * write copies: crct_attention_quant_ok(Tq, Tk, d) != 0 says whether a shape runs on them; the _q calls fail otherwise. */
+typedef struct CrctAttnQuant {
+  void* ctx_q; const float* ctx_scale; float* ctx_amax;
+  void* dq_q; void* dk_q; void* dv_q;
+  const float* dq_scale; float* dq_amax; const float* dkv_scale; float* dkv_amax;
+} CrctAttnQuant;
+int crct_attention_quant_ok(int Tq, int Tk, int d);
+int crct_attention_fwd_q(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx,
+                         int B, int heads, int Tq, int Tk, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed, const CrctAttnQuant* quant,
+                         crct_stream_t stream);
+int crct_attention_bwd_q(const void* q, const void* k, const void* v, const uint8_t* keymask,
+                         const void* dctx, void* dq, void* dk, void* dv,
+                         int B, int heads, int Tq, int Tk, int d,
+                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed, const CrctAttnQuant* quant,
+                         crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Step engine: the whole forward + loss + backward of one batch as one native call
@@ -480,7 +508,8 @@ typedef struct CrctStepCfg {
    *   fp8_w_scale     device fp32 [crct_engine_fp8_weights()]: scale of weight slot i (q = w * scale)
    *   fp8_act_scale   device fp32 [crct_engine_fp8_sites()]: scales the producers quantise the activations with
    *   fp8_act_amax    device fp32 [same]: max |activation| seen by this pass, for the caller's crct_fp8_update_scales */
-  int32_t fp8;
+  int32_t fp8;               /* 0 off, 1 on, 2 calibration: copies and maxima are written, the GEMMs read the bf16 operands (a dry forward pass
+                                before the first fp8 one: its maxima are those of the bf16 forward) */
   const void* params_fp8; const float* fp8_w_scale; const float* fp8_act_scale; float* fp8_act_amax;
   /* fp8 backward (configs[4], backward only; needs fp8 != 0).  fp8_bwd = 1: the data-gradient GEMMs of the FFN and attention-output
    * Linears (dx = dy W) read an OCP e5m2 copy of dy -- written by the producing LayerNorm-backward kernel / GELU' epilogue with the

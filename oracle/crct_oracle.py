@@ -36,22 +36,19 @@ def gelu_erf(x):
 
 
 # fp8 emulation of the product's BASELINE configs[4] mode (test yardstick only; the reference has no fp8 mode): the forward of
-# the QKV / FFN Linears whose input width is a multiple of 128 multiplies OCP e4m3 roundings of the input and the weight
-# (per-tensor scale 448 / max |.|), the backward uses the UNquantised operands -- what the HIP path does (bf16 backward from
-# the saved activations).  Switched on by ``FP8_EMULATION = True``.
+# every encoder Linear whose two dimensions are multiples of 128 (QKV, attention output / biOutput, FFN) multiplies OCP e4m3
+# roundings of the input and the weight (per-tensor scale 448 / max |.|), the backward uses the UNquantised operands -- the
+# product with params['fp8_backward'] = False.  Switched on by ``FP8_EMULATION = True``.
 FP8_EMULATION = False
-# ... and of its fp8 BACKWARD (round 3): the data gradients dx = dy W of the FFN Linears and of the attention-output / biOutput
-# projections multiply an OCP e5m2 rounding of dy (per-tensor scale 57344 / max |dy|) with the e4m3 rounding of the weight; the QKV
-# data gradients and every weight gradient use the unquantised operands.  Switched on by ``FP8_BWD_EMULATION = True`` (with
-# FP8_EMULATION).
+# ... and of its fp8 BACKWARD (round 3): the data gradients dx = dy W of the same Linears multiply an OCP e5m2 rounding of dy
+# (per-tensor scale 57344 / max |dy|; the product uses ONE scale for the fused dq | dk | dv gradient of a QKV projection, this
+# emulation one per Linear) with the e4m3 rounding of the weight; the weight gradients use the unquantised operands.  Switched on
+# by ``FP8_BWD_EMULATION = True`` (with FP8_EMULATION).
 FP8_BWD_EMULATION = False
-# ... and of the fp8 WEIGHT gradients of the FFN Linears: dW = dy^T x from the same e5m2 rounding of dy and the e4m3 rounding of x the
-# forward GEMM read; their bias gradients, and the weight gradients of every other Linear, use the unquantised operands.
+# ... and of the fp8 WEIGHT gradients of the same Linears: dW = dy^T x from the same e5m2 rounding of dy and the e4m3 rounding of x
+# the forward GEMM read; the bias gradients use the unquantised dy.
 # Switched on by ``FP8_WGRAD_EMULATION = True`` (with the two above).
 FP8_WGRAD_EMULATION = False
-_FP8_SUFFIXES = ("self.query", "self.key", "self.value", "query1", "key1", "value1", "query2", "key2", "value2",
-                 "intermediate.dense", "v_intermediate.dense", "t_intermediate.dense")
-
 
 def _fp8_round(t):
     s = 448.0 / float(t.detach().abs().max().clamp_min(1e-30))
@@ -86,34 +83,19 @@ class _Fp8Linear(torch.autograd.Function):
         return gx, gw, gy.reshape(-1, gy.shape[-1]).sum(0), None, None, None
 
 
-def _fp8_linear_site(prefix, in_features):
-    if in_features % 128 != 0:
-        return False
-    if prefix.endswith("attention.output.dense"):
-        return False
-    return prefix.endswith(_FP8_SUFFIXES) or prefix.endswith(".output.dense") or prefix.endswith("v_output.dense") or \
-        prefix.endswith("t_output.dense")
-
-
-_FP8_QKV = ("self.query", "self.key", "self.value", "query1", "key1", "value1", "query2", "key2", "value2")
-
-
-def _fp8_dgrad_site(prefix, w):
-    """Linears whose DATA gradient the product computes in fp8: FFN up / down and the attention-output / biOutput projections
-    (both weight dimensions whole 128-deep fp8 K tiles); not the QKV projections."""
-    if w.shape[0] % 128 != 0 or w.shape[1] % 128 != 0 or prefix.endswith(_FP8_QKV):
-        return False
-    return prefix.endswith(("intermediate.dense", "output.dense", "biOutput.dense1", "biOutput.dense2"))
+def _fp8_site(w):
+    """The Linears of the encoder the product runs in fp8: both weight dimensions whole 128-deep fp8 K tiles (the forward
+    contracts over ``in``, the data gradient over ``out``) -- QKV, attention output / biOutput, FFN up and down."""
+    return w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0
 
 
 def linear(sd, prefix, x):
     w = sd[prefix + ".weight"]
     if FP8_EMULATION and ".encoder." in prefix:
-        fwd_q = _fp8_linear_site(prefix, w.shape[1])
-        bwd_q = FP8_BWD_EMULATION and _fp8_dgrad_site(prefix, w)
-        # the FFN Linears: forward and data gradient both in fp8, not a QKV / attention-output / biOutput projection
-        wg_q = FP8_WGRAD_EMULATION and fwd_q and bwd_q and not prefix.endswith(_FP8_QKV) and not prefix.endswith(("biOutput.dense1", "biOutput.dense2"))
-        if fwd_q or bwd_q:
+        fwd_q = _fp8_site(w)
+        bwd_q = FP8_BWD_EMULATION and fwd_q
+        wg_q = FP8_WGRAD_EMULATION and bwd_q
+        if fwd_q:
             return _Fp8Linear.apply(x, w, sd[prefix + ".bias"], fwd_q, bwd_q, wg_q)
     return F.linear(x, w, sd[prefix + ".bias"])
 

@@ -704,6 +704,45 @@ def test_device_events_order_streams_without_the_system_fence(gemm_path):
     assert float(y.min()) == 20.0 and float(y.max()) == 20.0
 
 
+def test_attention_fp8_copies_of_context_and_gradients():
+    """CrctAttnQuant: the MFMA attention kernels also write ctx as OCP e4m3 and dq / dk / dv as OCP e5m2 (what the attention-output
+    and QKV projections' fp8 GEMMs read), quantised from the bf16-rounded results with a device scale, maxima into amax; the bf16
+    results are bit-identical to the plain calls, for every wave count; shapes the MFMA kernels do not cover are refused."""
+    lib = L.load()
+    try:
+        for split in (1, 2, 0):
+            lib.crct_attention_force_split(split)
+            for B, h, Tq, Tk, d in ((3, 16, 100, 100, 64), (3, 32, 40, 100, 32), (5, 12, 20, 20, 64), (5, 16, 36, 36, 64), (4, 32, 20, 36, 32)):
+                g = torch.Generator().manual_seed(Tq * 1000 + Tk + d)
+                q, k, v = (torch.randn(B, T, h * d, generator=g).cuda().bfloat16() for T in (Tq, Tk, Tk))
+                do = (torch.randn(B, Tq, h * d, generator=g) * 1e-3).cuda().bfloat16()
+                km = torch.ones(B, Tk, dtype=torch.uint8, device="cuda")
+                km[:, Tk - 3:] = 0
+                ctx = ops.attention_fwd(q, k, v, km, h, d, p_drop=0.1, site=3, seed=9)
+                sc, am = torch.tensor([37.0], device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV)
+                ctx2, ctx8 = ops.attention_fwd_q(q, k, v, km, h, d, sc, am, p_drop=0.1, site=3, seed=9)
+                assert torch.equal(ctx, ctx2)
+                assert torch.equal(ctx8.view(torch.float8_e4m3fn).float(), _q8(ctx, 37.0).float())
+                assert float(am.max()) == float(ctx.float().abs().max())
+                dq, dk, dv = ops.attention_bwd(q, k, v, km, do, h, d, p_drop=0.1, site=3, seed=9)
+                s1, a1 = torch.tensor([3.0e5], device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV)
+                s2, a2 = torch.tensor([1.0e5], device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV)
+                (dq2, dk2, dv2), (dq8, dk8, dv8) = ops.attention_bwd_q(q, k, v, km, do, h, d, s1, a1, s2, a2, p_drop=0.1, site=3, seed=9)
+                assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+                for t, t8, s in ((dq, dq8, 3.0e5), (dk, dk8, 1.0e5), (dv, dv8, 1.0e5)):
+                    want = (t.float() * s).clamp(-57344, 57344).to(torch.float8_e5m2)
+                    assert torch.equal(t8.view(torch.float8_e5m2).float(), want.float()), (split, Tq, Tk, d)
+                assert float(a1.max()) == float(dq.float().abs().max())
+                assert float(a2.max()) == max(float(dk.float().abs().max()), float(dv.float().abs().max()))
+    finally:
+        lib.crct_attention_force_split(0)
+    assert lib.crct_attention_quant_ok(20, 20, 64) == 1 and lib.crct_attention_quant_ok(20, 20, 40) == 0
+    q = torch.randn(2, 8, 4 * 40, device=DEV).bfloat16()
+    km = torch.ones(2, 8, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.attention_fwd_q(q, q, q, km, 4, 40, torch.ones(1, device=DEV), torch.zeros(L.FP8_AMAX_LANES, device=DEV))
+
+
 # ------------------------------------------------------------------------------------------- attention: waves per (batch, head)
 def _attn_split_case():
     out = {}
