@@ -177,7 +177,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(site_labels, workload):
+def pmc_traffic(site_labels, workload, dtype="bf16"):
     """Fabric-side bytes per launch (average over the launches of `site_labels`, e.g. 't.ffn_up.fwd') from the committed PMC
     passes of this same command (profiles/r*_pmc_sites*.json, made by tools/pmc_sites.py: separate --pmc FETCH_SIZE / WRITE_SIZE
     runs, FETCH_SIZE doubled per MI355X_MICROARCH.md, dispatches matched to the engine's launch log).  A table is used only if
@@ -191,7 +191,7 @@ def pmc_traffic(site_labels, workload):
                 table = json.load(f)
         except (OSError, ValueError):
             continue
-        if table.get("_source_hash") != source_hash() or table.get("_workload") != list(workload):
+        if table.get("_source_hash") != source_hash() or table.get("_workload") != list(workload) or table.get("_dtype", "bf16") != dtype:
             continue
         cand = [table["sites"][k] for k in site_labels if k in table.get("sites", {}) and table["sites"][k].get("bytes_per_launch")]
         if cand:
@@ -396,7 +396,7 @@ def main():
             recs.append(dict(site=L.SITE_NAMES[r.site] if r.site >= 0 else "group", kind=L.KIND_NAMES[r.kind], M=r.M, N=r.N, K=r.K, cfg=r.cfg,
                              split_k=r.split_k, n_problems=r.n_problems, flops=r.flops))
         with open(a.launch_log, "w") as f:
-            json.dump(dict(steps=a.steps, source_hash=source_hash(), workload=[a.batch, a.vis, a.tokens, a.feat], launches=recs), f)
+            json.dump(dict(steps=a.steps, source_hash=source_hash(), workload=[a.batch, a.vis, a.tokens, a.feat], dtype=a.dtype, launches=recs), f)
     host_ms = cur.get("host_ms_per_step")
     final_loss = float(loss.detach())
     # mean loss of the last timed step over the GLOBAL batch: the all-reduced stats when ranks exchange, else the local loss
@@ -473,7 +473,7 @@ def main():
             ffn = ffn_roofline(sites, a.profile_steps)
             grp = ffn["fwd_dgrad"]
             dom = max(rows, key=lambda r: r["ms_per_step"])
-            traffic = pmc_traffic(["%s.%s" % (s, k) for s in FFN_SITES for k in ("fwd", "dgrad")], (a.batch, a.vis, a.tokens, a.feat))
+            traffic = pmc_traffic(["%s.%s" % (s, k) for s in FFN_SITES for k in ("fwd", "dgrad")], (a.batch, a.vis, a.tokens, a.feat), a.dtype)
             out["roofline"] = {"bound": "mfma", "kernel": "FFN GEMMs: text / visual FFN-up + FFN-down, forward + data gradient (%d launches per step)"
                                                              % round(grp["launches_per_step"]),
                                "achieved": grp["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": grp["frac"], "traffic": traffic,

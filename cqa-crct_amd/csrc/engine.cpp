@@ -406,6 +406,7 @@ struct Run {
     g.M = M; g.N = l.in; g.K = l.out; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.seed = c->seed; g.site = l.site;
     g.fp8 = 1 | 2 | 8;                                   // A = e5m2 gradient, B = e4m3 weight; labelled as a data gradient
+    if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][1][phase].cfg >= 0) g.tile = e->policy[l.site][1][phase].cfg;
     g.scale_a = gscale(g_in); g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
     if (g_out >= 0) { g.fp8 |= 4; g.q_out = W<uint8_t>(q_out); g.ld_q = l.in; g.q_scale = gscale(g_out); g.q_amax = gamax(g_out); }
     if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
@@ -431,6 +432,7 @@ struct Run {
     g.M = M; g.N = l.out; g.K = l.in; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
     g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w); g.site = l.site;
+    if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][0][phase].cfg >= 0) g.tile = e->policy[l.site][0][phase].cfg;
     if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; }
     if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
     fail(crct_gemm_bf16(&g, s));
@@ -459,7 +461,8 @@ struct Run {
     }
     if (fold) g.rowsum_out = G(l.b);
     if (f8w) {
-      g.A = W<uint8_t>(q8.dyq); g.B = W<uint8_t>(q8.xq); g.fp8 = 1 | 2; g.tile = 37;
+      g.A = W<uint8_t>(q8.dyq); g.B = W<uint8_t>(q8.xq); g.fp8 = 1 | 2;
+      if (g.tile != 36) g.tile = 37;                      // 2 stages (two workgroups per CU) unless the site policy asks for 3
       g.scale_a = gscale(q8.g_dy); g.scale_b = c->fp8_act_scale + q8.site_x;
       pending_f8.push_back(g);
       return;
@@ -1567,7 +1570,7 @@ extern "C" int crct_engine_set_prefetch(crct_engine_t* e, int workgroups) {
 extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind, int phase, int cfg, int split_k) {
   CRCT_REQUIRE(e && site > 0 && site < CRCT_SITE_COUNT && kind >= CRCT_KIND_FWD && kind <= CRCT_KIND_WGRAD && phase <= 1,
                "set_site_policy: bad site / kind / phase (%d, %d, %d)", site, kind, phase);
-  CRCT_REQUIRE(cfg >= -1 && cfg <= 35 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
+  CRCT_REQUIRE(cfg >= -1 && cfg <= 37 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
   for (int ph = 0; ph < 2; ++ph)
     if (phase < 0 || phase == ph) { e->policy[site][kind][ph].cfg = cfg; e->policy[site][kind][ph].split_k = split_k; }
   return 0;

@@ -16,6 +16,13 @@ rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_IFETCH --kernel-trace --outp
 cc() { find $1 -name "*counter_collection.csv" | head -1; }
 python3 $R/tools/pmc_sites.py /tmp/log1.json $O/${tag}_pmc_sites.json $(cc /tmp/p1) $(cc /tmp/p2) $(cc /tmp/p3) $(cc /tmp/p4) $(cc /tmp/p5) > $O/${tag}_pmc_sites.txt 2>&1
 cp $O/${tag}_pmc_sites.json $R/profiles/${tag}_pmc_sites.json
+# the same for configs[4] (fp8): SQ pass + fabric read / write passes
+rm -rf /tmp/q1 /tmp/q3 /tmp/q4
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d /tmp/q1 -- $PB --dtype fp8 --launch-log /tmp/logq1.json > /tmp/q1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/q3 -- $PB --dtype fp8 --launch-log /tmp/logq3.json > /tmp/q3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/q4 -- $PB --dtype fp8 --launch-log /tmp/logq4.json > /tmp/q4.log 2>&1
+python3 $R/tools/pmc_sites.py /tmp/logq1.json $O/${tag}_pmc_sites_fp8.json $(cc /tmp/q1) $(cc /tmp/q3) $(cc /tmp/q4) > $O/${tag}_pmc_sites_fp8.txt 2>&1
+cp $O/${tag}_pmc_sites_fp8.json $R/profiles/${tag}_pmc_sites_fp8.json
 # long-context configuration (configs[3]): fabric traffic only
 LC="--batch 64 --vis 100 --tokens 40"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p6 -- $PB $LC --launch-log /tmp/log6.json > /tmp/p6.log 2>&1
@@ -32,11 +39,17 @@ cd $R
 F="RCCL\|HIP ver\|ROCm ver\|Hostname\|Librccl\|amdgpu.ids\|socket.cpp"
 python tools/step_phases.py 2>&1 | grep -v "$F" > $O/${tag}_step_phases.txt
 python tools/step_phases.py --exchange bf16 --stats 1 2>&1 | grep -v "$F" > $O/${tag}_step_phases_forced_exchange.txt
+python tools/step_phases.py --dtype fp8 2>&1 | grep -v "$F" > $O/${tag}_step_phases_fp8.txt
+python tools/lab/wgrad_fp8_lab.py 2>&1 | grep -v "$F" > $O/${tag}_wgrad_fp8_lab.txt
+python tools/lab/fp8_draws.py 2>&1 | grep -v "$F" > $O/${tag}_fp8_parity_draws.txt
+./tools/lab/tr8_probe.bin > $O/${tag}_tr8_probe.txt 2>&1
 python tools/coldstart_lab.py 2>&1 | grep -v "$F" > $O/${tag}_coldstart_lab.txt
 python bench.py --steps 20 --warmup 5 2> $O/${tag}_bench_n1.err | grep '^{' > $O/${tag}_bench_n1.json
 python bench.py --steps 20 --warmup 5 --dtype fp8 --no-cpu-baseline 2> $O/${tag}_bench_n1_fp8.err | grep '^{' > $O/${tag}_bench_n1_fp8.json
+python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-bf16-wgrad --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_bf16_wgrad.json
+python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-forward-only --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_forward_only.json
 python bench.py --steps 20 --warmup 5 $LC --no-cpu-baseline 2> $O/${tag}_bench_n1_longctx.err | grep '^{' > $O/${tag}_bench_n1_longctx.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange 2> $O/${tag}_bench_n1_forced_exchange.err | grep '^{' > $O/${tag}_bench_n1_forced_exchange.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --grad-dtype fp32 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp32.json
-for f in bench_n1 bench_n1_fp8 bench_n1_longctx bench_n1_forced_exchange bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
+for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_longctx bench_n1_forced_exchange bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
 head -45 $O/${tag}_pmc_sites.txt

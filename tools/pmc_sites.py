@@ -19,7 +19,7 @@ import re
 import sys
 from collections import defaultdict
 
-GEMM = re.compile(r"gemm_(pipe|splitk|group|f8)?_?kernel<")
+GEMM = re.compile(r"gemm_(pipe|splitk|group|f8|f8t|f8t_group)?_?kernel<")
 
 
 def kind_of_name(name):
@@ -29,7 +29,10 @@ def kind_of_name(name):
     m = re.search(r"gemm_kernel<(\d+), (\d+), (true|false), (true|false)>", name)
     if m:
         return "wgrad" if m.group(3) == "true" else ("dgrad" if m.group(4) == "true" else "fwd")
-    return "fwd"          # gemm_f8_kernel
+    if "gemm_f8t" in name:
+        return "wgrad"        # token-major fp8 weight gradients
+    m = re.search(r"gemm_f8_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    return "dgrad" if (m and m.group(6) == "true") else "fwd"          # gemm_f8_kernel: A_BF8 = an e5m2 gradient operand
 
 
 def load(path):
@@ -95,7 +98,7 @@ def main():
             e["mfma_busy_frac_of_chip"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["us_serialised"] * 2400.0 * 1024.0)
             e["tflops_serialised"] = e["gflop"] / e["us_serialised"] * 1e3          # GFLOP / us = PFLOP/s
         sites[key] = e
-    out = dict(_source_hash=log.get("source_hash"), _workload=log.get("workload"), _steps=log.get("steps"), _mismatched_dispatches=mismatches,
+    out = dict(_source_hash=log.get("source_hash"), _workload=log.get("workload"), _dtype=log.get("dtype", "bf16"), _steps=log.get("steps"), _mismatched_dispatches=mismatches,
                _note="per launch averages; dispatches serialised by the profiler (caches / order of the real step, no concurrency)", sites=sites)
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1)
