@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
+    ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
     ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
@@ -308,6 +309,8 @@ def main():
     opt.lazy_zero_grad = not a.eager_zero_grad
     if a.adamw_wgs >= 0:
         opt.overlap_workgroups = a.adamw_wgs
+    if a.adamw_groups >= 0:
+        opt.launch_groups = a.adamw_groups
     if a.opt_early and opt.overlap:
         opt.set_early(True)                          # ... or start per segment as soon as backward has finished it
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])

@@ -87,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
         self.overlap = False
         self.overlap_workgroups = 256        # throttle of the overlapped launches (one workgroup per CU), 0 = full width
+        self.launch_groups = 0               # > 0: the overlapped update in that many launches instead of one per backward segment
         self.fp8_transpose_workgroups = 256  # same for the transposed fp8 weight shadow that follows the update (fp8 backward)
         # the update zeroes every gradient element it has consumed; the zero_grad() that follows is then free.  Off by
         # default: torch optimizers leave .grad untouched in step() (a caller may still want to read it there)
@@ -231,6 +232,31 @@ class FusedAdamW(torch.optim.Optimizer):
                                                     int(st["w_updates"] % self.core.FP8_AMAX_WINDOW == 0), L.ptr(found), 448.0, stream),
                     "fp8_update_scales")
 
+    def _launch_groups(self, order):
+        """``order`` (segments in first-use order) cut into ``launch_groups`` runs of similar block counts, the first segment alone."""
+        key = (tuple(order), self.launch_groups)
+        if getattr(self, "_groups_key", None) != key:
+            sizes = [self._seg_blocks[i][1] - self._seg_blocks[i][0] for i in order]
+            groups, rest = [[order[0]]], order[1:]
+            n_rest = max(self.launch_groups - 1, 1)
+            target = (sum(sizes[1:]) + n_rest - 1) // n_rest
+            cur, acc = [], 0
+            for i, sz in zip(rest, sizes[1:]):
+                cur.append(i)
+                acc += sz
+                if acc >= target and len(groups) < self.launch_groups - 1:
+                    groups.append(cur)
+                    cur, acc = [], 0
+            if cur:
+                groups.append(cur)
+            for g in groups:                     # block ranges of a run must be adjacent (the flat buffer is in reverse first-use order)
+                spans = sorted(self._seg_blocks[i] for i in g if self._seg_blocks[i][1] > self._seg_blocks[i][0])
+                if any(a[1] != b[0] for a, b in zip(spans, spans[1:])):
+                    raise RuntimeError("optimizer launch groups: segments of a group are not adjacent in the block table")
+            self._groups_key, self._groups = key, groups
+            self._group_events = [None] * len(self._seg_blocks)
+        return self._groups
+
     def _plan_overlap(self):
         """Block ranges of the optimizer's table per engine backward-segment (both are sorted by flat offset)."""
         eng = self.core._engine
@@ -309,6 +335,22 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._upload_hyper(self._opt_stream)          # not behind the backward pass that `cur` still runs
                 order = range(n)                              # the order backward finishes them: heads ... embeddings
             self._fp8_before_update(self._opt_stream.cuda_stream)
+            if done is None and self.launch_groups > 0:
+                # fewer, larger launches: consecutive segments (adjacent block ranges) share one launch and one event; the first
+                # group is the first segment alone, so that the next forward can start at once
+                for members in self._launch_groups(list(order)):
+                    b0 = min(self._seg_blocks[i][0] for i in members)
+                    b1 = max(self._seg_blocks[i][1] for i in members)
+                    if b1 > b0:
+                        self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, self.overlap_workgroups)
+                    ev = self._events[members[0]]
+                    ev.record(self._opt_stream)
+                    for i in members[1:]:
+                        self._group_events[i] = ev
+                    self._group_events[members[0]] = ev
+                core._param_events = list(self._group_events)
+                core._opt_stream = self._opt_stream
+                order = ()
             for sgi in order:
                 b0, b1 = self._seg_blocks[sgi]
                 if done is not None:
@@ -319,7 +361,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._events[sgi].record(self._opt_stream)
             if done is not None:
                 order_streams(cur, self._opt_stream)          # the gradient memset that follows must not pass backward's tail
-            core._param_events = self._events                # the next forward waits segment by segment
+            if not (done is None and self.launch_groups > 0):
+                core._param_events = self._events            # the next forward waits segment by segment
             core._opt_stream = self._opt_stream               # ... and the next backward for the whole stream
         else:
             self._upload_hyper()
