@@ -59,6 +59,20 @@ def test_cpu_baseline_object(line):
     assert c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str) and c["sample"]
 
 
+def test_driver_entry_points_are_there():
+    """__graft_entry__.py: build() (compile every HIP source for gfx950, load the library, check the ABI) and smoke() exist and
+    build() works here without a GPU.  (The file was once committed EMPTY for most of a round: nothing imported it.)"""
+    import importlib
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    assert callable(getattr(g, "build", None)) and callable(getattr(g, "smoke", None))
+    g.build()
+    for top in ("bench.py", "DESIGN.md", "INTEGRATION.md", "include/crct_hip.h", "oracle/crct_oracle.py"):
+        assert os.path.getsize(os.path.join(ROOT, top)) > 1000, top
+
+
 @pytest.mark.gpu
 def test_two_rank_bench_runs_end_to_end():
     """The N > 1 path of bench.py as the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 bench.py
