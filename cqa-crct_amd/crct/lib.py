@@ -106,6 +106,7 @@ PROTOTYPES = {
     "crct_gemm_bf16_grouped": (C.c_int, [C.POINTER(GemmArgs), C.c_int, vp]),
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_group_max_workgroups": (C.c_int, [C.c_int]),
+    "crct_gemm_group_concat": (C.c_int, [C.c_int]),
     "crct_gemm_force_generic": (C.c_int, [C.c_int]),
     "crct_prof_enable": (C.c_int, [C.c_int]),
     "crct_prof_reset": (C.c_int, []),

@@ -1184,22 +1184,51 @@ struct GroupArgs {
   int n;
   int tile_begin[GROUP_MAX + 1];       // first block of every problem (multiples of 8: a problem starts on XCD 0)
   TileMap map[GROUP_MAX];              // per-problem XCD-aware block -> tile map, as for single launches
+  // concat != 0 (the weight gradients of a layer): the tiles of ALL problems form one list -- problem after problem, inside a
+  // problem along its shorter grid dimension first -- and XCD x (= block % 8) takes the x-th run of per_xcd consecutive tiles.  A
+  // run then lies inside one or two problems and covers a compact rectangle of each: an XCD's private L2 fetches the operand
+  // panels of ~1/8 of the group instead of 1/8 of EVERY problem (fabric reads of a text layer's group 143 -> ~50 MB).
+  int concat, per_xcd;
+  int tile_prefix[GROUP_MAX + 1];      // tiles before every problem (concat mode)
   CrctGemmArgs p[GROUP_MAX];           // the problems with their full epilogues (ta / tb are the kernel's template arguments)
 };
+// block -> (problem, tile) of a grouped launch; false: a padding block
+__device__ __forceinline__ bool group_pick(const GroupArgs& ga, int bid, int& pi, int& tm, int& tn) {
+  pi = 0;
+  if (ga.concat) {
+    const int j = bid >> 3, t = (bid & 7) * ga.per_xcd + j;
+    if (j >= ga.per_xcd || t >= ga.tile_prefix[ga.n]) return false;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+      if (i < ga.n && t >= ga.tile_prefix[i]) pi = i;
+    const int local = t - ga.tile_prefix[pi], nm = ga.map[pi].tiles_m, nn = ga.map[pi].tiles_n;
+    if (nn <= nm) { tm = local / nn; tn = local - tm * nn; }
+    else { tn = local / nm; tm = local - tn * nm; }
+    return true;
+  }
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
+  return map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn);
+}
+inline void group_concat(GroupArgs& ga, int* grid) {      // host side of concat mode
+  int tiles = 0;
+  for (int i = 0; i < ga.n; ++i) { ga.tile_prefix[i] = tiles; tiles += ga.map[i].tiles_m * ga.map[i].tiles_n; }
+  ga.tile_prefix[ga.n] = tiles;
+  ga.concat = 1;
+  ga.per_xcd = (tiles + 7) / 8;
+  *grid = 8 * ga.per_xcd;
+}
 
 // A grid smaller than the tile count (launch_group's max_wgs) makes the workgroups persistent: workgroup b takes tiles b, b + grid,
 // ... -- the weight gradients then occupy at most `grid` CUs' LDS at a time and the data-gradient chain that runs beside them
 // finds free CUs at once (grid a multiple of 8: a workgroup's tiles stay on its XCD's rectangle).
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArgs ga) {
-  const int total = ga.tile_begin[ga.n];
+  const int total = ga.concat ? 8 * ga.per_xcd : ga.tile_begin[ga.n];
   for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < GROUP_MAX; ++i)
-      if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
-    int tm, tn;
-    if (map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) {
+    int pi, tm, tn;
+    if (group_pick(ga, bid, pi, tm, tn)) {
       CrctGemmArgs g = ga.p[pi];
       g.ta = TA; g.tb = TB;
       gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
@@ -1209,6 +1238,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
 }
 
 static int g_group_max_wgs = 0;        // crct_gemm_group_max_workgroups: 0 = one workgroup per tile
+static int g_group_concat = 0;         // crct_gemm_group_concat: grouped weight gradients as ONE tile list over the XCDs (GroupArgs.concat); measured: no gain
+extern "C" int crct_gemm_group_concat(int on) { g_group_concat = on != 0; return 0; }
 extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -1227,6 +1258,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
     ga.p[i] = g;
   }
   ga.tile_begin[n] = total;
+  if (gs[0].ta && g_group_concat) group_concat(ga, &total);      // the weight gradients of a layer
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_GROUP(TA_, TB_)                                                                                        \
@@ -1251,14 +1283,10 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
 // the fp8 weight gradients of a layer in one grid (same block -> (problem, tile) table, gemm_f8t_body per tile)
 template <int TM, int TN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_group_kernel(const GroupArgs ga) {
-  const int total = ga.tile_begin[ga.n];
+  const int total = ga.concat ? 8 * ga.per_xcd : ga.tile_begin[ga.n];
   for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < GROUP_MAX; ++i)
-      if (i < ga.n && bid >= ga.tile_begin[i]) pi = i;
-    int tm, tn;
-    if (map_tile(ga.map[pi], bid - ga.tile_begin[pi], tm, tn)) gemm_f8t_body<TM, TN, WM, WN, NS>(ga.p[pi], tm, tn);
+    int pi, tm, tn;
+    if (group_pick(ga, bid, pi, tm, tn)) gemm_f8t_body<TM, TN, WM, WN, NS>(ga.p[pi], tm, tn);
     if (bid + (int)gridDim.x < total) __syncthreads();
   }
 }
@@ -1277,6 +1305,7 @@ hipError_t launch_group_f8t(const CrctGemmArgs* gs, int n, hipStream_t s) {
     ga.p[i] = gs[i];
   }
   ga.tile_begin[n] = total;
+  if (g_group_concat) group_concat(ga, &total);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   auto kern = gemm_f8t_group_kernel<TM, TN, WM, WN, NS>;
   static bool attr_set = false;

@@ -102,6 +102,12 @@ int crct_gemm_bf16_grouped(const CrctGemmArgs* args, int n, crct_stream_t stream
  * a layer's weight gradients occupy at most that many CUs at a time beside the data-gradient chain.  Process-wide knob of the
  * developer tools (bench.py --wgrad-wgs); results are identical for every value. */
 int crct_gemm_group_max_workgroups(int n);
+/* Block -> tile placement of a grouped weight-gradient launch.  0 (default): every problem is cut into 8 rectangles, one per XCD
+ * (each XCD touches every problem: 2.5 - 3.6 x the distinct operand bytes at the fabric).  on != 0: the tiles of all problems form
+ * one list and each XCD takes one run of consecutive tiles, i.e. a compact part of one or two problems, so that its private L2
+ * fetches ~1/8 of the group's operand panels.  Results are identical; measured neutral to slightly slower in the step
+ * (EXPERIMENTS.md round 3), kept as the developer A/B switch behind that statement (bench.py --wgrad-concat). */
+int crct_gemm_group_concat(int on);
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 
