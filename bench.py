@@ -99,6 +99,8 @@ def parse():
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
+    ap.add_argument("--exchange-pack-all", action="store_true", help="developer A/B: the exchange packs every gradient from fp32 (the weight-gradient "
+                    "GEMMs do not write the bf16 communication buffer themselves)")
     ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
     ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
@@ -322,6 +324,8 @@ def main():
     if exchange:                                     # attaches itself to the model
         ddp = FlatGradDDP(model, bucket_mb=a.bucket_mb, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32)
         ddp.force_exchange = bool(a.force_exchange)
+        if a.exchange_pack_all:
+            ddp.direct_bf16_wgrad = False
         ddp.debug_skip = tuple(filter(None, a.exchange_skip.split(",")))
     stats_red = AsyncStats(world, device=dev, ddp=ddp) if (exchange and "stats" not in a.exchange_skip) else None
     host_pool = [S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i) for i in range(8)]
@@ -452,6 +456,7 @@ def main():
                 "step_payload": {"dtype": a.grad_dtype, "bytes_per_step": used * (2 if a.grad_dtype == "bf16" else 4),
                                  "buckets": len(ddp._buckets or ()), "bucket_mb_of_fp32_gradients": a.bucket_mb,
                                  "collectives_issued_inside_the_backward_call": ddp.issued_inside_engine_call,
+                                 "weight_gradients_written_as_bf16_by_the_gemms": bool(getattr(ddp, "packed_runs_only", False)),
                                  "route": "RCCL called directly on the engine's auxiliary stream" if rc is not None else "torch.distributed (%s)" % dist.get_backend(),
                                  "hardware_queue_classes_seen": getattr(core, "queue_classes", None), "weight_gradient_streams": wg_mode,
                                  "single_rank_forced": bool(a.force_exchange and world == 1)}}

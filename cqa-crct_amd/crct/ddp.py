@@ -80,12 +80,13 @@ class BucketExchange(object):
     pack / unpack are HIP kernels; the CPU / gloo tests pass plain functions."""
 
     def __init__(self, flat_grads, buckets, group, comm_buf=None, materialize=False, stream_ctx=None, wait_events=None,
-                 pack=None, unpack=None, after_bucket=None, collective=None):
+                 pack=None, unpack=None, after_bucket=None, collective=None, pack_bucket=None):
         self.flat, self.buckets, self.group = flat_grads, buckets, group
         self.comm_buf, self.materialize = comm_buf, materialize
         self.stream_ctx = stream_ctx or contextlib.nullcontext
         self.wait_events = wait_events or (lambda b: None)
         self.pack = pack or (lambda src, dst: dst.copy_(src))
+        self.pack_bucket = pack_bucket      # pack_bucket(b): packs only what is not in the communication buffer yet (see FlatGradDDP.backward)
         self.unpack = unpack or (lambda src, dst: dst.copy_(src))
         self.after_bucket = after_bucket or (lambda b: None)
         # the collective: by default torch.distributed (gloo in the CPU tests; blocks until done), on the GPU RCCL called
@@ -103,7 +104,10 @@ class BucketExchange(object):
             self.wait_events(b)
             if self.comm_buf is not None:
                 if "pack" not in self.debug_skip:
-                    self.pack(self.flat[lo:hi], self.comm_buf[lo:hi])
+                    if self.pack_bucket is not None:
+                        self.pack_bucket(b)
+                    else:
+                        self.pack(self.flat[lo:hi], self.comm_buf[lo:hi])
                 payload = self.comm_buf[lo:hi]
             else:
                 payload = self.flat[lo:hi]
@@ -149,6 +153,8 @@ class FlatGradDDP(object):
         self.issued_inside_engine_call = 0      # collectives launched from the engine's callback during the last pass
         self._grad_source_valid = False
         self._rccl = None
+        self.direct_bf16_wgrad = True       # bf16 payload: the engine writes the Linear weight gradients into the communication buffer itself
+        self.packed_runs_only = False
         if broadcast:      # DDP constructor semantics: rank 0's parameters win (train.py:139)
             dist.broadcast(self.core.flat_params, 0, group=process_group)
             self.core._invalidate_shadow()
@@ -192,6 +198,33 @@ class FlatGradDDP(object):
         return [[(lambda st, ev=self._bucket_done[b]: st.wait_event(ev))] for b in self._seg_bucket]
 
     # ------------------------------------------------------------------ backward
+    def _pack_plans(self, core, eng):
+        """Per bucket: device tables (run offsets, run lengths, chunk table) of the gradient elements the engine does NOT own, i.e.
+        what still has to be cast into the bf16 communication buffer when the weight-gradient GEMMs write there themselves."""
+        key = eng.wgrad_owned_key()
+        if getattr(self, "_pack_plans_key", None) == key:
+            return self._pack_plans_cache
+        runs = core.non_owned_grad_runs()
+        plans = None
+        if runs is not None:
+            from . import lib as L
+            lib = L.load()
+            dev = core.flat_grads.device
+            plans = []
+            for _, lo, hi in self._buckets:
+                mine = [(max(o, lo), min(o + n, hi) - max(o, lo)) for o, n in runs if o < hi and o + n > lo]
+                if not mine:
+                    plans.append((None, None, None, None, 0))
+                    continue
+                num_host = torch.tensor([n for _, n in mine], dtype=torch.int64)
+                n_blk = lib.crct_adamw_plan(num_host.data_ptr(), len(mine), None, None, 0)
+                blk_seg, blk_off = torch.empty(n_blk, dtype=torch.int32), torch.empty(n_blk, dtype=torch.int64)
+                lib.crct_adamw_plan(num_host.data_ptr(), len(mine), blk_seg.data_ptr(), blk_off.data_ptr(), n_blk)
+                plans.append((torch.tensor([o for o, _ in mine], dtype=torch.int64, device=dev), num_host.to(dev), blk_seg.to(dev),
+                              blk_off.to(dev), int(n_blk)))
+        self._pack_plans_key, self._pack_plans_cache = key, plans
+        return plans
+
     def _plan(self, eng):
         self._buckets = plan_buckets(eng.segments, self.bucket_elems)
         self._seg_bucket, b = [], 0
@@ -249,12 +282,29 @@ class FlatGradDDP(object):
         def unpack(src, dst):
             L.check(lib.crct_cast_bf16_f32(src.data_ptr(), dst.data_ptr(), src.numel(), comm.cuda_stream), "unpack gradients")
 
+        # The engine writes the OWNED weight gradients (every Linear weight: ~95 % of the elements) straight into the communication
+        # buffer, rounded to bf16 by the GEMM epilogue (CrctStepCfg.grads_bf16): packing then only casts the runs of elements
+        # backward accumulates in fp32 (biases, LayerNorm, embeddings, heads).  Only on a pass that WRITES those gradients
+        # (wgrad_overwrite: the first pass after a clear -- an accumulation pass adds in fp32 and packs everything).
+        direct = self.grad_dtype == torch.bfloat16 and bool(step.get("wgrad_overwrite")) and self.direct_bf16_wgrad
+        plans = self._pack_plans(core, eng) if direct else None
+        pack_bucket = None
+        if plans is not None:
+            step["grads_bf16"] = self._comm_buf
+
+            def pack_bucket(b):
+                off, num, blk_seg, blk_off, n_blk = plans[b]
+                if n_blk:
+                    L.check(lib.crct_cast_runs_f32_bf16(core.flat_grads.data_ptr(), self._comm_buf.data_ptr(), off.data_ptr(), num.data_ptr(),
+                                                        blk_seg.data_ptr(), blk_off.data_ptr(), n_blk, comm.cuda_stream), "pack gradients (runs)")
+        self.packed_runs_only = plans is not None
         rccl = self.communicator()
         collective = (lambda t: rccl.all_reduce_(t, comm)) if rccl is not None else None        # on the auxiliary stream itself: no hidden stream
         ex = BucketExchange(core.flat_grads, self._buckets, self.group,
                             comm_buf=self._comm_buf if self.grad_dtype == torch.bfloat16 else None,
                             materialize=self.materialize_grads, stream_ctx=lambda: torch.cuda.stream(comm), wait_events=wait_events,
-                            pack=pack, unpack=unpack, after_bucket=lambda b: self._bucket_done[b].record(comm), collective=collective)
+                            pack=pack, unpack=unpack, after_bucket=lambda b: self._bucket_done[b].record(comm), collective=collective,
+                            pack_bucket=pack_bucket)
         self.last_exchange = ex
         ex.debug_skip = getattr(self, "debug_skip", ())
 

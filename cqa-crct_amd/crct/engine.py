@@ -94,6 +94,7 @@ class StepEngine(object):
         c.tol_margin, c.nsp_coeff, c.reg_coeff = step["tol_margin"], step["nsp_coeff"], step["reg_coeff"]
         c.grad_scale = step.get("grad_scale", 1.0)
         c.wgrad_overwrite = int(bool(step.get("wgrad_overwrite", False)))
+        c.grads_bf16 = L.ptr(step.get("grads_bf16")) if c.wgrad_overwrite else None
         c.seed = int(step["seed"])
         c.g_nsp_dev, c.g_reg_dev, c.g_loss_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg")), L.ptr(step.get("g_loss"))
         f8 = step.get("fp8")

@@ -91,7 +91,7 @@ class StepCfg(C.Structure):
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
                 ("fp8_bwd", c_i32), ("fp8_wgrad", c_i32), ("params_fp8_t", vp), ("fp8_grad_scale", vp), ("fp8_grad_amax", vp),
-                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32)]
+                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32), ("grads_bf16", vp)]
 
 
 SEG_ENQUEUED_FN = C.CFUNCTYPE(None, C.c_int, vp)      # void (*seg_enqueued)(int seg, void* user)
@@ -139,6 +139,7 @@ PROTOTYPES = {
     "crct_prefetch": (C.c_int, [vp, c_i64, C.c_int, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
+    "crct_cast_runs_f32_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
     "crct_attention_fwd_q": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp, vp]),

@@ -351,6 +351,13 @@ class CrctModel(nn.Module):
                                         blk_off.data_ptr(), n_blk, L.current_stream()), "zero_runs")
         self._wgrad_overwrite_next = True
 
+    def non_owned_grad_runs(self):
+        """Host list of (offset, numel) runs of the flat gradient buffer that backward ACCUMULATES into (everything but the Linear
+        weight gradients the engine owns); None before the first engine exists.  Same runs as the lazy clear's."""
+        if self._lazy_zero_plan() is None:
+            return None
+        return list(self._lazy_runs)
+
     def _lazy_zero_plan(self):
         """Device tables for crct_zero_runs over the complement of the engine's owned weight gradients.  The owned set is
         fixed by the layout (crct_engine_wgrad_owned), so one plan serves every engine this model creates; it is keyed on
@@ -373,6 +380,7 @@ class CrctModel(nn.Module):
                 runs[-1][1] += e.numel
             else:
                 runs.append([e.offset, e.numel])
+        self._lazy_runs = [tuple(r) for r in runs]
         plan = None
         if owned and runs:
             dev = self._flat_g.device

@@ -458,6 +458,10 @@ struct Run {
     if (c->wgrad_overwrite && e->wgrad_owned.count(l.w)) {
       if (++e->wgrad_pass[l.w] > 1) { rc = 1; crct_set_error("engine_backward: weight gradient at offset %lld is produced twice in one pass but is listed as owned", (long long)l.w); return; }
       g.accumulate = 0;               // the only producer of this gradient: write it, whatever the buffer held
+      if (c->grads_bf16) {            // ... straight into the exchange's bf16 buffer (CrctStepCfg.grads_bf16): the caller packs none of the owned gradients
+        if (l.in % 8 != 0 || l.w % 8 != 0) { rc = 1; crct_set_error("engine_backward: owned weight gradient at offset %lld (in = %d) cannot be written as bf16 rows", (long long)l.w, l.in); return; }
+        g.C = reinterpret_cast<bf16_t*>(c->grads_bf16) + l.w; g.c_is_f32 = 0;
+      }
     }
     if (fold) g.rowsum_out = G(l.b);
     if (f8w) {

@@ -794,6 +794,29 @@ __global__ void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
     for (long j = i; j < n; ++j) y[j] = f2bf(x[j]);
 }
 
+// y[off[r] + i] = bf16(x[off[r] + i]) over the runs (off, len) of a chunk table (crct_adamw_plan over the run lengths): the gradients
+// backward ACCUMULATES into (biases, LayerNorm, embeddings, heads) on their way into the bf16 exchange buffer, whose other
+// elements -- the Linear weight gradients -- the weight-gradient GEMMs have written there themselves
+__global__ __launch_bounds__(256) void cast_runs_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, const int64_t* __restrict__ run_off,
+                                                        const int64_t* __restrict__ run_len, const int32_t* __restrict__ blk_seg,
+                                                        const int64_t* __restrict__ blk_off, int n_blk) {
+  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    const int r = blk_seg[blk];
+    const int64_t off = blk_off[blk], base = run_off[r] + off;
+    int64_t n = run_len[r] - off;
+    if (n > 4096) n = 4096;                      // = ADAMW_CHUNK (optim.hip)
+    const int64_t head = (8 - (base & 7)) & 7;   // elements in front of the first 16-byte boundary of the bf16 side
+    for (int64_t i = threadIdx.x; i < (head < n ? head : n); i += 256) y[base + i] = f2bf(x[base + i]);
+    const int64_t nv = n > head ? (n - head) / 8 : 0;
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+      const int64_t e = base + head + 8 * i;
+      const float4 a = *reinterpret_cast<const float4*>(x + e), b = *reinterpret_cast<const float4*>(x + e + 4);
+      *reinterpret_cast<uint4*>(y + e) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+    }
+    for (int64_t i = head + nv * 8 + threadIdx.x; i < n; i += 256) y[base + i] = f2bf(x[base + i]);
+  }
+}
+
 __global__ void uncast_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   const long stride = (long)gridDim.x * blockDim.x * 8;
@@ -1386,6 +1409,17 @@ int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream)
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_cast_runs_f32_bf16(const float* x, void* y, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
+                            int64_t n_blk, crct_stream_t stream) {
+  CRCT_REQUIRE(x && y && off && len && blk_seg && blk_off, "cast_runs: null argument");
+  CRCT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cast_runs: 16-byte aligned buffers");
+  if (n_blk <= 0) return 0;
+  const long grid = n_blk > 2048 ? 2048 : n_blk;
+  hipLaunchKernelGGL(cast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, off, len, blk_seg, blk_off, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

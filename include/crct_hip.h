@@ -256,6 +256,11 @@ int crct_prefetch(const void* ptr, int64_t bytes, int workgroups, crct_stream_t 
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
 /* bf16 -> fp32 copy (a gradient bucket exchanged as bf16 put back into the fp32 gradient buffer for callers that read .grad). */
 int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream);
+/* y[off[r] + i] = bf16(x[off[r] + i]) for the runs (off[r], len[r]) of element offsets (x fp32, y bf16, same element offsets; 16-byte
+ * aligned bases), walked by the chunk table (blk_seg, blk_off) of crct_adamw_plan(len, ...).  The data-parallel exchange packs with
+ * it what the weight-gradient GEMMs have not already written into the bf16 buffer (CrctStepCfg.grads_bf16). */
+int crct_cast_runs_f32_bf16(const float* x, void* y, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
+                            int64_t n_blk, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scaled-dot-product attention over short sequences, one workgroup per (batch, head), everything
@@ -541,6 +546,11 @@ typedef struct CrctStepCfg {
                                 then WRITTEN instead of added to (bit-identical to adding into zeros) and need not be zeroed --
                                 no 0.96 GB zero fill and no read-modify-write of the weight gradients per step.  All other
                                 gradients (biases, LayerNorm, embeddings, heads) are still accumulated and must be zero. */
+  void* grads_bf16;          /* backward only, with wgrad_overwrite; may be NULL.  A bf16 buffer with the element offsets of grads_f32
+                                (the data-parallel exchange's payload, crct/ddp.py): the OWNED weight gradients are then written there,
+                                rounded to bf16 by the GEMM epilogue, and NOT into grads_f32 -- the exchange need not pack them (1.4 GB
+                                of traffic per step less) and the weight-gradient GEMMs write half the bytes.  Every other gradient
+                                still goes to grads_f32. */
 } CrctStepCfg;
 
 int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,

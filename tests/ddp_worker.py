@@ -100,6 +100,14 @@ def main():
     out["g_bf16_local_fp32"] = core.flat_grads.detach().cpu().numpy().copy()
     out["issued_inside_call_bf16"] = np.array([ddp16.issued_inside_engine_call])
     out["stats9_async"] = red.result().cpu().numpy()
+    out["packed_runs_only_after_full_clear"] = np.array([int(ddp16.packed_runs_only)])
+    # (3b) after a LAZY clear the pass writes the owned weight gradients: the engine puts them into the communication buffer itself
+    # (bf16 from the GEMM epilogue) and the exchange packs only the accumulated runs -- the same bits as packing everything
+    core.zero_flat_grads(lazy=True)
+    step_forward(model, mine, params)[0].backward()
+    torch.cuda.synchronize()
+    out["g_bf16_direct"] = ddp16.grad_source().float().cpu().numpy().copy()
+    out["packed_runs_only_after_lazy_clear"] = np.array([int(ddp16.packed_runs_only)])
     # (4) materialize_grads: the all-reduced bf16 bucket is written back into the fp32 .grad views (same weights, same batch)
     ddp16.materialize_grads = True
     core.zero_flat_grads()

@@ -99,6 +99,9 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     # materialize_grads: what the fp32 .grad views hold afterwards is that bf16 result (rewritten for this pass's batch: equal
     # to g_bf16 up to the dropout-free determinism of the step)
     assert np.array_equal(r0["g_materialized"][used], r0["g_bf16"][used])
+    # weight gradients written into the communication buffer by the GEMMs themselves (after a lazy clear): the same bits
+    assert int(r0["packed_runs_only_after_full_clear"][0]) == 0 and int(r0["packed_runs_only_after_lazy_clear"][0]) == 1
+    assert np.array_equal(r0["g_bf16_direct"][used], r0["g_bf16"][used]) and np.array_equal(r1["g_bf16_direct"][used], r0["g_bf16_direct"][used])
     # the AdamW step from the bf16 buffer moved the parameters (both ranks identically: asserted above)
     assert not np.array_equal(r0["params_after_step"][:4096], r0["params_after_broadcast"])
     # no exchange on the accumulation-only micro-step: the two ranks' local gradients differ
