@@ -49,7 +49,10 @@ python bench.py --steps 20 --warmup 5 --dtype fp8 --no-cpu-baseline 2> $O/${tag}
 python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-bf16-wgrad --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_bf16_wgrad.json
 python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-forward-only --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_forward_only.json
 python bench.py --steps 20 --warmup 5 $LC --no-cpu-baseline 2> $O/${tag}_bench_n1_longctx.err | grep '^{' > $O/${tag}_bench_n1_longctx.json
+python bench.py --steps 20 --warmup 5 $LC --dtype fp8 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_longctx_fp8.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --exchange-pack-all 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_pack_all.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --dtype fp8 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp8.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange 2> $O/${tag}_bench_n1_forced_exchange.err | grep '^{' > $O/${tag}_bench_n1_forced_exchange.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --grad-dtype fp32 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp32.json
-for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_longctx bench_n1_forced_exchange bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
+for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
 head -45 $O/${tag}_pmc_sites.txt
