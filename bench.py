@@ -101,6 +101,7 @@ def parse():
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
     ap.add_argument("--exchange-pack-all", action="store_true", help="developer A/B: the exchange packs every gradient from fp32 (the weight-gradient "
                     "GEMMs do not write the bf16 communication buffer themselves)")
+    ap.add_argument("--adamw-wide-first", type=int, default=-1, help="developer A/B: how many of the first overlapped AdamW launches run unthrottled")
     ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
     ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
@@ -316,6 +317,8 @@ def main():
         opt.overlap_workgroups = a.adamw_wgs
     if a.adamw_groups >= 0:
         opt.launch_groups = a.adamw_groups
+    if a.adamw_wide_first >= 0:
+        opt.full_width_first = a.adamw_wide_first
     if a.opt_early and opt.overlap:
         opt.set_early(True)                          # ... or start per segment as soon as backward has finished it
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])

@@ -87,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
         self.overlap = False
         self.overlap_workgroups = 256        # throttle of the overlapped launches (one workgroup per CU), 0 = full width
+        self.full_width_first = 1            # this many of the first overlapped launches (embeddings first) run unthrottled
         self.launch_groups = 0               # > 0: the overlapped update in that many launches instead of one per backward segment
         self.fp8_transpose_workgroups = 256  # same for the transposed fp8 weight shadow that follows the update (fp8 backward)
         # the update zeroes every gradient element it has consumed; the zero_grad() that follows is then free.  Off by
@@ -351,13 +352,18 @@ class FusedAdamW(torch.optim.Optimizer):
                 core._param_events = list(self._group_events)
                 core._opt_stream = self._opt_stream
                 order = ()
+            launched = 0
             for sgi in order:
                 b0, b1 = self._seg_blocks[sgi]
                 if done is not None:
                     for w in done[sgi]:
                         w(self._opt_stream)
                 if b1 > b0:
-                    self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, self.overlap_workgroups)
+                    # the first launches in first-use order (embeddings, first layers) run while the next forward is still waiting
+                    # for them: nothing to share the chip with yet, so no throttle (full_width_first = how many)
+                    wide = done is None and launched < int(self.full_width_first)
+                    self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, 0 if wide else self.overlap_workgroups)
+                    launched += 1
                 self._events[sgi].record(self._opt_stream)
             if done is not None:
                 order_streams(cur, self._opt_stream)          # the gradient memset that follows must not pass backward's tail
