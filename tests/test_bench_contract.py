@@ -92,9 +92,10 @@ def test_two_rank_bench_runs_end_to_end():
         port = sock.getsockname()[1]
     common = ["--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--profile-steps", "0", "--no-h2d-leg", "--no-dropout"]
     losses = {}
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16", "bf16+fp8"):            # the last one: BASELINE configs[4] under the exchange (bf16 payload)
+        extra = ["--dtype", "fp8"] if dtype.endswith("fp8") else []
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grad-dtype", dtype] + common
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grad-dtype", dtype.split("+")[0]] + extra + common
         res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         rows = [r for r in res.stdout.strip().split("\n") if r.startswith("{")]
@@ -103,7 +104,10 @@ def test_two_rank_bench_runs_end_to_end():
         assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
         assert line["config"]["global_batch"] == 2 * 16 and line["value"] > 0
         pay = line["config"]["gradient_allreduce"]["step_payload"]
-        assert pay["dtype"] == dtype and pay["collectives_issued_inside_the_backward_call"] == pay["buckets"] >= 8
+        assert pay["dtype"] == dtype.split("+")[0] and pay["collectives_issued_inside_the_backward_call"] == pay["buckets"] >= 8
+        if dtype.startswith("bf16"):      # the weight-gradient GEMMs wrote the communication buffer themselves (lazy clears from step 2 on)
+            assert pay["weight_gradients_written_as_bf16_by_the_gemms"] is True
+        assert line["dtype"] == ("fp8" if dtype.endswith("fp8") else "bf16")
         losses[dtype] = line["config"]["global_loss"]
     # the same four optimizer steps by ONE rank on the concatenation of the two ranks' batches: the data-parallel run must land on
     # the same mean loss (1/world folded into the gradient seeds, SUM all-reduce, every rank applying the same update)
@@ -116,3 +120,4 @@ def test_two_rank_bench_runs_end_to_end():
     ref = one["config"]["global_loss"]
     assert abs(losses["fp32"] - ref) <= 2e-3 * abs(ref), (losses, ref)       # different batch split -> other summation orders / bf16 roundings
     assert abs(losses["bf16"] - ref) <= 5e-3 * abs(ref), (losses, ref)
+    assert abs(losses["bf16+fp8"] - ref) <= 3e-2 * abs(ref), (losses, ref)   # e4m3 / e5m2 GEMMs: the loss moves by a per cent or so
