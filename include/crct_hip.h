@@ -513,8 +513,9 @@ typedef struct CrctStepCfg {
                                 on the four internal streams (text, text weight-gradient, visual, visual weight-gradient); once
                                 all four have fired, the gradient range of segments 0 .. s is final -- a data-parallel caller
                                 starts that range's all-reduce behind them while the rest of backward keeps running */
-  /* fp8 forward (BASELINE configs[4]).  fp8 != 0 with all four pointers set: the QKV and FFN Linears whose input width is a
-   * multiple of 128 run as e4m3 GEMMs (fp32 accumulate); everything else, and the whole backward pass, stays bf16.
+  /* fp8 forward (BASELINE configs[4]).  fp8 != 0 with all four pointers set: every Linear of the encoder whose two dimensions are
+   * multiples of 128 (QKV, attention output / biOutput, FFN) runs its forward GEMM on e4m3 operands (fp32 accumulate) -- the inputs
+   * are e4m3 copies written by the producing LayerNorm / GELU epilogue / attention kernel; embeddings, poolers and heads stay bf16.
    *   params_fp8      flat e4m3 weight shadow, element offsets of params_f32 (kept current by crct_adamw_step / CrctFp8Shadow)
    *   fp8_w_scale     device fp32 [crct_engine_fp8_weights()]: scale of weight slot i (q = w * scale)
    *   fp8_act_scale   device fp32 [crct_engine_fp8_sites()]: scales the producers quantise the activations with
@@ -522,14 +523,16 @@ typedef struct CrctStepCfg {
   int32_t fp8;               /* 0 off, 1 on, 2 calibration: copies and maxima are written, the GEMMs read the bf16 operands (a dry forward pass
                                 before the first fp8 one: its maxima are those of the bf16 forward) */
   const void* params_fp8; const float* fp8_w_scale; const float* fp8_act_scale; float* fp8_act_amax;
-  /* fp8 backward (configs[4], backward only; needs fp8 != 0).  fp8_bwd = 1: the data-gradient GEMMs of the FFN and attention-output
-   * Linears (dx = dy W) read an OCP e5m2 copy of dy -- written by the producing LayerNorm-backward kernel / GELU' epilogue with the
-   * per-site scales fp8_grad_scale[crct_engine_fp8_grad_sites()], maxima into fp8_grad_amax -- and the TRANSPOSED e4m3 weight
-   * shadow params_fp8_t (crct_fp8_transpose_weights of params_fp8; weight scales = fp8_w_scale).  fp8_bwd = 2: calibration -- the
-   * maxima are collected, the GEMMs run in bf16 (the first backward pass).  The QKV data gradient stays bf16.
-   * fp8_wgrad != 0 (with fp8_bwd = 1): the WEIGHT gradients of the FFN Linears dW = dy^T x also read fp8 operands -- the same e5m2
-   * copy of dy and the e4m3 copy of x the forward GEMM read, both token-major, through the transposing LDS load (gemm.hip); their
-   * bias gradients and every other weight gradient stay bf16. */
+  /* fp8 backward (configs[4], backward only; needs fp8 != 0).  fp8_bwd = 1: the data-gradient GEMMs of the same Linears (dx = dy W)
+   * read an OCP e5m2 copy of dy -- written by the producing LayerNorm-backward kernel / GELU' epilogue / attention-backward kernel
+   * with the per-site scales fp8_grad_scale[crct_engine_fp8_grad_sites()], maxima into fp8_grad_amax -- and the TRANSPOSED e4m3
+   * weight shadow params_fp8_t (crct_fp8_transpose_weights of params_fp8, kept current by crct_adamw_step / CrctFp8Shadow.qt;
+   * weight scales = fp8_w_scale).  fp8_bwd = 2: calibration -- the maxima are collected, the GEMMs run in bf16 (the first
+   * backward pass).
+   * fp8_wgrad != 0 (with fp8_bwd = 1): their WEIGHT gradients dW = dy^T x also read fp8 operands -- the same e5m2 copy of dy and
+   * the e4m3 copy of x the forward GEMM read, both token-major, through the transposing LDS load (gemm.hip); the bias gradients
+   * are column sums of the bf16 dy.  Shapes the MFMA attention kernels do not cover (crct_attention_quant_ok) keep the
+   * attention-output forward and the QKV gradients of that layer in bf16. */
   int32_t fp8_bwd; int32_t fp8_wgrad;
   const void* params_fp8_t; const float* fp8_grad_scale; float* fp8_grad_amax;
   /* Host callback of crct_engine_backward(seg < 0): invoked on the calling thread, INSIDE the call, right after the four
