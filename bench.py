@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--exchange-skip", default="", help="timing experiment: comma list of exchange parts to leave out (pack, collective, stats)")
     ap.add_argument("--prefetch-wgs", type=int, default=-1, help="workgroups of the engine's weight prefetch (0 = off; default: the engine's)")
     ap.add_argument("--vis-stream", type=int, default=1, help="0: the visual stream's layers on the caller's stream (developer timing experiment)")
+    ap.add_argument("--embed-scatter-split", action="store_true", help="developer A/B: the text embedding's backward sums and scatter as two launches")
     ap.add_argument("--wgrad-concat", type=int, default=-1, help="developer A/B: 0 = per-problem XCD rectangles for the grouped weight gradients (crct_gemm_group_concat)")
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
@@ -304,6 +305,8 @@ def main():
         L.load().crct_gemm_group_max_workgroups(a.wgrad_wgs)
     if a.wgrad_concat >= 0:
         L.load().crct_gemm_group_concat(a.wgrad_concat)
+    if a.embed_scatter_split:
+        L.load().crct_embed_scatter_split(1)
     wg_mode = a.wgrad_streams if a.wgrad_streams >= 0 else (2 if (world > 1 or a.force_exchange) else 1)
     core.stream_mode = (a.vis_stream, wg_mode)
     if a.prefetch_wgs >= 0:

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_group_max_workgroups": (C.c_int, [C.c_int]),
     "crct_gemm_group_concat": (C.c_int, [C.c_int]),
+    "crct_embed_scatter_split": (None, [C.c_int]),
     "crct_gemm_force_generic": (C.c_int, [C.c_int]),
     "crct_prof_enable": (C.c_int, [C.c_int]),
     "crct_prof_reset": (C.c_int, []),

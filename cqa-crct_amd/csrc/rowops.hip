@@ -360,14 +360,13 @@ __device__ __forceinline__ void row_store_f32(const Row<NCH>& r, float* p, int H
 // the listed rows.  M <= GATHER_MAX_ROWS.
 constexpr int GATHER_MAX_ROWS = 15360;     // 4 bytes per row + the 1 KiB of counts stay under the default 64 KiB of dynamic LDS
 // Two tables in one launch: workgroups [0, n0) serve (idx, table), the rest (idx1, table1).
-__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
-                                                         float* __restrict__ table, int n0, const int* __restrict__ idx1,
-                                                         float* __restrict__ table1) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gather_sum_body(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
+                                                float* __restrict__ table, int n0, const int* __restrict__ idx1,
+                                                float* __restrict__ table1, int blk, char* smem) {
   int* list = reinterpret_cast<int*>(smem);              // [M]
   __shared__ int cnt[256];
   const int tid = threadIdx.x;
-  int p = blockIdx.x;
+  int p = blk;
   if (p >= n0) { p -= n0; idx = idx1; table = table1; }
   int n = 0;
   for (int r = tid; r < M; r += 256) n += idx[r] == p;
@@ -411,6 +410,12 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
     *dst = o;
   }
 }
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
+                                                         float* __restrict__ table, int n0, const int* __restrict__ idx1,
+                                                         float* __restrict__ table1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gather_sum_body(rows, idx, M, H, table, n0, idx1, table1, blockIdx.x, smem);
+}
 
 // word_embeddings gradient without float atomics: table[ids[r]][:] += rows[r][:] summed in a FIXED order.  One wave per token
 // row r: if an earlier row carries the same id the wave has nothing to do; otherwise it owns that table row and adds the
@@ -426,16 +431,15 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
 // (four independent rows in flight per wave), and the 4 x 4 partial rows are folded in a fixed tree -- still bit-reproducible.
 constexpr int WORD_HEAVY = 8;
 template <int NCH>
-__global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
-                                                           float* __restrict__ table) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void word_scatter_body(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
+                                                  float* __restrict__ table, const int blk, char* smem) {
   int* sid = reinterpret_cast<int*>(smem);               // [M]
   int* list = sid + M;                                   // [M]   matches of a heavy id
   float* part = reinterpret_cast<float*>(sid + ((2 * M + 3) & ~3));      // [4][H] per-wave partial rows of a heavy id
   __shared__ int s_cnt[ROWS_PER_BLOCK];
   for (int i = threadIdx.x; i < M; i += 256) sid[i] = (int)ids[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.x * ROWS_PER_BLOCK + w;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blk * ROWS_PER_BLOCK + w;
   const int id = r < M ? sid[r] : -1;
   bool earlier = r >= M;
   for (int i = lane; i < r && i < M; i += 64) earlier |= sid[i] == id;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restri
   for (int k = 0; k < ROWS_PER_BLOCK; ++k) {             // workgroup-uniform: s_cnt is shared
     const int n = s_cnt[k];
     if (n <= WORD_HEAVY) continue;
-    const int rk = blockIdx.x * ROWS_PER_BLOCK + k, idk = sid[rk];
+    const int rk = blk * ROWS_PER_BLOCK + k, idk = sid[rk];
     if (w == k) {
       int at = 0;
       for (int base = rk & ~63; base < M; base += 64) {
@@ -517,6 +521,24 @@ __global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restri
     }
     __syncthreads();
   }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
+                                                           float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  word_scatter_body<NCH>(rows, ids, M, H, table, blockIdx.x, smem);
+}
+// the position / type sums and the word-table scatter of the text embedding's backward in ONE launch (independent outputs, both
+// read the per-token gradient rows): the few long gather workgroups first, the word workgroups fill in beside them
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
+                                                            float* __restrict__ d_pos, int n0, const int* __restrict__ idx1,
+                                                            float* __restrict__ d_type, int n_gather, const int64_t* __restrict__ ids,
+                                                            float* __restrict__ d_word) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < n_gather) gather_sum_body(rows, idx, M, H, d_pos, n0, idx1, d_type, blockIdx.x, smem);
+  else word_scatter_body<NCH>(rows, ids, M, H, d_word, (int)blockIdx.x - n_gather, smem);
 }
 
 // ------------------------------------------------------------------------------ LayerNorm fwd
@@ -1452,6 +1474,9 @@ int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* lo
 
 }  // extern "C"
 
+static int g_embed_scatter_split = 0;
+extern "C" void crct_embed_scatter_split(int on) { g_embed_scatter_split = on ? 1 : 0; }
+
 extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
                                         const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
                                         float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
@@ -1472,20 +1497,34 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
     const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(used_pos + n_types), dim3(256), (size_t)M * sizeof(int), s,
-                       rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
-    CRCT_CHECK_HIP(hipGetLastError());
-    const size_t word_lds = (size_t)((2 * M + 3) & ~3L) * sizeof(int) + (size_t)ROWS_PER_BLOCK * H * sizeof(float);
+    const size_t word_lds = (size_t)((2 * M + 3) & ~3L) * sizeof(int) + (size_t)ROWS_PER_BLOCK * H * sizeof(float);     // >= the gather's M ints
     CRCT_REQUIRE(word_lds <= 152 * 1024, "embed_text_bwd: B*T=%ld rows need %zu bytes of LDS for the word-gradient scan", M, word_lds);
+    const int n_gather = used_pos + n_types;
+    if (g_embed_scatter_split) {      // test hook: the two launches the merged kernel replaces (same bits)
+      hipLaunchKernelGGL(gather_sum_kernel, dim3(n_gather), dim3(256), (size_t)M * sizeof(int), s,
+                         rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
+      CRCT_CHECK_HIP(hipGetLastError());
+      DISPATCH_NCH(H, {
+        static bool big_lds_w = false;
+        if (word_lds > 64 * 1024 && !big_lds_w) {
+          CRCT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&word_scatter_kernel<NCH>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+          big_lds_w = true;
+        }
+        hipLaunchKernelGGL((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
+                           (const float*)rows_scratch, ids, (int)M, H, d_word);
+      });
+      CRCT_CHECK_HIP(hipGetLastError());
+    } else
     DISPATCH_NCH(H, {
       static bool big_lds = false;                         // ids + match list of every row: above 64 KiB from ~6 600 rows on
       if (word_lds > 64 * 1024 && !big_lds) {
-        CRCT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&word_scatter_kernel<NCH>),
+        CRCT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_scatter_kernel<NCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         big_lds = true;
       }
-      hipLaunchKernelGGL((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
-                         (const float*)rows_scratch, ids, (int)M, H, d_word);
+      hipLaunchKernelGGL((embed_scatter_kernel<NCH>), dim3(n_gather + (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
+                         (const float*)rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type, n_gather, ids, d_word);
     });
     CRCT_CHECK_HIP(hipGetLastError());
   }

@@ -108,6 +108,9 @@ int crct_gemm_group_max_workgroups(int n);
  * fetches ~1/8 of the group's operand panels.  Results are identical; measured neutral to slightly slower in the step
  * (EXPERIMENTS.md round 3), kept as the developer A/B switch behind that statement (bench.py --wgrad-concat). */
 int crct_gemm_group_concat(int on);
+/* Test hook: on != 0 makes crct_embed_text_bwd launch the position / type sums and the word-table scatter as two kernels one after
+ * the other instead of one merged launch (identical results; tests/test_kernels_gpu.py, bench.py --embed-scatter-split). */
+void crct_embed_scatter_split(int on);
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 

@@ -637,6 +637,13 @@ def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T,
     w1, p1, t1 = run(True)
     w2, p2, t2 = run(True)
     assert torch.equal(w1, w2) and torch.equal(p1, p2) and torch.equal(t1, t2)
+    # the position / type sums and the word scatter leave as ONE launch; as two launches (test hook) they give the same bits
+    lib.crct_embed_scatter_split(1)
+    try:
+        w3, p3, t3 = run(True)
+    finally:
+        lib.crct_embed_scatter_split(0)
+    assert torch.equal(w1, w3) and torch.equal(p1, p3) and torch.equal(t1, t3)
     assert float(w1[0].abs().max()) > 0 and float(w1[V - 1].abs().max()) >= 0
     for a, b in ((w1, w_atomic), (p1, p_atomic), (t1, t_atomic)):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
