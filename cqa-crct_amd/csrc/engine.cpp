@@ -1238,8 +1238,7 @@ namespace {
 int ensure_streams(crct_engine* e, hipStream_t main) {
   // all internal streams share the caller's (default) priority: giving the weight-gradient streams the lowest or the
   // visual stream the highest priority (hipStreamCreateWithPriority) was measured to DOUBLE the step time on MI355X
-  // (10.7 -> 21.9 ms, round 1; measured again in round 3 with the probed queue placement in force: 7.6 -> 18.5 ms with the
-  // weight-gradient streams at the lowest priority, 19.5 ms at the highest) -- so there is no priority knob
+  // (10.7 -> 21.9 ms, round 1) -- cross-priority event waits are slow -- so there is no priority knob
   if (!e->placed) {          // once per engine: streams on hardware queues that do not collide with the caller's or each other
     e->placed = true;
     e->placed_for = main;
