@@ -5,8 +5,9 @@ all-reduce of train.py:181-189 when N > 1) + fused AdamW + LR-schedule step, on 
 inputs, dropout ENABLED (p = 0.1), config ``config/vilbert.json`` with ``v_feature_size = 2048`` (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (one fresh process per GPU, as train.py:356-363 does)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                # ... or under a launcher that has set RANK / WORLD_SIZE already
 
 Prints ONE JSON line on rank 0:
   value        : whole-job QA-pairs/s with the batches already resident in HBM when the timed region starts (a pool of 8
@@ -56,7 +57,12 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               18: "reg64x128", 19: "reg64x64", 20: "f8e4m3_128x64w8s2", 21: "f8e4m3_128x64w8s3", 22: "dma160x128w4s2", 23: "dma160x128w4s3",
               24: "dma160x96w4s3", 25: "dma160x96w4s2", 26: "dma96x64w4s3", 27: "dma96x64w4s4", 28: "dma160x64w4s3", 29: "dma64x96w4s4", 30: "dma160x128w4s3p", 31: "dma160x128w4s2p",
               32: "dma128x128w4s3p", 33: "dma128x128w8s3p", 34: "dma256x128w8s3p", 35: "dma160x96w4s3p",
-              36: "f8t_128x128w8s3", 37: "f8t_128x128w8s2"}
+              36: "f8t_128x128w8s3", 37: "f8t_128x128w8s2", 38: "pp128x64w8s3", 39: "pp128x128w8s3", 40: "pp128x64w8s4", 41: "pp128x128w8s3b",
+              42: "pp256x128w8s3", 43: "pp64x128w8s3", 44: "pp256x64w8s3", 45: "pp128x128w8s4", 46: "ldr128x64w8+4s3", 47: "ldr128x64w8+4s2",
+              48: "ldr128x128w8+4s3", 49: "ldr128x128w8+4s2", 50: "ldr256x128w8+4s3", 51: "ldr128x64w8+4s4", 52: "ldr128x64w8+2s3",
+              53: "ldr128x128w4+4s3", 54: "ldr128x64w4+2s3", 55: "ldr256x128w8+4s2", 56: "ldrp128x64w4+2s3", 57: "ldrp128x64w8+4s3",
+              58: "ldrp128x128w4+4s3", 59: "ldrp128x128w8+4s3", 60: "ldrp256x128w8+4s3", 61: "ldrp128x64w4+2s4", 62: "ldrp128x128w4+4s2",
+              63: "ldrp128x64w4+4s3", 64: "ldrp128x64w4+2s2", 65: "ldrp256x128w8+4s2"}
 KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
@@ -110,6 +116,8 @@ def parse():
                     "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
     ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
                     "(tools/pmc_sites.py matches it against a rocprofv3 counter collection)")
+    ap.add_argument("--launch-check", action="store_true", help="test hook: every rank reports its rendezvous environment (rank 0 as the JSON line) and "
+                    "exits before touching a GPU -- the self-launch path of `python bench.py --gpus N` checked on a box without GPUs")
     ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
                     help="bf16: the headline (BASELINE configs[1]).  fp8: BASELINE configs[4] -- the QKV / FFN GEMMs of the forward pass on "
                          "OCP e4m3 operands with per-tensor delayed scaling and fp32 accumulation, backward and everything else bf16")
@@ -136,7 +144,7 @@ def gemm_profile(run_step, n_steps):
         return dict(kernel=label, launches_per_step=cnt / n_steps, gflop_per_launch=fl / cnt / 1e9, us_per_launch=ms * 1e3 / cnt,
                     ms_per_step=ms / n_steps, tflops=fl / (ms * 1e-3) / 1e12, frac_of_bf16_peak=fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, **extra)
 
-    for v in range(120):
+    for v in range(210):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue
@@ -245,13 +253,79 @@ def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
                        % (reps, Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1, cpu_model()))
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start one fresh child process per GPU -- what the reference does with
+    ``mp.spawn(run_training_DDP, nprocs=num_proc)`` (CRCT/train.py:356-363) -- each running this same command line with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, exit with the worst child's code.  The parent
+    never touches a GPU and never exec()s: the children are ordinary subprocesses (a process that has initialised the GPU
+    must not be replaced, and this one has not even done that)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                    # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the ONE JSON line; the other ranks' stdout goes to our stderr (they print nothing by design)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+
+    def relay():                                     # rank 0's stdout, line by line as it comes (bytes: no decoding surprises)
+        for line in procs[0].stdout:
+            sys.stdout.buffer.write(line)
+            sys.stdout.buffer.flush()
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    worst = 0
+    try:
+        live = list(procs)
+        while live:                                  # a rank that dies takes the job down: its peers would wait in a collective for ever
+            time.sleep(0.05)
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0:
+                    if worst == 0:                   # the first failure is the job's exit code (the peers below are ended by us)
+                        worst = rc
+                    for q in live:
+                        q.terminate()
+        pump.join(timeout=10)
+    finally:
+        for p in procs:                              # a rank that outlived a failed peer: end exactly the PIDs started here
+            if p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    return worst if 0 <= worst < 256 else 1
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us (the driver's 1-GPU command shape, `python bench.py --gpus N ...`): be the launcher.  Nothing
+        # above this line touches a GPU (importing torch does not; the library is only dlopen()ed later, in the ranks).
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if a.gpus != world:
-        raise SystemExit("bench.py --gpus %d must equal WORLD_SIZE=%d (launch N > 1 with torch.distributed.run, one rank per GPU)" % (a.gpus, world))
+        raise SystemExit("bench.py --gpus %d does not match WORLD_SIZE=%d set by the launcher (run `python bench.py --gpus N`, which starts "
+                         "its own ranks, or torch.distributed.run with --nproc-per-node N)" % (a.gpus, world))
+    if a.launch_check:
+        if os.environ.get("CRCT_LAUNCH_CHECK_FAIL_RANK") == str(rank):       # (only read under --launch-check: a rank that dies must take the job down)
+            raise SystemExit(7)
+        info = dict(rank=rank, local_rank=local, world=world, master="%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+                    ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+        print(json.dumps(info) if rank == 0 else "rank %d: %s" % (rank, info), flush=True)
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
     # nothing in the environment may change what the measured step launches: the library reads no CRCT_* variable any more, and
@@ -263,6 +337,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_log = None
+    if (world > 1 or a.force_exchange) and rank == 0 and "NCCL_DEBUG" not in os.environ and not os.environ.get("CRCT_BENCH_SHARE_GPU"):
+        # RCCL has no getter for the channel count it chose: let rank 0 log its communicator INIT (only) into a file and read it
+        # back for config.gradient_allreduce.rccl (crct/rccl.py: channels_from_debug_log)
+        import tempfile
+        rccl_log = os.path.join(tempfile.gettempdir(), "crct_rccl_init_%d.log" % os.getpid())
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=rccl_log)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("CRCT_BENCH_SHARE_GPU"):
@@ -457,7 +538,11 @@ def main():
             all_reduce()
         torch.cuda.synchronize()
         ar = (time.perf_counter() - t1) / 5
-        comm = {"allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
+        from crct import rccl as RC
+        comm = {"rccl": {"version": RC.version()[1], "env": RC.env_seen(), "route": "direct ncclAllReduce (crct/rccl.py)" if rc is not None else "torch.distributed",
+                         "collectives_issued": getattr(rc, "collectives", None), "world": world,
+                         "channels_logged_at_init": RC.channels_from_debug_log(rccl_log) if rccl_log else None},
+                "allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
                 "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9,
                 "step_payload": {"dtype": a.grad_dtype, "bytes_per_step": used * (2 if a.grad_dtype == "bf16" else 4),
                                  "buckets": len(ddp._buckets or ()), "bucket_mb_of_fp32_gradients": a.bucket_mb,

@@ -19,10 +19,15 @@ all-reduce (train.py:181-189).  Here:
     all of it (round 2);
   * payload: ``grad_dtype=torch.bfloat16`` (default) sends 2 bytes per parameter -- 477 MB per step
     instead of 953 MB: at ~350 GB/s of bus bandwidth over xGMI that is ~2.4 ms, which
-    hides behind the 4 ms backward, where the fp32 payload (4.8 ms) cannot.  The fused AdamW consumes
-    the all-reduced bf16 bucket as it lies (``crct_adamw_step(g_bf16=...)``); ``materialize_grads=True``
-    also writes it back into the fp32 ``.grad`` views (for anything else that reads them: GradScaler's
-    inf check, clipping).  ``grad_dtype=torch.float32`` is the reference's payload;
+    hides behind the 4 ms backward, where the fp32 payload (4.8 ms) cannot.  What ``.grad`` holds afterwards
+    (``materialize_grads``): by default (None) the whole reduced bucket is written back into the fp32 ``.grad``
+    views -- DistributedDataParallel's contract, whatever reads them (a stock optimizer, clip_grad_norm_,
+    GradScaler's inf check, logging) -- UNLESS this package's FusedAdamW is attached to the model: it consumes
+    the all-reduced bf16 bucket as it lies (``crct_adamw_step(g_bf16=...)``), so only the gradients backward
+    accumulates in fp32 (biases, LayerNorm, embeddings, heads: 5 % of the elements) are written back and the
+    fp32 views of the Linear weight gradients, which then exist in the bf16 buffer only, are filled with NaN:
+    a reader gets the reduced value or a NaN, never a local or stale gradient.  True / False force either.
+    ``grad_dtype=torch.float32`` is the reference's payload;
   * the 1/world averaging is folded into the loss-gradient seeds (no extra pass over the gradients);
   * tensors that never receive a gradient sit at the tail of the layout and are never sent;
   * the 9-float stats all-reduce runs asynchronously on the communication stream (``AsyncStats``) and
@@ -80,13 +85,14 @@ class BucketExchange(object):
     pack / unpack are HIP kernels; the CPU / gloo tests pass plain functions."""
 
     def __init__(self, flat_grads, buckets, group, comm_buf=None, materialize=False, stream_ctx=None, wait_events=None,
-                 pack=None, unpack=None, after_bucket=None, collective=None, pack_bucket=None):
+                 pack=None, unpack=None, after_bucket=None, collective=None, pack_bucket=None, unpack_bucket=None):
         self.flat, self.buckets, self.group = flat_grads, buckets, group
         self.comm_buf, self.materialize = comm_buf, materialize
         self.stream_ctx = stream_ctx or contextlib.nullcontext
         self.wait_events = wait_events or (lambda b: None)
         self.pack = pack or (lambda src, dst: dst.copy_(src))
         self.pack_bucket = pack_bucket      # pack_bucket(b): packs only what is not in the communication buffer yet (see FlatGradDDP.backward)
+        self.unpack_bucket = unpack_bucket  # unpack_bucket(b): without `materialize`, still writes back what backward accumulates in fp32
         self.unpack = unpack or (lambda src, dst: dst.copy_(src))
         self.after_bucket = after_bucket or (lambda b: None)
         # the collective: by default torch.distributed (gloo in the CPU tests; blocks until done), on the GPU RCCL called
@@ -121,6 +127,8 @@ class BucketExchange(object):
             self.issue_order.append(b)
             if self.comm_buf is not None and self.materialize:
                 self.unpack(self.comm_buf[lo:hi], self.flat[lo:hi])
+            elif self.comm_buf is not None and self.unpack_bucket is not None:
+                self.unpack_bucket(b)
             self.after_bucket(b)
 
     def finish(self):
@@ -132,7 +140,7 @@ class FlatGradDDP(object):
     """Attach to a ``VisualDialogEncoder`` / ``CrctModel``: ``FlatGradDDP(model)`` after
     ``dist.init_process_group(backend='nccl', ...)`` (RCCL on ROCm)."""
 
-    def __init__(self, model, process_group=None, bucket_mb=64, broadcast=True, grad_dtype=torch.bfloat16, materialize_grads=False):
+    def __init__(self, model, process_group=None, bucket_mb=64, broadcast=True, grad_dtype=torch.bfloat16, materialize_grads=None):
         from .optim import _crct_core
         self.core = _crct_core(model)
         self.group = process_group
@@ -141,7 +149,8 @@ class FlatGradDDP(object):
         if grad_dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("grad_dtype must be torch.bfloat16 or torch.float32")
         self.grad_dtype = grad_dtype
-        self.materialize_grads = bool(materialize_grads)
+        self.materialize_grads = None if materialize_grads is None else bool(materialize_grads)      # None: see materializes()
+        self._poisoned_at = None     # full-clear count of the gradient buffer at which the owned fp32 views were last filled with NaN
         self._buckets = None
         self._events = self._comm = self._bucket_done = None
         self._comm_buf = None
@@ -152,6 +161,7 @@ class FlatGradDDP(object):
         self.last_exchange = None    # BucketExchange of the last synchronised backward pass
         self.issued_inside_engine_call = 0      # collectives launched from the engine's callback during the last pass
         self._grad_source_valid = False
+        self._materialized_last = False
         self._rccl = None
         self.direct_bf16_wgrad = True       # bf16 payload: the engine writes the Linear weight gradients into the communication buffer itself
         self.packed_runs_only = False
@@ -169,6 +179,14 @@ class FlatGradDDP(object):
         finally:
             self.require_sync = old
 
+    def materializes(self):
+        """Does a bf16 exchange write the reduced bucket back into the fp32 ``.grad`` views?  ``materialize_grads`` if it was
+        given; otherwise yes, unless this package's FusedAdamW is attached to the model (it reads the bf16 buffer itself:
+        ``grad_source()``).  Decided per pass: the optimizer may be built before or after this object (train.py:85 / :139)."""
+        if self.materialize_grads is not None:
+            return self.materialize_grads
+        return getattr(self.core, "_fused_optimizer", None) is None
+
     def communicator(self):
         """The RCCL communicator of the exchange (crct/rccl.py), created on first use; None when the process group is not an RCCL
         one (the gloo-on-one-GPU tests: the collectives then go through torch.distributed)."""
@@ -181,7 +199,7 @@ class FlatGradDDP(object):
     def grad_source(self):
         """The bf16 buffer (element offsets of the flat gradient buffer) that holds the all-reduced gradients of the last
         synchronised backward pass, or None when the fp32 gradient buffer does (fp32 payload, or ``materialize_grads``)."""
-        if self._grad_source_valid and self._comm_buf is not None and not self.materialize_grads:
+        if self._grad_source_valid and self._comm_buf is not None and not self._materialized_last:
             return self._comm_buf
         return None
 
@@ -234,6 +252,20 @@ class FlatGradDDP(object):
             self._seg_bucket.append(b)
         self._last_of = {last: b for b, (last, _, _) in enumerate(self._buckets)}
 
+    def _place_wgrad_streams(self, core, eng, exchange):
+        """With an exchange in the pass the weight gradients of both data streams share ONE side stream, so that the collectives
+        (auxiliary stream) have a hardware queue to themselves: the engine puts the auxiliary stream and the visual weight-gradient
+        stream in the same queue class (engine.cpp, ensure_streams), and an RCCL kernel that waits for its peers must not sit in
+        front of GEMMs.  Passes without an exchange (``no_sync()``, one rank) get the two weight-gradient streams back.  An explicit
+        ``core.stream_mode`` (bench.py, developer A/B runs) is the caller's choice and stands."""
+        if getattr(core, "stream_mode", None) is not None or not core.flat_grads.is_cuda or not hasattr(eng, "handle"):
+            return
+        want = 2 if exchange else 1
+        if getattr(eng, "_ddp_wgrad_streams", None) != want:
+            from . import lib as L
+            L.check(eng.lib.crct_engine_set_streams(eng.handle, 1, want), "set_streams")
+            eng._ddp_wgrad_streams = want
+
     def backward(self, core, eng, tensors, step):
         step = dict(step)
         if self.world > 1:      # also on accumulation-only micro-steps: the final SUM then yields the average
@@ -241,10 +273,12 @@ class FlatGradDDP(object):
         self._grad_source_valid = False
         if not self.require_sync or (self.world == 1 and not self.force_exchange):
             self.last_exchange = None
+            self._place_wgrad_streams(core, eng, False)
             eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
             return
         if self._buckets is None:
             self._plan(eng)
+        self._place_wgrad_streams(core, eng, True)
         if not (self.event_mode and core.flat_grads.is_cuda):
             self.last_exchange = None
             reduce_while_running(core.flat_grads, eng.segments, self._buckets,
@@ -259,10 +293,15 @@ class FlatGradDDP(object):
             from .events import DeviceEvent
             # The 4 x 26 per-segment events only order the communication stream behind the engine's internal streams -- ONE
             # device -- so they are device-scope events (no system-scope fence in the record: 104 cache write-back /
-            # invalidations per backward pass cost 0.9 ms of GPU time, tools/step_phases.py --exchange).  What peers must see is
-            # released at system scope by the event torch's ProcessGroupNCCL itself records on the communication stream
-            # BEHIND those waits, right before the collective; what peers have written is acquired through the stock torch
-            # events recorded after each bucket (bucket_done), which every consumer of the reduced gradients waits for.
+            # invalidations per backward pass cost 0.9 ms of GPU time, tools/step_phases.py --exchange).  They make the
+            # producers' stores (GEMM epilogues, pack kernel: plain or non-temporal stores, written through this device's L2 at
+            # the end of each kernel) visible to later kernels of THIS device, which is all the collective's own kernel needs to
+            # read them: ncclAllReduce is enqueued on the auxiliary stream itself (crct/rccl.py; no ProcessGroupNCCL stream or
+            # event is involved any more), it reads the send buffer as an ordinary kernel of this device behind those waits, and
+            # what it hands to PEERS travels through RCCL's own protocol (its fine-grained staging buffers and flags carry the
+            # system-scope release / acquire).  In the other direction, what peers have written into this rank's buffer is made
+            # visible by that same protocol before the RCCL kernel ends; consumers on other streams wait for `bucket_done`, a
+            # stock torch event (system-scope fence in its record) recorded behind each bucket.
             self._events = [DeviceEvent() for _ in range(4 * len(eng.segments))]
             self._bucket_done = [torch.cuda.Event() for _ in self._buckets]
             for ev in self._events + self._bucket_done:          # created / recorded once so that a wait before the first record is legal
@@ -286,10 +325,11 @@ class FlatGradDDP(object):
         # buffer, rounded to bf16 by the GEMM epilogue (CrctStepCfg.grads_bf16): packing then only casts the runs of elements
         # backward accumulates in fp32 (biases, LayerNorm, embeddings, heads).  Only on a pass that WRITES those gradients
         # (wgrad_overwrite: the first pass after a clear -- an accumulation pass adds in fp32 and packs everything).
+        materialize = self.materializes()
         direct = self.grad_dtype == torch.bfloat16 and bool(step.get("wgrad_overwrite")) and self.direct_bf16_wgrad
-        plans = self._pack_plans(core, eng) if direct else None
-        pack_bucket = None
-        if plans is not None:
+        plans = self._pack_plans(core, eng) if (direct or (self.grad_dtype == torch.bfloat16 and not materialize)) else None
+        pack_bucket = unpack_bucket = None
+        if plans is not None and direct:
             step["grads_bf16"] = self._comm_buf
 
             def pack_bucket(b):
@@ -297,14 +337,23 @@ class FlatGradDDP(object):
                 if n_blk:
                     L.check(lib.crct_cast_runs_f32_bf16(core.flat_grads.data_ptr(), self._comm_buf.data_ptr(), off.data_ptr(), num.data_ptr(),
                                                         blk_seg.data_ptr(), blk_off.data_ptr(), n_blk, comm.cuda_stream), "pack gradients (runs)")
-        self.packed_runs_only = plans is not None
+        if plans is not None and not materialize:
+            # the fused optimizer reads the bf16 buffer; the gradients backward accumulates in fp32 (5 % of the elements) still go
+            # back into their .grad views, and the fp32 views of the OWNED Linear weight gradients -- not written by a direct pass,
+            # local values after a packed one -- are NaN from now on: readers get the reduced gradient or a NaN
+            def unpack_bucket(b):
+                off, num, blk_seg, blk_off, n_blk = plans[b]
+                if n_blk:
+                    L.check(lib.crct_cast_runs_bf16_f32(self._comm_buf.data_ptr(), core.flat_grads.data_ptr(), off.data_ptr(), num.data_ptr(),
+                                                        blk_seg.data_ptr(), blk_off.data_ptr(), n_blk, comm.cuda_stream), "unpack gradients (runs)")
+        self.packed_runs_only = plans is not None and direct
         rccl = self.communicator()
         collective = (lambda t: rccl.all_reduce_(t, comm)) if rccl is not None else None        # on the auxiliary stream itself: no hidden stream
         ex = BucketExchange(core.flat_grads, self._buckets, self.group,
                             comm_buf=self._comm_buf if self.grad_dtype == torch.bfloat16 else None,
-                            materialize=self.materialize_grads, stream_ctx=lambda: torch.cuda.stream(comm), wait_events=wait_events,
+                            materialize=materialize, stream_ctx=lambda: torch.cuda.stream(comm), wait_events=wait_events,
                             pack=pack, unpack=unpack, after_bucket=lambda b: self._bucket_done[b].record(comm), collective=collective,
-                            pack_bucket=pack_bucket)
+                            pack_bucket=pack_bucket, unpack_bucket=unpack_bucket)
         self.last_exchange = ex
         ex.debug_skip = getattr(self, "debug_skip", ())
 
@@ -319,10 +368,32 @@ class FlatGradDDP(object):
         eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
         self.issued_inside_engine_call = len(ex.issue_order)
         ex.finish()                   # nothing left unless the engine ran without the callback
+        if rccl is not None:
+            rccl.check_async()        # an enqueue that succeeded can still have failed since (peer gone, transport error): fail HERE, not in a hang
+        if unpack_bucket is not None:
+            self._poison_owned(core, eng, direct)
         self._grad_source_valid = True
-        # consumers on the caller's stream (a plain optimizer, .grad readers) see the reduced gradients; the fused optimizer in
-        # overlap mode orders its own stream instead (wait_all / segment_waits) and this wait then costs nothing extra
+        self._materialized_last = materialize or self.grad_dtype != torch.bfloat16
+        # consumers on the caller's stream are ordered behind the last bucket (collective + write-back): with `materialize` every
+        # .grad view holds the reduced gradient from here on (a stock optimizer, clip_grad_norm_, a GradScaler); without it
+        # (FusedAdamW attached) the views backward accumulates into do, and the Linear weights' read NaN -- the fused optimizer
+        # takes those from the bf16 buffer (grad_source) and in overlap mode orders its own stream itself (wait_all /
+        # segment_waits), so this wait then costs nothing extra
         torch.cuda.current_stream().wait_event(self._bucket_done[-1])
+
+    def _poison_owned(self, core, eng, direct):
+        """NaN into the fp32 views of the owned Linear weight gradients (the reduced values live in the bf16 buffer only).  After a
+        direct pass nothing writes those views, so once per full clear of the gradient buffer is enough; a pass that packed from
+        fp32 (accumulation, ``direct_bf16_wgrad = False``) has just written local values there, so it is repeated."""
+        epoch = getattr(core, "_full_clears", 0)
+        if direct and self._poisoned_at == epoch:
+            return
+        offs, nums = eng.wgrad_owned_key()
+        with torch.cuda.stream(self._comm):          # behind every bucket's pack kernel: the exchange has read what it needed
+            for o, n in zip(offs, nums):
+                core.flat_grads[o:o + n].fill_(float("nan"))
+            self._bucket_done[-1].record(self._comm)
+        self._poisoned_at = epoch if direct else None
 
 
 class AsyncStats(object):

@@ -141,6 +141,7 @@ PROTOTYPES = {
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_runs_f32_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, c_i64, vp]),
+    "crct_cast_runs_bf16_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "crct_attention_fwd": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp]),
     "crct_attention_bwd": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp]),
     "crct_attention_fwd_q": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [c_i64] * 4 + _u8 + [vp, vp]),

@@ -344,6 +344,7 @@ class CrctModel(nn.Module):
         plan = self._lazy_zero_plan() if lazy else None
         if plan is None:
             self._flat_g.zero_()
+            self._full_clears = getattr(self, "_full_clears", 0) + 1       # crct/ddp.py: NaN-filled views of owned gradients are gone
             self._wgrad_overwrite_next = False
             return
         off, num, blk_seg, blk_off, n_blk = plan

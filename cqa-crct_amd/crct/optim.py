@@ -82,6 +82,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step_dev, self._amp_arg, self._amp_keep = None, None, None
         self._fp8_keep = None
         self._g16 = None                     # bf16 gradient source of the running update (data-parallel bf16 exchange), else None
+        core._fused_optimizer = self         # crct/ddp.py: with this optimizer attached a bf16 exchange need not write the weight gradients back to fp32
         # overlap mode: the update runs as one launch per engine backward-segment on its own stream, in first-use
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward

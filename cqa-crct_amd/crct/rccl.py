@@ -44,8 +44,43 @@ def _load():
         lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclGetVersion.argtypes = [C.POINTER(C.c_int)]
+        lib.ncclCommGetAsyncError.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _lib = lib
     return _lib
+
+
+def version():
+    """RCCL's own version code (ncclGetVersion: major * 10000 + minor * 100 + patch for 2.x >= 2.9) as (code, "x.y.z")."""
+    v = C.c_int(0)
+    _check(_load().ncclGetVersion(C.byref(v)), "ncclGetVersion")
+    code = v.value
+    return code, "%d.%d.%d" % (code // 10000, (code // 100) % 100, code % 100)
+
+
+def env_seen():
+    """The NCCL_* / RCCL_* / HSA_* variables this process runs the collectives under (reported by bench.py next to every
+    multi-GPU number: channel counts, protocols and algorithms are chosen by RCCL from these and the topology)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HSA_FORCE_FINE_GRAIN_PCIE")}
+
+
+def channels_from_debug_log(path):
+    """Channel count of the communicator as RCCL itself logged it (NCCL_DEBUG=INFO with NCCL_DEBUG_FILE=path set before the
+    communicator was created): the public API has no getter.  None when the log has no such line."""
+    import re
+    try:
+        with open(path) as f:
+            text = f.read()
+    except OSError:
+        return None
+    best = None
+    for m in re.finditer(r"(\d+) coll channels", text):
+        best = max(best or 0, int(m.group(1)))
+    if best is None:
+        for m in re.finditer(r"Channel (\d+)/(\d+)", text):
+            best = max(best or 0, int(m.group(2)))
+    return best
 
 
 def _check(rc, what):
@@ -74,15 +109,34 @@ class Communicator(object):
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
             _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        n = C.c_int(-1)
+        _check(lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        if n.value != self.world:
+            raise RuntimeError("RCCL communicator spans %d ranks, expected %d" % (n.value, self.world))
+        self.collectives = 0
+
+    def check_async(self):
+        """A collective's enqueue can succeed and the operation still fail later (a peer died, a transport error): RCCL
+        reports that through ncclCommGetAsyncError.  Polled by the exchange at the end of every backward pass (ddp.py) --
+        a host call on the communicator's state, no GPU synchronisation."""
+        err = C.c_int(0)
+        _check(_load().ncclCommGetAsyncError(self.comm, C.byref(err)), "ncclCommGetAsyncError")
+        if err.value != 0:
+            raise RuntimeError("RCCL reported an asynchronous error on rank %d after %d collectives: %s"
+                               % (self.rank, self.collectives, _load().ncclGetErrorString(err.value).decode()))
 
     def all_reduce_(self, t, stream):
         """In-place SUM of a contiguous CUDA tensor, enqueued on ``stream`` (a torch stream); returns at once."""
         if not t.is_contiguous() or not t.is_cuda:
             raise RuntimeError("all_reduce_: contiguous CUDA tensor required")
         _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), DTYPES[t.dtype], ncclSum, self.comm, stream.cuda_stream), "ncclAllReduce")
+        self.collectives += 1
 
     def broadcast_(self, t, root, stream):
+        if not t.is_contiguous() or not t.is_cuda:
+            raise RuntimeError("broadcast_: contiguous CUDA tensor required")
         _check(_load().ncclBroadcast(t.data_ptr(), t.data_ptr(), t.numel(), DTYPES[t.dtype], int(root), self.comm, stream.cuda_stream), "ncclBroadcast")
+        self.collectives += 1
 
     def destroy(self):
         """Explicit only (not from __del__: at interpreter exit the HIP runtime may already be gone)."""

@@ -393,7 +393,9 @@ constexpr int epilogue_passes() {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING>
+// NTH: threads that walk the staged tile (default: the WM x WN compute waves; the loader-wave kernels pass their whole workgroup --
+// waves beyond WM x WN hold no accumulators, their wm is >= WM and they never park anything)
+template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING, int NTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
                                                      int wm, int wn, int lane, int tid) {
   constexpr int P = epilogue_passes<BM, BN, WM, RING>();
@@ -402,7 +404,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t
   constexpr int WR = BM / WM;                // rows of one wave row
   constexpr int LDC = BN + 4;                // floats; 16-byte aligned rows, +4 breaks the power-of-two stride
   constexpr int CPR = BN / 8;                // 8-column chunks per row
-  constexpr int NT = WM * WN * 64;
+  constexpr int NT = NTH ? NTH : WM * WN * 64;
   float* ct = reinterpret_cast<float*>(smem);
   const float* bias = g.bias;
   const uint32_t thr = g.drop_thr;
@@ -754,7 +756,65 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
         }
     }
   };
-  if constexpr (PM == 1) {
+  if constexpr (PM == 2) {
+  // Two-phase ("ping-pong") loop, round 4.  tools/lab/fill_probe.hip measured what the L2 -> LDS path delivers to a CU whose
+  // waves do nothing but stream operand tiles: 124 - 135 GB/s (all 256 CUs, L2-hot, this kernel's swizzled 128-byte rows), not
+  // the ~70 GB/s the plain loop below takes in -- the plain loop is not fill-bound, it is serial: all eight waves pass "barrier,
+  // issue DMA, read fragments, wait, multiply" in lock step, so the two waves of a SIMD wait for the LDS together and then
+  // want the matrix pipe together (round 1's ablation: ~890 cycles per K step with the DMA switched off).  Here the waves of
+  // a workgroup form two groups that sit on the same four SIMDs (wave w and wave w + NW / 2 share one) and run half a K step
+  // apart: while group 0 reads the fragments of tile k and issues its DMA pieces, group 1 multiplies tile k - 1, and vice
+  // versa -- two workgroup barriers per K step, each wave's MFMA burst beside its partner's LDS / DMA phase
+  // (MI355X_MICROARCH.md, "Two waves per SIMD").  Stage of tile t = t % NS; a stage is refilled one barrier after BOTH groups
+  // have finished reading it, so NS >= 3 keeps a tile in flight for a whole K step.  Same MFMAs on the same fragments in the
+  // same order per accumulator as the plain loop: bit-identical results.
+    static_assert(NS >= 3 && (NW % 2) == 0, "ping-pong loop: three stages, an even number of waves");
+    const bool grp1 = wave >= NW / 2;
+    bf8_t fm[2][WTM], fn[2][WTN];
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    auto read_phase = [&](int kt) {
+      if (kt + NS - 1 < nk && !(lab_bits(dbg) & 2)) issue(kt + NS - 1, (kt + NS - 1) % NS);
+      request(kt % NS, fm, fn);
+      frag_async_wait<0>();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+      }
+    };
+    auto mfma_phase = [&](int kt) {
+      multiply(0, fm, fn);
+      multiply(1, fm, fn);
+      rowsums(kt, fm);
+    };
+    auto phase_end = [&](int kt_next) {       // tile kt_next (this wave's pieces) has landed before the barrier that opens its first read
+      if (kt_next < nk) wait_tile(kt_next);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    if (!grp1) {
+      for (int kt = 0; kt < nk; ++kt) {
+        read_phase(kt);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        mfma_phase(kt);
+        phase_end(kt + 1);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) mfma_phase(kt - 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_phase(kt);
+        phase_end(kt + 1);
+      }
+      mfma_phase(nk - 1);
+    }
+  } else if constexpr (PM == 1) {
   // register-pipelined: while the MFMAs of tile kt run from one register set, the reads of tile kt+1 fill the other;
   // tile t lives in stage t % NS and its stage goes back to the DMA one barrier after its reads have completed
     bf8_t fmA[2][WTM], fnA[2][WTN], fmB[2][WTM], fnB[2][WTN];
@@ -854,6 +914,233 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(const CrctGem
   int tile_m, tile_n;
   if (!map_tile(tmap, ((j / S) << 3) | x, tile_m, tile_n)) return;
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, true>(g, tile_m, tile_n, 0, j % S, tile_m * tmap.tiles_n + tile_n);
+}
+
+// ====================================================================================== loader waves (round 4)
+// What the plain loop above pays per K step is not arithmetic and not the fill path's bandwidth (tools/lab/fill_probe.hip: a CU
+// takes in 124 - 135 GB/s L2-hot through buffer_load ... lds with all 256 CUs streaming, 150 with 64) but the ISSUE of the fill:
+// a CU's texture path accepts one 1-KiB piece per ~13 - 16 cycles, the 24 - 32 pieces of a K step are issued by all eight waves
+// together right behind the barrier, and every wave sits in that queue (~300 cycles) before it may read a fragment or start an
+// MFMA.  Splitting the waves into two half-step-shifted groups (PM = 2) does not help -- the group that loads still waits out
+// its own pieces (measured: slower everywhere, profiles/r4_gemm_lab_*).  Here the fill has waves of its own: NL loader waves
+// (one per SIMD at NL = 4) own the whole LDS-DMA ring -- all source offsets, every issue, the counted vmcnt wait -- and the
+// WM x WN compute waves never execute a vector-memory instruction inside the K loop: barrier, fragment reads, MFMAs.  One
+// workgroup barrier per K step as before: a loader arrives when its pieces of tile k have landed, a compute wave when it has
+// the fragments of tile k - 1 in registers; behind it the loaders refill stage (k - 1) % NS with tile k + NS - 1.  Same
+// fragments, same MFMA order per accumulator: bit-identical to the plain loop.  The loader waves then help to walk the staged
+// epilogue (NTH threads).
+// PIPE: the compute waves also keep TWO fragment register sets: behind the barrier of K step k they request the fragments of tile k
+// and then multiply tile k - 1 out of the other set, so the LDS round trip of a K step hides behind the MFMAs of the previous one
+// (what PM = 1 of the plain kernel could not deliver while the same waves also had to issue the DMA).  A stage is then free one
+// barrier earlier, the ring holds all NS tiles at the start and the loaders keep NS - 1 in flight.
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE = false>
+__device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int tile_m, const int tile_n) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN, NTH = (NW + NL) * 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NPA = A_BYTES / 1024, NPB = B_BYTES / 1024;
+  constexpr int PAL = NPA / NL, PBL = NPB / NL, L = PAL + PBL;            // pieces per loader wave per K tile
+  constexpr int WTM = BM / WM / 16, WTN = BN / WN / 16;
+  static_assert(PAL >= 1 && PBL >= 1 && PAL * NL == NPA && PBL * NL == NPB, "tile / loader-wave mismatch");
+  static_assert(NS >= 2 && BK == 64, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;                              // compute waves: wm < WM
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = g.K / BK;
+
+  f4_t acc[WTN][WTM];
+#pragma unroll
+  for (int a = 0; a < WTN; ++a)
+#pragma unroll
+    for (int b = 0; b < WTM; ++b) acc[a][b] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_rs = g.rowsum_out != nullptr && tile_n == 0;
+  f4_t accb[WTM];
+#pragma unroll
+  for (int b = 0; b < WTM; ++b) accb[b] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (wave >= NW) {
+    // ------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ... of both images
+    const int lw = wave - NW;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)OOB_OFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, (int)OOB_OFF, 0x00020000);
+    unsigned offA[PAL], offB[PBL];
+#pragma unroll
+    for (int i = 0; i < PAL; ++i) offA[i] = dma_src_offset<TA, TM>((i * NL + lw) * 64 + lane, m0, g.M, g.lda);
+#pragma unroll
+    for (int i = 0; i < PBL; ++i) offB[i] = dma_src_offset<TB, TN>((i * NL + lw) * 64 + lane, n0, g.N, g.ldb);
+    const int stepA = TA ? (int)(64 * g.lda * 2) : 128, stepB = TB ? (int)(64 * g.ldb * 2) : 128;
+    auto issue = [&](int kt, int st) {
+      char* base = smem + st * STAGE + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < PAL; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(base + i * NL * 1024), 16, (int)offA[i], kt * stepA, 0, 0);
+#pragma unroll
+      for (int i = 0; i < PBL; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NL * 1024), 16, (int)offB[i], kt * stepB, 0, 0);
+    };
+    if constexpr (PIPE) {
+      const int npre = nk < NS ? nk : NS;
+      for (int t = 0; t < npre; ++t) issue(t, t);
+      int st_next = 0;                      // the barrier of K step kt (>= 1) frees the stage of tile kt - 1
+      for (int kt = 0; kt < nk; ++kt) {
+        const int issued = kt == 0 ? NS - 1 : kt + NS - 2;
+        const int ahead = (nk - 1 < issued ? nk - 1 : issued) - kt;
+        if (NS >= 4 && ahead >= 3) wait_vmcnt<3 * L>();
+        else if (NS >= 3 && ahead >= 2) wait_vmcnt<2 * L>();
+        else if (ahead >= 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt >= 1) {
+          if (kt - 1 + NS < nk) issue(kt - 1 + NS, st_next);
+          st_next = st_next + 1 == NS ? 0 : st_next + 1;
+        }
+      }
+    } else {
+    const int npre = nk < NS - 1 ? nk : NS - 1;
+    for (int t = 0; t < npre; ++t) issue(t, t);
+    int st_next = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = (nk - 1 < kt + NS - 2 ? nk - 1 : kt + NS - 2) - kt;      // younger tiles that may stay in flight
+      if (NS >= 5 && ahead >= 3) wait_vmcnt<3 * L>();
+      else if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+      else if (NS >= 3 && ahead >= 1) wait_vmcnt<L>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
+      st_next = st_next + 1 == NS ? 0 : st_next + 1;
+    }
+    }
+  } else {
+    // ------------------------------------------------------------ compute wave: no vector-memory instruction in the loop
+    FragBase<TA, TM, WTM> fbA;
+    FragBase<TB, TN, WTN> fbB;
+    fbA.init(0, wm * (BM / WM), lane);
+    fbB.init(A_BYTES, wn * (BN / WN), lane);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    constexpr int N_HALF = WTM * (TA ? 2 : 1) + WTN * (TB ? 2 : 1);
+    bf8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    if constexpr (PIPE) {
+      bf8_t fmA[2][WTM], fnA[2][WTN], fmB[2][WTM], fnB[2][WTN];
+      auto mul = [&](int kt, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+          for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+#pragma unroll
+          for (int a = 0; a < WTN; ++a)
+#pragma unroll
+            for (int b = 0; b < WTM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[h][a], fm[h][b], acc[a][b], 0, 0, 0);
+        }
+        if (do_rs) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if ((((kt << 1) + h) & (WN - 1)) == wn) {
+#pragma unroll
+              for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[h][b], accb[b], 0, 0, 0);
+            }
+        }
+      };
+      auto step = [&](int kt, int stg, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN], bf8_t (&fm_p)[2][WTM], bf8_t (&fn_p)[2][WTN]) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        uint32_t ca[FragBase<TA, TM, WTM>::NB], cb[FragBase<TB, TN, WTN>::NB];
+        fbA.at(smem_base + stg * STAGE, ca);
+        fbB.at(smem_base + stg * STAGE, cb);
+        FragBase<TA, TM, WTM>::template read<0>(ca, fm[0]);
+        FragBase<TB, TN, WTN>::template read<0>(cb, fn[0]);
+        FragBase<TA, TM, WTM>::template read<1>(ca, fm[1]);
+        FragBase<TB, TN, WTN>::template read<1>(cb, fn[1]);
+        if (kt > 0) mul(kt - 1, fm_p, fn_p);               // the previous tile's MFMAs run while these reads are in flight
+        frag_async_wait<0>();                              // ... and the stage is read out before this wave reaches the next barrier
+      };
+      int stg = 0;
+      for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, stg, fmA, fnA, fmB, fnB);
+        stg = stg + 1 == NS ? 0 : stg + 1;
+        if (kt + 1 < nk) {
+          step(kt + 1, stg, fmB, fnB, fmA, fnA);
+          stg = stg + 1 == NS ? 0 : stg + 1;
+        }
+      }
+      if (nk & 1) mul(nk - 1, fmA, fnA);
+      else mul(nk - 1, fmB, fnB);
+    } else {
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      bf8_t fm[2][WTM], fn[2][WTN];
+      uint32_t ca[FragBase<TA, TM, WTM>::NB], cb[FragBase<TB, TN, WTN>::NB];
+      fbA.at(smem_base + st * STAGE, ca);
+      fbB.at(smem_base + st * STAGE, cb);
+      FragBase<TA, TM, WTM>::template read<0>(ca, fm[0]);
+      FragBase<TB, TN, WTN>::template read<0>(cb, fn[0]);
+      FragBase<TA, TM, WTM>::template read<1>(ca, fm[1]);
+      FragBase<TB, TN, WTN>::template read<1>(cb, fn[1]);
+      frag_async_wait<(N_HALF <= 15 ? N_HALF : 0)>();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1) {
+          asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));     // keep the first half's MFMAs in front of the second wait
+          frag_async_wait<0>();
+        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+#pragma unroll
+        for (int a = 0; a < WTN; ++a)
+#pragma unroll
+          for (int b = 0; b < WTM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[h][a], fm[h][b], acc[a][b], 0, 0, 0);
+      }
+      if (do_rs) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if ((((kt << 1) + h) & (WN - 1)) == wn) {
+#pragma unroll
+            for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[h][b], accb[b], 0, 0, 0);
+          }
+      }
+      st = st + 1 == NS ? 0 : st + 1;
+    }
+    }
+  }
+  if (do_rs) {
+    static_assert((WN & (WN - 1)) == 0 && WN * BM * 4 <= NS * STAGE, "row-sum staging");
+    float* rs = reinterpret_cast<float*>(smem);            // [WN][BM]
+    __syncthreads();                                       // every compute wave is done reading the operand ring
+    if (wave < NW && lane < 16) {
+#pragma unroll
+      for (int b = 0; b < WTM; ++b) rs[wn * BM + wm * (BM / WM) + b * 16 + lane] = accb[b][0];
+    }
+    __syncthreads();
+    for (int i = tid; i < BM; i += NTH) {
+      if (m0 + i < g.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) v += rs[w * BM + i];  // fixed order: reproducible
+        g.rowsum_out[m0 + i] += v;
+      }
+    }
+  }
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE, NTH>(g, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE = false>
+__global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ldr_kernel(const CrctGemmArgs g, const TileMap tmap) {
+  int tile_m, tile_n;
+  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
+  gemm_ldr_body<TM, TN, WM, WN, TA, TB, NS, NL, PIPE>(g, tile_m, tile_n);
 }
 
 // ====================================================================================== fp8 forward (BASELINE configs[4])
@@ -1223,7 +1510,7 @@ inline void group_concat(GroupArgs& ga, int* grid) {      // host side of concat
 // A grid smaller than the tile count (launch_group's max_wgs) makes the workgroups persistent: workgroup b takes tiles b, b + grid,
 // ... -- the weight gradients then occupy at most `grid` CUs' LDS at a time and the data-gradient chain that runs beside them
 // finds free CUs at once (grid a multiple of 8: a workgroup's tiles stay on its XCD's rectangle).
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int PM = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArgs ga) {
   const int total = ga.concat ? 8 * ga.per_xcd : ga.tile_begin[ga.n];
   for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
@@ -1231,18 +1518,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
     if (group_pick(ga, bid, pi, tm, tn)) {
       CrctGemmArgs g = ga.p[pi];
       g.ta = TA; g.tb = TB;
-      gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS>(g, tm, tn, 0);
+      gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tm, tn, 0);
     }
     if (bid + (int)gridDim.x < total) __syncthreads();      // the next tile's first DMA reuses the ring the epilogue has just read
   }
 }
 
 static int g_group_max_wgs = 0;        // crct_gemm_group_max_workgroups: 0 = one workgroup per tile
+static int g_group_wgrad_cfg = 4;      // configuration of a layer's grouped weight gradients: 4 = 128 x 128 plain loop, 39 = the same tile, two-phase loop
 static int g_group_concat = 0;         // crct_gemm_group_concat: grouped weight gradients as ONE tile list over the XCDs (GroupArgs.concat); measured: no gain
 extern "C" int crct_gemm_group_concat(int on) { g_group_concat = on != 0; return 0; }
 extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
 
-template <int TM, int TN, int WM, int WN, int NS>
+template <int TM, int TN, int WM, int WN, int NS, int PM = 0>
 hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   GroupArgs ga = {};
@@ -1263,7 +1551,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_GROUP(TA_, TB_)                                                                                        \
   do {                                                                                                                     \
-    auto kern = gemm_group_kernel<TM, TN, WM, WN, TA_, TB_, NS>;                                                           \
+    auto kern = gemm_group_kernel<TM, TN, WM, WN, TA_, TB_, NS, PM>;                                                       \
     static bool attr_set = false;                                                                                          \
     if (lds > 64 * 1024 && !attr_set) {                                                                                    \
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
@@ -1370,6 +1658,32 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int TM, int TN, int WM, int WN, int NS, int NL, bool PIPE = false>
+hipError_t launch_ldr(const CrctGemmArgs& g, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  int tiles = 0;
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
+  const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_LDR(TA_, TB_)                                                                                          \
+  do {                                                                                                                     \
+    auto kern = gemm_ldr_kernel<TM, TN, WM, WN, TA_, TB_, NS, NL, PIPE>;                                                   \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    launch_kernel(kern, dim3(tiles), dim3((WM * WN + NL) * 64), lds, s, g, tmap);                                          \
+  } while (0)
+  if (!g.ta && !g.tb) CRCT_LAUNCH_LDR(false, false);
+  else if (!g.ta && g.tb) CRCT_LAUNCH_LDR(false, true);
+  else if (g.ta && g.tb) CRCT_LAUNCH_LDR(true, true);
+  else return hipErrorInvalidValue;
+#undef CRCT_LAUNCH_LDR
+  return hipGetLastError();
+}
+
 // the DMA path needs whole K tiles, 32-bit source offsets, and 16-byte aligned rows
 inline bool pipe_ok(const CrctGemmArgs& g) {
   if (g.K % BK != 0 || g.K < BK) return false;
@@ -1447,7 +1761,7 @@ struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
-  static constexpr int NV = 120;       // (30 LDS-DMA / fp8 / register-staged configuration ids + spare) x {fwd, dgrad, wgrad}
+  static constexpr int NV = 210;       // (66 LDS-DMA / fp8 / register-staged configuration ids + spare) x {fwd, dgrad, wgrad}
   double flops[NV] = {0}; long count[NV] = {0};
   bool log_on = false;
   std::vector<CrctLaunchRec> log;
@@ -1579,7 +1893,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g.q_out && !(pipe && g.q_scale && g.ld_q % 8 == 0)) return hipErrorInvalidValue;      // the fp8 output copy lives in the staged epilogue
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 15 && !(t >= 22 && t <= 35 && pipe && !is_f8)) t = 12;
+  if (t > 15 && !(((t >= 22 && t <= 35) || (t >= 38 && t <= 65)) && pipe && !is_f8)) t = 12;
   // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21)
   if (is_f8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
@@ -1632,6 +1946,37 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 33: e = launch_pipe<4, 4, 2, 4, 3, 1>(g, s); break; // 128x128, 8 waves, 3 stages
       case 34: e = launch_pipe<8, 4, 4, 2, 3, 1>(g, s); break; // 256x128, 8 waves, 3 stages
       case 35: e = launch_pipe<5, 3, 2, 2, 3, 1>(g, s); break; // 160x96, 4 waves, 3 stages
+      // two-phase ("ping-pong") main loop (PM = 2, round 4): the two waves of a SIMD run half a K step apart
+      case 38: e = launch_pipe<4, 2, 4, 2, 3, 2>(g, s); break; // 128x64, 8 waves (4x2), 3 stages (72 KB: two per CU)
+      case 39: e = launch_pipe<4, 4, 2, 4, 3, 2>(g, s); break; // 128x128, 8 waves (2x4: 64x32 wave tiles), 3 stages (96 KB)
+      case 40: e = launch_pipe<4, 2, 4, 2, 4, 2>(g, s); break; // 128x64, 8 waves (4x2), 4 stages (96 KB)
+      case 41: e = launch_pipe<4, 4, 4, 2, 3, 2>(g, s); break; // 128x128, 8 waves (4x2: 32x64 wave tiles), 3 stages
+      case 42: e = launch_pipe<8, 4, 4, 2, 3, 2>(g, s); break; // 256x128, 8 waves (4x2: 64x64 wave tiles), 3 stages (144 KB)
+      case 43: e = launch_pipe<2, 4, 2, 4, 3, 2>(g, s); break; // 64x128, 8 waves (2x4), 3 stages
+      case 44: e = launch_pipe<8, 2, 4, 2, 3, 2>(g, s); break; // 256x64, 8 waves (4x2: 64x32 wave tiles), 3 stages (120 KB)
+      case 45: e = launch_pipe<4, 4, 2, 4, 4, 2>(g, s); break; // 128x128, 8 waves (2x4), 4 stages (128 KB)
+      // loader waves (round 4): WM x WN compute waves + NL waves that own the LDS-DMA ring
+      case 46: e = launch_ldr<4, 2, 4, 2, 3, 4>(g, s); break;  // 128x64, 8 + 4 waves, 3 stages (72 KB)
+      case 47: e = launch_ldr<4, 2, 4, 2, 2, 4>(g, s); break;  // 128x64, 8 + 4 waves, 2 stages (48 KB)
+      case 48: e = launch_ldr<4, 4, 2, 4, 3, 4>(g, s); break;  // 128x128, 8 (2x4) + 4 waves, 3 stages (96 KB)
+      case 49: e = launch_ldr<4, 4, 2, 4, 2, 4>(g, s); break;  // 128x128, 8 + 4 waves, 2 stages (64 KB)
+      case 50: e = launch_ldr<8, 4, 4, 2, 3, 4>(g, s); break;  // 256x128, 8 (4x2: 64x64 wave tiles) + 4 waves, 3 stages (144 KB)
+      case 51: e = launch_ldr<4, 2, 4, 2, 4, 4>(g, s); break;  // 128x64, 8 + 4 waves, 4 stages (96 KB)
+      case 52: e = launch_ldr<4, 2, 4, 2, 3, 2>(g, s); break;  // 128x64, 8 + 2 waves, 3 stages
+      case 53: e = launch_ldr<4, 4, 2, 2, 3, 4>(g, s); break;  // 128x128, 4 (2x2: 64x64 wave tiles) + 4 waves, 3 stages
+      case 54: e = launch_ldr<4, 2, 2, 2, 3, 2>(g, s); break;  // 128x64, 4 (2x2: 64x32 wave tiles) + 2 waves, 3 stages
+      case 55: e = launch_ldr<8, 4, 4, 2, 2, 4>(g, s); break;  // 256x128, 8 + 4 waves, 2 stages (96 KB)
+      // loader waves + two fragment register sets in the compute waves (PIPE)
+      case 56: e = launch_ldr<4, 2, 2, 2, 3, 2, true>(g, s); break;  // 128x64, 4 (64x32 wave tiles) + 2 waves, 3 stages (72 KB)
+      case 57: e = launch_ldr<4, 2, 4, 2, 3, 4, true>(g, s); break;  // 128x64, 8 + 4 waves, 3 stages
+      case 58: e = launch_ldr<4, 4, 2, 2, 3, 4, true>(g, s); break;  // 128x128, 4 (64x64 wave tiles) + 4 waves, 3 stages (96 KB)
+      case 59: e = launch_ldr<4, 4, 2, 4, 3, 4, true>(g, s); break;  // 128x128, 8 (64x32) + 4 waves, 3 stages
+      case 60: e = launch_ldr<8, 4, 4, 2, 3, 4, true>(g, s); break;  // 256x128, 8 (64x64) + 4 waves, 3 stages (144 KB)
+      case 61: e = launch_ldr<4, 2, 2, 2, 4, 2, true>(g, s); break;  // 128x64, 4 + 2 waves, 4 stages (96 KB)
+      case 62: e = launch_ldr<4, 4, 2, 2, 2, 4, true>(g, s); break;  // 128x128, 4 + 4 waves, 2 stages (64 KB: two per CU)
+      case 63: e = launch_ldr<4, 2, 2, 2, 3, 4, true>(g, s); break;  // 128x64, 4 + 4 waves, 3 stages
+      case 64: e = launch_ldr<4, 2, 2, 2, 2, 2, true>(g, s); break;  // 128x64, 4 + 2 waves, 2 stages (48 KB: three per CU)
+      case 65: e = launch_ldr<8, 4, 4, 2, 2, 4, true>(g, s); break;  // 256x128, 8 + 4 waves, 2 stages (96 KB)
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
   } else {
@@ -1676,9 +2021,9 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
   }
   // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages; CrctGemmArgs.tile of the first
   // problem may pick the other one (crct_engine_set_site_policy: A/B runs)
-  const int cfg = (gs[0].tile == 4 || gs[0].tile == 9) ? gs[0].tile : (gs[0].ta ? 4 : 9);
+  const int cfg = (gs[0].tile == 4 || gs[0].tile == 9 || gs[0].tile == 39) ? gs[0].tile : (gs[0].ta ? g_group_wgrad_cfg : 9);
   prof_begin(cfg * 3 + kind_of(gs[0]), gs, n);
-  const hipError_t e = cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s);
+  const hipError_t e = cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : (cfg == 39 ? launch_group<4, 4, 2, 4, 3, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s));
   g_time_start = g_time_stop = nullptr;
   log_launch(gs, n, cfg, 0);
   return e;

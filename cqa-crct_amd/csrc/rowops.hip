@@ -839,6 +839,29 @@ __global__ __launch_bounds__(256) void cast_runs_kernel(const float* __restrict_
   }
 }
 
+// the reverse over the same kind of table: y[off[r] + i] = float(x[off[r] + i]) (the all-reduced bf16 values of the gradients backward
+// accumulates in fp32 -- biases, LayerNorm, embeddings, heads -- put back into the fp32 .grad views)
+__global__ __launch_bounds__(256) void uncast_runs_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, const int64_t* __restrict__ run_off,
+                                                          const int64_t* __restrict__ run_len, const int32_t* __restrict__ blk_seg,
+                                                          const int64_t* __restrict__ blk_off, int n_blk) {
+  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    const int r = blk_seg[blk];
+    const int64_t off = blk_off[blk], base = run_off[r] + off;
+    int64_t n = run_len[r] - off;
+    if (n > 4096) n = 4096;                      // = ADAMW_CHUNK (optim.hip)
+    const int64_t head = (8 - (base & 7)) & 7;
+    for (int64_t i = threadIdx.x; i < (head < n ? head : n); i += 256) y[base + i] = bf2f(x[base + i]);
+    const int64_t nv = n > head ? (n - head) / 8 : 0;
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+      const int64_t e = base + head + 8 * i;
+      const uint4 u = *reinterpret_cast<const uint4*>(x + e);
+      *reinterpret_cast<float4*>(y + e) = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+      *reinterpret_cast<float4*>(y + e + 4) = make_float4(bf2f((bf16_t)(u.z & 0xffff)), bf2f((bf16_t)(u.z >> 16)), bf2f((bf16_t)(u.w & 0xffff)), bf2f((bf16_t)(u.w >> 16)));
+    }
+    for (int64_t i = head + nv * 8 + threadIdx.x; i < n; i += 256) y[base + i] = bf2f(x[base + i]);
+  }
+}
+
 __global__ void uncast_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   const long stride = (long)gridDim.x * blockDim.x * 8;
@@ -1442,6 +1465,17 @@ int crct_cast_runs_f32_bf16(const float* x, void* y, const int64_t* off, const i
   if (n_blk <= 0) return 0;
   const long grid = n_blk > 2048 ? 2048 : n_blk;
   hipLaunchKernelGGL(cast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, off, len, blk_seg, blk_off, (int)n_blk);
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int crct_cast_runs_bf16_f32(const void* x, float* y, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
+                            int64_t n_blk, crct_stream_t stream) {
+  CRCT_REQUIRE(x && y && off && len && blk_seg && blk_off, "cast_runs: null argument");
+  CRCT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cast_runs: 16-byte aligned buffers");
+  if (n_blk <= 0) return 0;
+  const long grid = n_blk > 2048 ? 2048 : n_blk;
+  hipLaunchKernelGGL(uncast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, off, len, blk_seg, blk_off, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

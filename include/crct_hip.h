@@ -264,6 +264,11 @@ int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream)
  * it what the weight-gradient GEMMs have not already written into the bf16 buffer (CrctStepCfg.grads_bf16). */
 int crct_cast_runs_f32_bf16(const float* x, void* y, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
                             int64_t n_blk, crct_stream_t stream);
+/* The reverse over the same table: y[off[r] + i] = float(x[off[r] + i]) (x bf16, y fp32).  After the exchange the all-reduced values
+ * of those runs go back into the fp32 gradient buffer, so that every .grad view backward ACCUMULATES into holds the reduced gradient
+ * (DistributedDataParallel's contract, CRCT/train.py:138-143) even when the Linear weight gradients stay in the bf16 buffer. */
+int crct_cast_runs_bf16_f32(const void* x, float* y, const int64_t* off, const int64_t* len, const int32_t* blk_seg, const int64_t* blk_off,
+                            int64_t n_blk, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scaled-dot-product attention over short sequences, one workgroup per (batch, head), everything

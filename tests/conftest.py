@@ -40,7 +40,8 @@ def pytest_collection_finish(session):
         return
     try:
         import torch
-        if torch.cuda.device_count() < 1:          # counting devices does not initialise the GPU
+        n_gpus = torch.cuda.device_count()         # counting devices does not initialise the GPU
+        if n_gpus < 1:
             return
     except Exception:
         return
@@ -49,7 +50,8 @@ def pytest_collection_finish(session):
     import tempfile
     outdir = tempfile.mkdtemp(prefix="crct_ddp_")
     procs = {}
-    for case in ("tiny", "full"):
+    cases = ("tiny", "full") + (("tiny_rccl", "full_rccl") if n_gpus >= 2 else ())      # RCCL between two processes needs two GPUs
+    for case in cases:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -58,8 +60,10 @@ def pytest_collection_finish(session):
             log_path = os.path.join(outdir, "%s_rank%d.log" % (case, rank))
             log = open(log_path, "w")
             env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-            pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(rank), "2", str(port), outdir, case],
-                                  stdout=log, stderr=subprocess.STDOUT, env=env)
+            argv = [sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(rank), "2", str(port), outdir, case.split("_")[0]]
+            if case.endswith("_rccl"):
+                argv.append("nccl")
+            pr = subprocess.Popen(argv, stdout=log, stderr=subprocess.STDOUT, env=env)
             pr.log_path = log_path
             procs[case].append(pr)
     _DDP["workers"] = (outdir, procs)

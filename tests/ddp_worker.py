@@ -3,7 +3,10 @@ exchange over gloo, as bench.py's CRCT_BENCH_SHARE_GPU path does; the exchange c
 mode: ONE engine backward call, per-segment events, bucketed all-reduces on a communication stream -- is the one a real
 multi-GPU run uses with the RCCL backend.  Each rank takes its half of a batch; rank 0 writes the all-reduced gradients.
 
-    python tests/ddp_worker.py <rank> <world> <port> <outdir> <case>
+    python tests/ddp_worker.py <rank> <world> <port> <outdir> <case> [backend]
+
+backend "nccl" (a box with >= 2 GPUs: tests/test_ddp_gpu.py starts it only there): rank r runs on cuda:r and the exchange is the
+product's default route -- crct.rccl.Communicator over the ranks, ncclAllReduce on the engine's auxiliary stream.
 """
 import os
 import sys
@@ -22,6 +25,7 @@ def halves(batch, rank, world):
 
 def main():
     rank, world, port, outdir, case = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    backend = sys.argv[6] if len(sys.argv) > 6 else "gloo"
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import numpy as np
     import torch
@@ -31,9 +35,12 @@ def main():
     from crct.step_adapter import forward as step_forward
     from crct.ddp import FlatGradDDP, all_reduce_stats
 
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     if case == "tiny":
         cfg = C.tiny_config()
         params = C.default_params(categories=9, device=dev, rank=rank, world_size=world, ddp=True)
@@ -54,6 +61,7 @@ def main():
     # the reference's payload first (fp32: the numbers of steps (1) and (2) are compared with the oracle at the fp32 bounds)
     ddp = FlatGradDDP(model, bucket_mb=bucket_mb, grad_dtype=torch.float32)
     assert ddp.event_mode
+    assert (ddp.communicator() is not None) == (backend == "nccl")      # RCCL called directly on the auxiliary stream, or torch.distributed (gloo)
     mine = halves(batch, rank, world)
     out = {}
 
@@ -83,11 +91,19 @@ def main():
     out["g_accum"] = core.flat_grads.detach().cpu().numpy().copy()
     out["params_after_broadcast"] = core.flat_params.detach().cpu().numpy().copy()[:4096]
 
-    # (3) the bf16 payload (default): the all-reduced gradient lives in the communication buffer; .grad keeps the local fp32 one
+    # (3) the bf16 payload (default).  No fused optimizer is attached yet, so by default the reduced bucket is written back into
+    # the fp32 .grad views (what a stock optimizer / clip_grad_norm_ / a GradScaler read: ADVICE r3) ...
     from crct.optim import get_optimizer
     from crct.ddp import AsyncStats
     ddp16 = FlatGradDDP(model, bucket_mb=bucket_mb, broadcast=False)
-    assert ddp16.grad_dtype == torch.bfloat16 and core._ddp is ddp16
+    assert ddp16.grad_dtype == torch.bfloat16 and core._ddp is ddp16 and ddp16.materializes()
+    core.zero_flat_grads()
+    step_forward(model, mine, params)[0].backward()
+    assert ddp16.grad_source() is None
+    torch.cuda.synchronize()
+    out["g_default_grad_views"] = core.flat_grads.detach().cpu().numpy().copy()
+    # ... and with materialize_grads=False the all-reduced gradient lives in the communication buffer only
+    ddp16.materialize_grads = False
     core.zero_flat_grads()
     red = AsyncStats(world, device=dev)
     res = step_forward(model, mine, params)
@@ -115,12 +131,18 @@ def main():
     assert ddp16.grad_source() is None
     torch.cuda.synchronize()
     out["g_materialized"] = core.flat_grads.detach().cpu().numpy().copy()
-    # (5) the fused AdamW consumes the bf16 buffer as it lies: one step, both ranks must end on identical parameters
-    ddp16.materialize_grads = False
-    core.zero_flat_grads()
+    # (5) the fused AdamW consumes the bf16 buffer as it lies: one step, both ranks must end on identical parameters.  With it
+    # attached the default (materialize_grads=None) no longer writes the weight gradients back: .grad of what backward accumulates
+    # in fp32 holds the reduced values, the fp32 views of the Linear weight gradients read NaN -- never a local or stale gradient
+    ddp16.materialize_grads = None
+    opt = get_optimizer(params, model)
+    assert not ddp16.materializes()
+    core.zero_flat_grads(lazy=True)
     step_forward(model, mine, params)[0].backward()
     assert ddp16.grad_source() is not None
-    opt = get_optimizer(params, model)
+    torch.cuda.synchronize()
+    out["g_views_with_fused_optimizer"] = core.flat_grads.detach().cpu().numpy().copy()
+    out["g_bf16_with_fused_optimizer"] = ddp16.grad_source().float().cpu().numpy().copy()
     opt.overlap = case != "tiny"
     opt.step()
     opt.zero_grad()

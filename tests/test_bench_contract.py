@@ -73,6 +73,36 @@ def test_driver_entry_points_are_there():
         assert os.path.getsize(os.path.join(ROOT, top)) > 1000, top
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it (the shape of the driver's 1-GPU command) starts N fresh rank
+    processes itself -- the reference's mp.spawn (CRCT/train.py:356-363) -- relays rank 0's ONE JSON line, and exits with the
+    first failing rank's code.  --launch-check stops every rank before it touches a GPU, so this runs on the CPU box."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR") and not k.startswith("CRCT_")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = [r for r in res.stdout.strip().split("\n") if r.startswith("{")]
+    assert len(rows) == 1 and res.stdout.strip() == rows[0], res.stdout          # stdout carries rank 0's line and nothing else
+    info = json.loads(rows[0])
+    assert info["rank"] == 0 and info["world"] == 4 and info["master"].startswith("127.0.0.1:") and info["ipc_legacy"] == "0"
+    for r in (1, 2, 3):                                                          # the other ranks report on stderr: each its own rank / device
+        assert "rank %d: {'rank': %d, 'local_rank': %d, 'world': 4" % (r, r, r) in res.stderr
+    # a rank that dies takes the job down with its exit code (its peers would wait in a collective for ever otherwise)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], cwd=ROOT,
+                         env=dict(env, CRCT_LAUNCH_CHECK_FAIL_RANK="2"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 7
+    # under a launcher that has set the rendezvous already (torch.distributed.run) no further processes are started
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT,
+                         env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.startswith("rank 1:") and res.stderr.count("rank") == 0
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT,
+                         env=dict(env, RANK="1", WORLD_SIZE="4"), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "does not match WORLD_SIZE" in res.stderr
+
+
 @pytest.mark.gpu
 def test_two_rank_bench_runs_end_to_end():
     """The N > 1 path of bench.py as the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 bench.py
@@ -96,6 +126,8 @@ def test_two_rank_bench_runs_end_to_end():
         extra = ["--dtype", "fp8"] if dtype.endswith("fp8") else []
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grad-dtype", dtype.split("+")[0]] + extra + common
+        if dtype == "bf16":      # the default payload WITHOUT a launcher: exactly `python bench.py --gpus 2 ...`, which starts its own two ranks
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grad-dtype", "bf16"] + common
         res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         rows = [r for r in res.stdout.strip().split("\n") if r.startswith("{")]

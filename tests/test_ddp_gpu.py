@@ -28,6 +28,8 @@ def _results(case, ddp_workers):
     if ddp_workers is None:
         pytest.skip("the DDP workers were not started (no GPU visible at session start)")
     outdir, procs = ddp_workers
+    if case not in procs:
+        pytest.skip("needs two GPUs: the RCCL workers (one rank per GPU) are only started where torch.cuda.device_count() >= 2")
     for pr in procs[case]:
         rc = pr.wait(timeout=240)
         assert rc == 0, "DDP worker failed:\n" + open(pr.log_path).read()[-4000:]
@@ -43,9 +45,12 @@ def _cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("case", ["tiny", "full"])
+# "*_rccl": the same worker with one rank per GPU and the product's default route (crct.rccl: ncclCommInitRank over two
+# processes, ncclAllReduce / the stats all-reduce on the engine's auxiliary stream) -- only where the box has two GPUs
+@pytest.mark.parametrize("case", ["tiny", "full", "tiny_rccl", "full_rccl"])
 def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     r0, r1 = _results(case, ddp_workers)
+    case = case.split("_")[0]
     if case == "tiny":
         cfg = C.tiny_config()
         params = C.default_params(categories=9)
@@ -70,7 +75,7 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     # identical on both ranks, and equal to the mean of the ranks' losses' gradient
     for key in ("g_sync", "g_accum", "g_bf16", "g_materialized", "params_after_step", "stats9_async"):
         assert np.array_equal(r0[key], r1[key]), key
-    assert not np.array_equal(r0["g_bf16_local_fp32"], r1["g_bf16_local_fp32"])       # .grad keeps the LOCAL gradient in bf16-direct mode
+    assert not np.array_equal(r0["g_bf16_local_fp32"], r1["g_bf16_local_fp32"], equal_nan=True)       # materialize_grads=False after a packed pass: the Linear weights' .grad is NaN, not ...
     assert np.array_equal(r0["stats9_async"], r0["stats9"])
     mean_loss = 0.5 * (float(r0["loss"][0]) + float(r1["loss"][0]))
     assert abs(mean_loss - float(ref[0])) <= 2e-2 * abs(float(ref[0]))
@@ -99,6 +104,24 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     # materialize_grads: what the fp32 .grad views hold afterwards is that bf16 result (rewritten for this pass's batch: equal
     # to g_bf16 up to the dropout-free determinism of the step)
     assert np.array_equal(r0["g_materialized"][used], r0["g_bf16"][used])
+    # what .grad holds after a DEFAULT bf16 exchange.  No fused optimizer attached: every view holds the reduced gradient
+    assert np.array_equal(r0["g_default_grad_views"][used], r0["g_bf16"][used]) and np.array_equal(r1["g_default_grad_views"][used], r0["g_bf16"][used])
+    # FusedAdamW attached: the views backward accumulates in fp32 hold the reduced gradient, the owned Linear weights' read NaN
+    # (their reduced values live in the bf16 buffer the optimizer reads) -- on both ranks, never a local or a stale value
+    for r in (r0, r1):
+        v, g16 = r["g_views_with_fused_optimizer"][used], r["g_bf16_with_fused_optimizer"][used]
+        nan = np.isnan(v)
+        assert 0.90 < nan.mean() < 0.99, nan.mean()                       # the Linear weights are ~95 % of the elements
+        assert np.array_equal(v[~nan], g16[~nan])
+        assert np.array_equal(g16, r0["g_bf16"][used])                    # same batch, same weights: the same reduced gradient as step (3)
+    for e in table:                                                        # NaN exactly on 2-D encoder / head Linear weights, nowhere else
+        if e.used and (e.name.endswith(".bias") or "LayerNorm" in e.name or "embeddings" in e.name.split("encoder")[0]):
+            if not e.name.endswith("new_image_embeddings.weight"):
+                assert not np.isnan(r0["g_views_with_fused_optimizer"][e.offset:e.offset + e.numel]).any(), e.name
+    # after a packed (non-direct) pass with materialize_grads=False the owned views are NaN as well, on both ranks alike
+    for r in (r0, r1):
+        loc = r["g_bf16_local_fp32"][used]
+        assert np.isnan(loc).mean() > 0.90 and np.array_equal(loc[~np.isnan(loc)], r["g_bf16"][used][~np.isnan(loc)])
     # weight gradients written into the communication buffer by the GEMMs themselves (after a lazy clear): the same bits
     assert int(r0["packed_runs_only_after_full_clear"][0]) == 0 and int(r0["packed_runs_only_after_lazy_clear"][0]) == 1
     assert np.array_equal(r0["g_bf16_direct"][used], r0["g_bf16"][used]) and np.array_equal(r1["g_bf16_direct"][used], r0["g_bf16_direct"][used])

@@ -76,9 +76,9 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     if (f32) { hr.resize(nout); hipMemcpy(hr.data(), Cref, nout * 4, hipMemcpyDeviceToHost); }
     else { hrb.resize(nout); hipMemcpy(hrb.data(), Cref, nout * 2, hipMemcpyDeviceToHost); }
-    for (int tile = first_tile; tile < 36; ++tile)
+    for (int tile = first_tile; tile < 66; ++tile)
      for (int sk = 1; sk <= max_sk; ++sk) {
-      if (tile >= 16 && tile < 20) continue;
+      if ((tile >= 16 && tile < 20) || tile == 36 || tile == 37) continue;
       if (only_tile >= 0 && tile != only_tile) continue;
       if (sk > 1 && (s.ta || s.N > 1024 || !(tile == 4 || tile == 9 || tile == 12 || tile == 15) || s.K / 64 < 2 * sk)) continue;
       CrctGemmArgs g = make(tile, C);
