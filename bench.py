@@ -83,6 +83,8 @@ def parse():
                     help="what `value` is measured on.  resident: batches already in HBM (the contract's headline); prefetch: pageable "
                          "host batches through crct.input_pipeline.DevicePrefetcher; sync: pageable host batches moved by the step "
                          "adapter's synchronous .to(device), as the reference does")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="length in seconds of the extra sustained leg (config.sustained): the same step "
+                    "repeated back to back for at least this long, so that an outside sampler (rocm-smi, 5 s period) sees the GPU busy; 0 = skip")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the PCIe-inclusive leg (config.h2d_inclusive)")
     ap.add_argument("--host-feat", choices=("bf16", "fp32"), default="bf16", help="dtype of image_feat in the host batches of the prefetch legs")
     ap.add_argument("--fuse-zero-grad", action="store_true", help="AdamW zeroes the gradients it consumes (measured: no gain)")
@@ -103,6 +105,9 @@ def parse():
     ap.add_argument("--vis-stream", type=int, default=1, help="0: the visual stream's layers on the caller's stream (developer timing experiment)")
     ap.add_argument("--embed-scatter-split", action="store_true", help="developer A/B: the text embedding's backward sums and scatter as two launches")
     ap.add_argument("--wgrad-concat", type=int, default=-1, help="developer A/B: 0 = per-problem XCD rectangles for the grouped weight gradients (crct_gemm_group_concat)")
+    ap.add_argument("--wgrad-defer-sim", type=int, default=0, help="TIMING ONLY (wrong gradients): drop the co-attention-phase layers' weight-gradient "
+                    "launches and run the text-only tail's 1 + N times (prices a deferral policy; crct_engine_set_wgrad_defer_sim)")
+    ap.add_argument("--wgrad-cfg", type=int, default=-1, help="developer A/B: kernel configuration of the grouped weight-gradient launches (crct_gemm_group_wgrad_config)")
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
@@ -111,9 +116,13 @@ def parse():
     ap.add_argument("--adamw-wide-first", type=int, default=-1, help="developer A/B: how many of the first overlapped AdamW launches run unthrottled")
     ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
+    ap.add_argument("--fp8-bf16-forward", action="store_true", help="--dtype fp8 with bf16 FORWARD GEMMs: only the data and weight gradients run on fp8 "
+                    "operands (params['fp8_forward'] = False: the high-fidelity fp8 mode, gradient cosine ~0.97 against fp32 instead of ~0.87)")
     ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
     ap.add_argument("--site-policy", default="", help="developer A/B: comma list of site:kind:phase:cfg:split_k overrides of the per-site "
                     "GEMM launch policy (crct_engine_set_site_policy), e.g. t.ffn_down:fwd:0:4:3; reported in config.site_policy")
+    ap.add_argument("--class-policy", default="", help="developer A/B: comma list of class=cfg overrides of the GEMM shape-class table "
+                    "(crct_gemm_class_config; classes S.w S.n S.nl M.w M.n M.nl L.w L.n L.nl), e.g. L.w=9,L.n=9; reported in config.class_policy")
     ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
                     "(tools/pmc_sites.py matches it against a rocprofv3 counter collection)")
     ap.add_argument("--launch-check", action="store_true", help="test hook: every rank reports its rendezvous environment (rank 0 as the JSON line) and "
@@ -370,6 +379,8 @@ def main():
         params["fp8_backward"] = False
     if a.fp8_bf16_wgrad:
         params["fp8_wgrad"] = False
+    if a.fp8_bf16_forward:
+        params["fp8_forward"] = False
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
@@ -386,12 +397,18 @@ def main():
         L.load().crct_gemm_group_max_workgroups(a.wgrad_wgs)
     if a.wgrad_concat >= 0:
         L.load().crct_gemm_group_concat(a.wgrad_concat)
+    if a.wgrad_cfg >= 0:
+        L.load().crct_gemm_group_wgrad_config(a.wgrad_cfg)
+    for item in filter(None, a.class_policy.split(",")):
+        name, cfg_id = item.split("=")
+        L.load().crct_gemm_class_config(L.CLASS_NAMES.index(name), int(cfg_id))
     if a.embed_scatter_split:
         L.load().crct_embed_scatter_split(1)
     wg_mode = a.wgrad_streams if a.wgrad_streams >= 0 else (2 if (world > 1 or a.force_exchange) else 1)
     core.stream_mode = (a.vis_stream, wg_mode)
     if a.prefetch_wgs >= 0:
         core.prefetch_workgroups = a.prefetch_wgs
+    core.wgrad_defer_sim = a.wgrad_defer_sim
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1
@@ -500,6 +517,14 @@ def main():
     global_loss = float(cur["stats"][0]) if (stats_red is not None and cur.get("stats") is not None) else final_loss
     qa_per_s = a.batch * a.emulate_ranks * world * a.steps / dt
 
+    sustained = None
+    if a.sustained_s > 0:
+        # the timed region above is K steps (0.15 s at the driver's K = 20): too short for any outside observer of GPU utilisation.
+        # The same step, resident batches, for >= sustained_s seconds; reported next to the headline, never instead of it.
+        n_sus = max(a.steps, int(a.sustained_s / max(dt / a.steps, 1e-4)) + 1)
+        dt_s, _ = timed(n_sus)
+        sustained = {"seconds": dt_s, "steps": n_sus, "ms_per_step": dt_s / n_sus * 1e3,
+                     "qa_pairs_per_s": a.batch * a.emulate_ranks * world * n_sus / dt_s}
     h2d = None
     if a.input == "resident" and not a.no_h2d_leg:
         cur["feed"] = feed_of("prefetch")
@@ -561,13 +586,14 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
-                                      ("; fp8 (e4m3) forward GEMMs of every encoder Linear, bf16 backward" if a.fp8_forward_only else
+                                      ("; bf16 forward, fp8 backward: data gradient e5m2 x e4m3, weight gradient e5m2 x e4m3 of every encoder Linear" if a.fp8_bf16_forward else
+                                       "; fp8 (e4m3) forward GEMMs of every encoder Linear, bf16 backward" if a.fp8_forward_only else
                                        "; every encoder Linear in fp8: forward e4m3 x e4m3, data gradient e5m2 x e4m3" +
                                        (", bf16 weight gradients" if a.fp8_bf16_wgrad else ", weight gradient e5m2 x e4m3"))
                                       if a.dtype == "fp8" else ""),
                           "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                           "global_loss": global_loss, "input": a.input, "host_enqueue_ms_per_step": host_ms,
-                          "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None,
+                          "sustained": sustained, "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None, "class_policy": a.class_policy or None,
                           "gemm_sites": sites, "gemm_variants": rows}}
         if flop_qa:
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)

@@ -32,6 +32,7 @@ class LaunchRec(C.Structure):
 SITE_NAMES = ["none", "t.qkv", "t.out", "t.ffn_up", "t.ffn_down", "v.qkv", "v.out", "v.ffn_up", "v.ffn_down",
               "c.qkv_t", "c.qkv_v", "c.out_t", "c.out_v", "img_emb", "head"]      # CRCT_SITE_* of include/crct_hip.h
 KIND_NAMES = ["fwd", "dgrad", "wgrad"]
+CLASS_NAMES = ["S.w", "S.n", "S.nl", "M.w", "M.n", "M.nl", "L.w", "L.n", "L.nl"]      # crct_gemm_class_config: rows bucket x column class
 
 
 class HeadArgs(C.Structure):
@@ -138,6 +139,10 @@ PROTOTYPES = {
     "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, c_f32, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
     "crct_prefetch": (C.c_int, [vp, c_i64, C.c_int, vp]),
+    "crct_gemm_group_wgrad_config": (C.c_int, [C.c_int]),
+    "crct_lab_xcd_band": (C.c_int, [C.c_int]),
+    "crct_engine_set_wgrad_defer_sim": (C.c_int, [vp, C.c_int]),
+    "crct_gemm_class_config": (C.c_int, [C.c_int, C.c_int]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_runs_f32_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, c_i64, vp]),

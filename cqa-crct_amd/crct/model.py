@@ -109,6 +109,12 @@ class CrctModel(nn.Module):
         self.fp8_backward = self.fp8 and bool(params.get("fp8_backward", True))
         # ... and the FFN weight gradients from the same fp8 copies (params['fp8_wgrad'] = False: bf16 weight gradients)
         self.fp8_wgrad = self.fp8_backward and bool(params.get("fp8_wgrad", True))
+        # params['fp8_forward'] = False (round 4): the forward GEMMs stay on the bf16 operands -- the producers still write the e4m3 /
+        # scale state the fp8 BACKWARD GEMMs read (the engine's calibration form of the forward, CrctStepCfg.fp8 = 2, kept on).  What
+        # costs an fp8 step its gradient fidelity is the e4m3 rounding of the FORWARD (oracle emulation, tools/lab/mx_emulation.py:
+        # median gradient cosine 0.90 forward-only, 0.88 with everything; block scaling does not change it), while fp8 data and weight
+        # gradients behind an unrounded forward cost ~0.01: this mode keeps most of the speed (backward is 2/3 of the GEMM work).
+        self.fp8_forward = bool(params.get("fp8_forward", True)) if params else True
         self._fp8 = None
         self._entries = {e.name: e for e in self.table}
         self._build_tree()
@@ -427,6 +433,8 @@ class CrctModel(nn.Module):
                 self._engine.set_site_policy(**pol)
             if getattr(self, "prefetch_workgroups", None) is not None:
                 L.check(self._engine.lib.crct_engine_set_prefetch(self._engine.handle, int(self.prefetch_workgroups)), "set_prefetch")
+            if getattr(self, "wgrad_defer_sim", 0):               # developer timing experiment (bench.py --wgrad-defer-sim)
+                L.check(self._engine.lib.crct_engine_set_wgrad_defer_sim(self._engine.handle, int(self.wgrad_defer_sim)), "set_wgrad_defer_sim")
             mode = getattr(self, "stream_mode", None)             # (use_visual_stream, use_wgrad_streams) of crct_engine_set_streams
             if mode is not None:
                 L.check(self._engine.lib.crct_engine_set_streams(self._engine.handle, int(mode[0]), int(mode[1])), "set_streams")
@@ -567,6 +575,8 @@ class CrctModel(nn.Module):
             if self.training or not self._fp8.get("scaled"):
                 self._fp8_update_act_scales()          # delayed scaling: this pass quantises with the previous pass's amax
                 self._fp8["scaled"] = True
+            if not self.fp8_forward:
+                step["fp8_mode"] = 2                   # bf16 forward GEMMs; the e4m3 copies / maxima for the fp8 backward are still written
         if train_branch and torch.is_grad_enabled():
             loss, nsp, reg_loss, logits, reg, stats = _StepFn.apply(self._anchor, self, tensors, step)
         else:

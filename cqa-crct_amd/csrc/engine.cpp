@@ -142,6 +142,7 @@ struct crct_engine {
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
+  int defer_sim = 0;                   // timing experiment (crct_engine_set_wgrad_defer_sim): see Run::flush_wgrads
   int prefetch_wgs = 0;                // workgroups of the weight prefetch one schedule step ahead (crct_engine_set_prefetch).  OFF: measured 7.79-8.04 vs 7.62-7.65 ms
                                        // per step (the lab gain of 2.4 us per GEMM does not survive in the step)
   bool one_wgrad_stream = false;       // both data streams' weight gradients on ONE side stream (frees a hardware queue for the exchange)
@@ -494,8 +495,13 @@ struct Run {
     for (const FinJob& f : pending_fin)
       if (!rc) fail(crct_layernorm_bwd_finalize(f.part, f.dg, f.db, f.dlb, f.M, f.H, 1, sw));
     pending_fin.clear();
-    for (size_t i = 0; i < pending.size() && !rc; i += 8)
-      fail(crct_gemm_bf16_grouped(pending.data() + i, (int)std::min<size_t>(8, pending.size() - i), sw));
+    // defer_sim (crct_engine_set_wgrad_defer_sim, TIMING ONLY, wrong gradients): what would a deferral of the co-attention-phase
+    // layers' weight gradients into the text-only tail of backward buy?  Their grouped launches are dropped where they are and the
+    // tail layers' groups are launched (1 + defer_sim) times instead -- the same amount of side-stream work, moved.
+    const int reps = (e->defer_sim > 0 && c->training) ? (phase == 1 ? 0 : 1 + e->defer_sim) : 1;
+    for (int rep = 0; rep < reps; ++rep)
+      for (size_t i = 0; i < pending.size() && !rc; i += 8)
+        fail(crct_gemm_bf16_grouped(pending.data() + i, (int)std::min<size_t>(8, pending.size() - i), sw));
     pending.clear();
     for (size_t i = 0; i < pending_f8.size() && !rc; i += 8)
       fail(crct_gemm_bf16_grouped(pending_f8.data() + i, (int)std::min<size_t>(8, pending_f8.size() - i), sw));
@@ -1563,6 +1569,12 @@ extern "C" crct_stream_t crct_engine_aux_stream(crct_engine_t* e, crct_stream_t 
   if (ensure_streams(e, (hipStream_t)main_stream)) return nullptr;
   if (queue_classes) *queue_classes = e->queue_classes;
   return e->aux;
+}
+
+extern "C" int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps) {
+  if (!e || extra_reps < 0 || extra_reps > 8) return 1;
+  e->defer_sim = extra_reps;
+  return 0;
 }
 
 extern "C" int crct_engine_set_prefetch(crct_engine_t* e, int workgroups) {

@@ -221,12 +221,18 @@ __device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int
   return true;
 }
 
+}  // namespace
+int g_crct_lab_band_rows = 0;
+extern "C" int crct_lab_xcd_band(int rows_per_band) { g_crct_lab_band_rows = rows_per_band > 0 ? rows_per_band : 0; return 0; }
+namespace {
+
 inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid) {
   TileMap t;
   t.tiles_m = (M + BM - 1) / BM; t.tiles_n = (N + BN - 1) / BN;
   long best = -1;
   int bgm = 1;
-  for (int gm = 1; gm <= 8; gm *= 2) {
+  const bool banded = g_crct_lab_band_rows > 0 && g_crct_lab_band_rows % BM == 0 && (long)g_crct_lab_band_rows * 8 >= M;
+  for (int gm = banded ? 8 : 1; gm <= 8; gm *= 2) {
     const int gn = 8 / gm;
     const int rm = (t.tiles_m + gm - 1) / gm, rn = (t.tiles_n + gn - 1) / gn;
     // panel rows held per XCD, plus a penalty for padded (idle) blocks
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(const CrctGem
 // (what PM = 1 of the plain kernel could not deliver while the same waves also had to issue the DMA).  A stage is then free one
 // barrier earlier, the ring holds all NS tiles at the start and the loaders keep NS - 1 in flight.
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE = false>
-__device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int tile_m, const int tile_n) {
+__device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg = 0) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN, NTH = (NW + NL) * 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NPA = A_BYTES / 1024, NPB = B_BYTES / 1024;
@@ -994,7 +1000,7 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt >= 1) {
-          if (kt - 1 + NS < nk) issue(kt - 1 + NS, st_next);
+          if (kt - 1 + NS < nk && !(lab_bits(dbg) & 2)) issue(kt - 1 + NS, st_next);
           st_next = st_next + 1 == NS ? 0 : st_next + 1;
         }
       }
@@ -1010,7 +1016,7 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
+      if (kt + NS - 1 < nk && !(lab_bits(dbg) & 2)) issue(kt + NS - 1, st_next);
       st_next = st_next + 1 == NS ? 0 : st_next + 1;
     }
     }
@@ -1078,6 +1084,7 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
     for (int kt = 0; kt < nk; ++kt) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (lab_bits(dbg) & 32) continue;        // lab ablation: the compute waves only keep the barrier count (pure fill time)
       bf8_t fm[2][WTM], fn[2][WTN];
       uint32_t ca[FragBase<TA, TM, WTM>::NB], cb[FragBase<TB, TN, WTN>::NB];
       fbA.at(smem_base + st * STAGE, ca);
@@ -1140,7 +1147,7 @@ template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool
 __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ldr_kernel(const CrctGemmArgs g, const TileMap tmap) {
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
-  gemm_ldr_body<TM, TN, WM, WN, TA, TB, NS, NL, PIPE>(g, tile_m, tile_n);
+  gemm_ldr_body<TM, TN, WM, WN, TA, TB, NS, NL, PIPE>(g, tile_m, tile_n, tmap.dbg);
 }
 
 // ====================================================================================== fp8 forward (BASELINE configs[4])
@@ -1518,9 +1525,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
     if (group_pick(ga, bid, pi, tm, tn)) {
       CrctGemmArgs g = ga.p[pi];
       g.ta = TA; g.tb = TB;
-      gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tm, tn, 0);
+      gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tm, tn, lab_bits(ga.map[pi].dbg));
     }
     if (bid + (int)gridDim.x < total) __syncthreads();      // the next tile's first DMA reuses the ring the epilogue has just read
+  }
+}
+
+// the same with the loader-wave body (configurations 48 / 53 / 58 / 59: 128 x 128 tiles)
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE>
+__global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_group_ldr_kernel(const GroupArgs ga) {
+  const int total = ga.concat ? 8 * ga.per_xcd : ga.tile_begin[ga.n];
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+    int pi, tm, tn;
+    if (group_pick(ga, bid, pi, tm, tn)) {
+      CrctGemmArgs g = ga.p[pi];
+      g.ta = TA; g.tb = TB;
+      gemm_ldr_body<TM, TN, WM, WN, TA, TB, NS, NL, PIPE>(g, tm, tn);
+    }
+    if (bid + (int)gridDim.x < total) __syncthreads();
   }
 }
 
@@ -1528,6 +1550,12 @@ static int g_group_max_wgs = 0;        // crct_gemm_group_max_workgroups: 0 = on
 static int g_group_wgrad_cfg = 4;      // configuration of a layer's grouped weight gradients: 4 = 128 x 128 plain loop, 39 = the same tile, two-phase loop
 static int g_group_concat = 0;         // crct_gemm_group_concat: grouped weight gradients as ONE tile list over the XCDs (GroupArgs.concat); measured: no gain
 extern "C" int crct_gemm_group_concat(int on) { g_group_concat = on != 0; return 0; }
+// configuration of the grouped weight-gradient launches (4 / 39 / 48 / 53 / 58 / 59: all 128 x 128 tiles); returns the previous one
+extern "C" int crct_gemm_group_wgrad_config(int cfg) {
+  const int old = g_group_wgrad_cfg;
+  if (cfg == 4 || cfg == 39 || cfg == 48 || cfg == 53 || cfg == 58 || cfg == 59) g_group_wgrad_cfg = cfg;
+  return old;
+}
 extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
 
 template <int TM, int TN, int WM, int WN, int NS, int PM = 0>
@@ -1541,7 +1569,6 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
     ga.tile_begin[i] = total;
     int grid = 0;
     ga.map[i] = make_tile_map(g.M, g.N, BM, BN, &grid);
-    ga.map[i].dbg = 0;
     total += grid;
     ga.p[i] = g;
   }
@@ -1565,6 +1592,43 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   else if (!gs[0].ta && !gs[0].tb) CRCT_LAUNCH_GROUP(false, false);
   else return hipErrorInvalidValue;
 #undef CRCT_LAUNCH_GROUP
+  return hipGetLastError();
+}
+
+template <int TM, int TN, int WM, int WN, int NS, int NL, bool PIPE>
+hipError_t launch_group_ldr(const CrctGemmArgs* gs, int n, hipStream_t s) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  GroupArgs ga = {};
+  ga.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    ga.tile_begin[i] = total;
+    int grid = 0;
+    ga.map[i] = make_tile_map(gs[i].M, gs[i].N, BM, BN, &grid);
+    ga.map[i].dbg = 0;
+    total += grid;
+    ga.p[i] = gs[i];
+  }
+  ga.tile_begin[n] = total;
+  if (gs[0].ta && g_group_concat) group_concat(ga, &total);
+  const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_GROUP_LDR(TA_, TB_)                                                                                    \
+  do {                                                                                                                     \
+    auto kern = gemm_group_ldr_kernel<TM, TN, WM, WN, TA_, TB_, NS, NL, PIPE>;                                             \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3((WM * WN + NL) * 64), lds, s, ga); \
+  } while (0)
+  if (gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP_LDR(true, true);
+  else if (!gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP_LDR(false, true);
+  else if (!gs[0].ta && !gs[0].tb) CRCT_LAUNCH_GROUP_LDR(false, false);
+  else return hipErrorInvalidValue;
+#undef CRCT_LAUNCH_GROUP_LDR
   return hipGetLastError();
 }
 
@@ -1739,18 +1803,31 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 // commit 11e1801).  Stand-alone with cold weights it won 10-17 % on several shapes (profiles/r2_gemm_lab_cold.txt), in the
 // step EVERY class lost 0.1-0.4 ms (profiles/r2_gemm_flex_step_ab.txt): its 108-160 KB of LDS allow one workgroup per CU,
 // so the kernels of the other internal streams can no longer share the CUs.  The 48-72 KB configurations below stay.
-enum { CLS_TW, CLS_TN, CLS_TNL, CLS_VW, CLS_VM, CLS_VML, CLS_COUNT };
-static const int* class_table() {
-  static const int tab[CLS_COUNT] = {12, 12, 15, 12, 12, 4};      // vml: 128x128, 3 stages (long context 12.33 -> 12.19 ms, configs[1] 7.61 -> 7.56)
-  return tab;
+// Round 4: the classes are keyed by the ROW COUNT of the output in three buckets -- S (<= 2000 rows: the text stream of configs[1]),
+// M (<= 4000: the visual stream of configs[1], the text stream of the long-context configs[3]), L (> 4000: its visual stream) --
+// times the three column / contraction classes above (w: N >= 2304, n: N <= 1024 and K <= 1024, nl: N <= 1024 and K > 1024).
+// Round 3 classified by M <= 2000 alone, so the long-context text GEMMs (2560 rows) ran with the visual stream's choices and
+// its 6400-row visual GEMMs with tiles picked for 2880 rows.  The table is filled from in-step sweeps (bench.py --class-policy,
+// profiles/r4_longctx_class_sweep.txt); crct_gemm_class_config overrides an entry for such a sweep.
+enum { CLS_W, CLS_N, CLS_NL, CLS_PER_BUCKET };
+enum { MB_S, MB_M, MB_L, MB_COUNT };
+constexpr int CLS_COUNT = MB_COUNT * CLS_PER_BUCKET;
+static int g_class_table[CLS_COUNT] = {12, 12, 15,      // S: text rows of configs[1]
+                                       12, 12, 4,       // M: visual rows of configs[1] (vml: 128x128, 3 stages: 7.61 -> 7.56 ms), long-context text rows
+                                       12, 12, 4};      // L: long-context visual rows
+extern "C" int crct_gemm_class_config(int cls, int cfg) {
+  if (cls < 0 || cls >= CLS_COUNT) return -1;
+  const int old = g_class_table[cls];
+  if (cfg >= 0 && cfg <= 65) g_class_table[cls] = cfg;
+  return old;
 }
 static int pick_pipe_config(const CrctGemmArgs& g) {
   if (g.M <= 96) return 3;                                          // head / regressor GEMMs: B rows
   if (g.ta) return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 9;      // single weight gradient (grouped ones: crct_gemm_launch_grouped)
-  const bool text = g.M <= 2000, wide = g.N >= 2304, longk = g.K > 1024;
-  const int cls = text ? (wide ? CLS_TW : (longk ? CLS_TNL : CLS_TN)) : (wide ? CLS_VW : (longk ? CLS_VML : CLS_VM));
-  const int t = class_table()[cls];
-  return (t < 0 || t > 15) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
+  const int mb = g.M <= 2000 ? MB_S : (g.M <= 4000 ? MB_M : MB_L);
+  const bool wide = g.N >= 2304, longk = g.K > 1024;
+  const int t = g_class_table[mb * CLS_PER_BUCKET + (wide ? CLS_W : (longk ? CLS_NL : CLS_N))];
+  return (t < 0 || t > 65) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
 }
 
 // ---- optional live profiling: begin / end stamps of every GEMM kernel, on the launch stream ----------
@@ -1772,6 +1849,9 @@ inline int kind_of(const CrctGemmArgs& g) { return g.ta ? CRCT_KIND_WGRAD : ((g.
 inline int site_of(const CrctGemmArgs& g) { return (g.site > 0 && g.site < CRCT_SITE_COUNT) ? g.site : 0; }
 
 ProfSlot* prof_begin(int variant, const CrctGemmArgs* gs, int n) {
+#ifdef CRCT_NO_PROF_HOOKS      // A/B build (tools/ab_lib.sh): the hooks compiled out, to show what they cost a launch when they are off
+  return nullptr;
+#endif
   if (!g_prof.on) return nullptr;
   if (g_prof.used == g_prof.slots.size()) {
     ProfSlot ns;
@@ -1792,6 +1872,9 @@ ProfSlot* prof_begin(int variant, const CrctGemmArgs* gs, int n) {
   return slot;
 }
 void log_launch(const CrctGemmArgs* gs, int n, int cfg, int grid) {
+#ifdef CRCT_NO_PROF_HOOKS
+  return;
+#endif
   if (!g_prof.log_on) return;
   CrctLaunchRec r;
   r.site = n == 1 ? site_of(gs[0]) : -1; r.kind = kind_of(gs[0]); r.M = gs[0].M; r.N = gs[0].N; r.K = gs[0].K;
@@ -1971,12 +2054,10 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 57: e = launch_ldr<4, 2, 4, 2, 3, 4, true>(g, s); break;  // 128x64, 8 + 4 waves, 3 stages
       case 58: e = launch_ldr<4, 4, 2, 2, 3, 4, true>(g, s); break;  // 128x128, 4 (64x64 wave tiles) + 4 waves, 3 stages (96 KB)
       case 59: e = launch_ldr<4, 4, 2, 4, 3, 4, true>(g, s); break;  // 128x128, 8 (64x32) + 4 waves, 3 stages
-      case 60: e = launch_ldr<8, 4, 4, 2, 3, 4, true>(g, s); break;  // 256x128, 8 (64x64) + 4 waves, 3 stages (144 KB)
       case 61: e = launch_ldr<4, 2, 2, 2, 4, 2, true>(g, s); break;  // 128x64, 4 + 2 waves, 4 stages (96 KB)
       case 62: e = launch_ldr<4, 4, 2, 2, 2, 4, true>(g, s); break;  // 128x128, 4 + 4 waves, 2 stages (64 KB: two per CU)
       case 63: e = launch_ldr<4, 2, 2, 2, 3, 4, true>(g, s); break;  // 128x64, 4 + 4 waves, 3 stages
       case 64: e = launch_ldr<4, 2, 2, 2, 2, 2, true>(g, s); break;  // 128x64, 4 + 2 waves, 2 stages (48 KB: three per CU)
-      case 65: e = launch_ldr<8, 4, 4, 2, 2, 4, true>(g, s); break;  // 256x128, 8 + 4 waves, 2 stages (96 KB)
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
   } else {
@@ -2021,9 +2102,19 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
   }
   // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages; CrctGemmArgs.tile of the first
   // problem may pick the other one (crct_engine_set_site_policy: A/B runs)
-  const int cfg = (gs[0].tile == 4 || gs[0].tile == 9 || gs[0].tile == 39) ? gs[0].tile : (gs[0].ta ? g_group_wgrad_cfg : 9);
+  const int t0 = gs[0].tile;
+  const int cfg = (t0 == 4 || t0 == 9 || t0 == 39 || t0 == 48 || t0 == 53 || t0 == 58 || t0 == 59) ? t0 : (gs[0].ta ? g_group_wgrad_cfg : 9);
   prof_begin(cfg * 3 + kind_of(gs[0]), gs, n);
-  const hipError_t e = cfg == 9 ? launch_group<4, 4, 2, 4, 2>(gs, n, s) : (cfg == 39 ? launch_group<4, 4, 2, 4, 3, 2>(gs, n, s) : launch_group<4, 4, 2, 4, 3>(gs, n, s));
+  hipError_t e;
+  switch (cfg) {
+    case 9: e = launch_group<4, 4, 2, 4, 2>(gs, n, s); break;
+    case 39: e = launch_group<4, 4, 2, 4, 3, 2>(gs, n, s); break;
+    case 48: e = launch_group_ldr<4, 4, 2, 4, 3, 4, false>(gs, n, s); break;
+    case 53: e = launch_group_ldr<4, 4, 2, 2, 3, 4, false>(gs, n, s); break;
+    case 58: e = launch_group_ldr<4, 4, 2, 2, 3, 4, true>(gs, n, s); break;
+    case 59: e = launch_group_ldr<4, 4, 2, 4, 3, 4, true>(gs, n, s); break;
+    default: e = launch_group<4, 4, 2, 4, 3>(gs, n, s); break;
+  }
   g_time_start = g_time_stop = nullptr;
   log_launch(gs, n, cfg, 0);
   return e;

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
 struct LnFwdP {
   const bf16_t* x; const float* gamma; const float* beta; bf16_t* y; float* mean_o; float* rstd_o; int M, H; float eps;
   uint32_t thr; float scale; uint32_t site; uint64_t seed; uint8_t* q_out; const float* q_scale; float* q_amax;
+  int band;      // lab hook (crct_lab_xcd_band): > 0 = rows per XCD band, workgroup b serves rows of band b % 8
 };
 template <int NCH>
 __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, const int nblk) {
@@ -556,7 +557,15 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, cons
   row_load_f32(b, a.beta, H, lane);
   const float qs = a.q_out ? a.q_scale[0] : 0.f;
   float amax = 0.f;
-  for (long row = (long)blk * ROWS_PER_BLOCK + wave; row < M; row += (long)nblk * ROWS_PER_BLOCK) {
+  long row0 = (long)blk * ROWS_PER_BLOCK + wave, stride = (long)nblk * ROWS_PER_BLOCK, row_end = M;
+  if (a.band > 0) {            // band x = blk % 8 is walked by the workgroups blk = x, x + 8, ...
+    const int x = blk & 7, j = blk >> 3, per = nblk >> 3;
+    row0 = (long)x * a.band + (long)j * ROWS_PER_BLOCK + wave;
+    stride = (long)(per > 0 ? per : 1) * ROWS_PER_BLOCK;
+    row_end = (long)(x + 1) * a.band < M ? (long)(x + 1) * a.band : M;
+    if (j >= per) row0 = row_end;
+  }
+  for (long row = row0; row < row_end; row += stride) {
     Row<NCH> r;
     row_load_bf16(r, a.x + row * H, H, lane);
     float mean, rstd;
@@ -1085,7 +1094,8 @@ extern "C" {
 
 static LnFwdP ln_fwd_problem(const CrctLnFwdArgs& a) {
   return LnFwdP{(const bf16_t*)a.x, a.gamma, a.beta, (bf16_t*)a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale,
-                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax};
+                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax,
+                (g_crct_lab_band_rows > 0 && (long)g_crct_lab_band_rows * 8 >= a.M) ? g_crct_lab_band_rows : 0};
 }
 static int ln_fwd_check(const CrctLnFwdArgs& a) {
   CRCT_REQUIRE(a.H % 8 == 0 && a.H > 0, "layernorm: H=%d must be a positive multiple of 8", a.H);

@@ -111,6 +111,22 @@ int crct_gemm_group_concat(int on);
 /* Test hook: on != 0 makes crct_embed_text_bwd launch the position / type sums and the word-table scatter as two kernels one after
  * the other instead of one merged launch (identical results; tests/test_kernels_gpu.py, bench.py --embed-scatter-split). */
 void crct_embed_scatter_split(int on);
+/* Kernel configuration of the grouped weight-gradient launches of the step (all 128 x 128 tiles; see gemm.hip): 4 = plain loop,
+ * 39 = two-phase loop, 48 / 53 = loader waves (8 + 4 / 4 + 4 waves), 58 / 59 = loader waves + two fragment register sets.  Returns
+ * the previous value; other values are ignored. */
+int crct_gemm_group_wgrad_config(int cfg);
+
+/* Lab hook (tools/lab/band_lab.py): rows per XCD band, 0 = off (the product).  With a band the GEMM tile maps
+ * give XCD x (= block % 8) the row tiles of band x and every column tile, and crct_layernorm_fwd serves band b % 8 from workgroup
+ * b, so that a LayerNorm -> GEMM -> GEMM chain produces and consumes an activation row on ONE XCD.  Results do not change. */
+int crct_lab_xcd_band(int rows_per_band);
+
+/* Kernel configuration of one shape class of the forward / data-gradient GEMMs: cls = 3 * rows_bucket + column_class with
+ * rows_bucket 0: M <= 2000, 1: M <= 4000, 2: M > 4000 and column_class 0: N >= 2304 (wide), 1: N <= 1024 with K <= 1024, 2: N <= 1024
+ * with K > 1024 (gemm.hip, pick_pipe_config).  cfg < 0 only reads.  Returns the previous configuration id (-1: bad class).  For
+ * in-step sweeps (bench.py --class-policy); per-site overrides: crct_engine_set_site_policy. */
+int crct_gemm_class_config(int cls, int cfg);
+
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 
@@ -592,6 +608,11 @@ crct_stream_t crct_engine_aux_stream(crct_engine_t*, crct_stream_t main_stream, 
  * (crct_gemm_bf16_grouped with n = 2, crct_layernorm_*_pair) instead of running on two concurrent streams.  Results are
  * bit-identical in both modes.  The fp8 forward always uses the two-stream schedule. */
 int crct_engine_set_pairing(crct_engine_t*, int on);
+/* TIMING EXPERIMENT ONLY (wrong gradients; bench.py --wgrad-defer-sim): the grouped weight-gradient launches of the layers that
+ * run beside the visual stream are dropped and those of the text-only tail of backward are launched 1 + extra_reps times -- the
+ * side-stream work of a deferral policy without its buffers, to price it before building it.  0 = off. */
+int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps);
+
 /* Weight prefetch: while a schedule step runs, the bf16 weights of the NEXT step (forward) / the previous one (backward) are
  * touched by `workgroups` workgroups on a weight-gradient side stream, so that the GEMMs find them in the Infinity Cache instead
  * of in HBM (crct_prefetch).  0 = off.  Only with side streams; reads only -- results are identical. */

@@ -50,12 +50,43 @@ FP8_BWD_EMULATION = False
 # Switched on by ``FP8_WGRAD_EMULATION = True`` (with the two above).
 FP8_WGRAD_EMULATION = False
 
-def _fp8_round(t):
+# Block-scaled ("MX") variant of the same emulation (round 4, diagnostic): every operand of an fp8 GEMM is OCP e4m3 with one power-of-two
+# (e8m0) scale per 32 consecutive elements ALONG THE CONTRACTION INDEX -- the operand format of gfx950's
+# v_mfma_scale_f32_16x16x128_f8f6f4 -- gradients included (e4m3, not e5m2: the block scale carries the range).  ``FP8_MX = True``
+# switches _Fp8Linear's roundings over; tools/lab/mx_emulation.py prices it against the per-tensor recipe.
+FP8_MX = False
+MX_BLOCK = 32
+# ... and of the product's params['fp8_forward'] = False mode (round 4): the forward GEMMs multiply the unquantised operands, only the
+# backward GEMMs (data and / or weight gradients, as the two flags above say) read fp8 roundings.  ``FP8_FWD_BF16 = True``.
+FP8_FWD_BF16 = False
+
+
+def _mx_round(t, dim):
+    """e4m3 rounding of t with an e8m0 scale per MX_BLOCK elements along ``dim`` (scale = 2^ceil(log2(amax / 448)))."""
+    x = t.movedim(dim, -1)
+    shape = x.shape
+    n = shape[-1]
+    pad = (-n) % MX_BLOCK
+    if pad:
+        x = F.pad(x, (0, pad))
+    xb = x.reshape(*x.shape[:-1], -1, MX_BLOCK)
+    amax = xb.detach().abs().amax(-1, keepdim=True).clamp_min(2.0 ** -126)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    q = (xb / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype) * scale
+    q = q.reshape(*x.shape)[..., :n].reshape(shape)
+    return q.movedim(-1, dim)
+
+
+def _fp8_round(t, dim=-1):
+    if FP8_MX:
+        return _mx_round(t, dim)
     s = 448.0 / float(t.detach().abs().max().clamp_min(1e-30))
     return (t * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype) / s
 
 
-def _bf8_round(t):
+def _bf8_round(t, dim=-1):
+    if FP8_MX:
+        return _mx_round(t, dim)
     s = 57344.0 / float(t.detach().abs().max().clamp_min(1e-30))
     return (t * s).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(t.dtype) / s
 
@@ -74,10 +105,13 @@ class _Fp8Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        # (block-scaled mode: the blocks run along each GEMM's own contraction index -- ``out`` for the data gradient, tokens for the
+        # weight gradient -- so the two backward GEMMs read different roundings of gy)
         gq = _bf8_round(gy) if (ctx.bwd_q or ctx.wg_q) else None
-        gx = (gq @ _fp8_round(w)) if ctx.bwd_q else gy @ w
+        gx = (gq @ _fp8_round(w, 0)) if ctx.bwd_q else gy @ w
         if ctx.wg_q:
-            gw = gq.reshape(-1, gy.shape[-1]).t() @ _fp8_round(x).reshape(-1, x.shape[-1])
+            g2 = gy.reshape(-1, gy.shape[-1])
+            gw = (_bf8_round(g2, 0) if FP8_MX else gq.reshape(-1, gy.shape[-1])).t() @ _fp8_round(x.reshape(-1, x.shape[-1]), 0 if FP8_MX else -1)
         else:
             gw = gy.reshape(-1, gy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
         return gx, gw, gy.reshape(-1, gy.shape[-1]).sum(0), None, None, None
@@ -92,10 +126,11 @@ def _fp8_site(w):
 def linear(sd, prefix, x):
     w = sd[prefix + ".weight"]
     if FP8_EMULATION and ".encoder." in prefix:
-        fwd_q = _fp8_site(w)
-        bwd_q = FP8_BWD_EMULATION and fwd_q
+        site = _fp8_site(w)
+        fwd_q = site and not FP8_FWD_BF16
+        bwd_q = FP8_BWD_EMULATION and site
         wg_q = FP8_WGRAD_EMULATION and bwd_q
-        if fwd_q:
+        if site:
             return _Fp8Linear.apply(x, w, sd[prefix + ".bias"], fwd_q, bwd_q, wg_q)
     return F.linear(x, w, sd[prefix + ".bias"])
 

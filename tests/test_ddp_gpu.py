@@ -75,7 +75,9 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     # identical on both ranks, and equal to the mean of the ranks' losses' gradient
     for key in ("g_sync", "g_accum", "g_bf16", "g_materialized", "params_after_step", "stats9_async"):
         assert np.array_equal(r0[key], r1[key]), key
-    assert not np.array_equal(r0["g_bf16_local_fp32"], r1["g_bf16_local_fp32"], equal_nan=True)       # materialize_grads=False after a packed pass: the Linear weights' .grad is NaN, not ...
+    # materialize_grads=False: what the fp32 .grad views hold is the SAME on both ranks (reduced values where backward accumulates in
+    # fp32, NaN for the Linear weights) -- round 3 left each rank's LOCAL gradient there
+    assert np.array_equal(r0["g_bf16_local_fp32"], r1["g_bf16_local_fp32"], equal_nan=True)
     assert np.array_equal(r0["stats9_async"], r0["stats9"])
     mean_loss = 0.5 * (float(r0["loss"][0]) + float(r1["loss"][0]))
     assert abs(mean_loss - float(ref[0])) <= 2e-2 * abs(float(ref[0]))
@@ -111,7 +113,7 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     for r in (r0, r1):
         v, g16 = r["g_views_with_fused_optimizer"][used], r["g_bf16_with_fused_optimizer"][used]
         nan = np.isnan(v)
-        assert 0.90 < nan.mean() < 0.99, nan.mean()                       # the Linear weights are ~95 % of the elements
+        assert 0.80 < nan.mean() < 0.99, nan.mean()                       # the owned Linear weights: ~90 % of the elements (the word table is not one of them)
         assert np.array_equal(v[~nan], g16[~nan])
         assert np.array_equal(g16, r0["g_bf16"][used])                    # same batch, same weights: the same reduced gradient as step (3)
     for e in table:                                                        # NaN exactly on 2-D encoder / head Linear weights, nowhere else
@@ -121,7 +123,7 @@ def test_two_rank_gradient_exchange_matches_oracle(case, ddp_workers):
     # after a packed (non-direct) pass with materialize_grads=False the owned views are NaN as well, on both ranks alike
     for r in (r0, r1):
         loc = r["g_bf16_local_fp32"][used]
-        assert np.isnan(loc).mean() > 0.90 and np.array_equal(loc[~np.isnan(loc)], r["g_bf16"][used][~np.isnan(loc)])
+        assert np.isnan(loc).mean() > 0.80 and np.array_equal(loc[~np.isnan(loc)], r["g_bf16"][used][~np.isnan(loc)])
     # weight gradients written into the communication buffer by the GEMMs themselves (after a lazy clear): the same bits
     assert int(r0["packed_runs_only_after_full_clear"][0]) == 0 and int(r0["packed_runs_only_after_lazy_clear"][0]) == 1
     assert np.array_equal(r0["g_bf16_direct"][used], r0["g_bf16"][used]) and np.array_equal(r1["g_bf16_direct"][used], r0["g_bf16_direct"][used])

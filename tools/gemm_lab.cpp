@@ -33,7 +33,13 @@ int main(int argc, char** argv) {
       {"t.ffn_up wg ", 3072, 768, 1600, 1, 1},  {"t.ffn_dn wg ", 768, 3072, 1600, 1, 1},  {"v.qkv wg    ", 3072, 1024, 2880, 1, 1},
       {"v.ffn wg    ", 1024, 1024, 2880, 1, 1}, {"t.qkv wg    ", 2304, 768, 1600, 1, 1},  {"big 4096^3  ", 4096, 4096, 4096, 0, 0},
       {"lc t.up fwd ", 2560, 3072, 768, 0, 0},  {"lc v.qkv fwd", 6400, 3072, 1024, 0, 0}, {"c.qkv2 fwd  ", 1600, 3072, 768, 0, 0},
-      {"c.dense2 fwd", 1600, 768, 1024, 0, 0},  {"img emb fwd ", 2880, 1024, 2048, 0, 0}};
+      {"c.dense2 fwd", 1600, 768, 1024, 0, 0},  {"img emb fwd ", 2880, 1024, 2048, 0, 0},
+      // long context (BASELINE configs[3]: B = 64, 100 visual elements, 40 tokens: 2560 text rows, 6400 visual rows)
+      {"lc t.qkv fwd", 2560, 2304, 768, 0, 0},  {"lc t.dn fwd ", 2560, 768, 3072, 0, 0},  {"lc t.out fwd", 2560, 768, 768, 0, 0},
+      {"lc v.ffn fwd", 6400, 1024, 1024, 0, 0}, {"lc t.up dg  ", 2560, 768, 3072, 0, 1},  {"lc t.dn dg  ", 2560, 3072, 768, 0, 1},
+      {"lc v.qkv dg ", 6400, 1024, 3072, 0, 1}, {"lc v.ffn dg ", 6400, 1024, 1024, 0, 1}, {"lc t.qkv dg ", 2560, 768, 2304, 0, 1},
+      {"lc v.qkv wg ", 3072, 1024, 6400, 1, 1}, {"lc v.ffn wg ", 1024, 1024, 6400, 1, 1}, {"lc t.up wg  ", 3072, 768, 2560, 1, 1},
+      {"lc t.dn wg  ", 768, 3072, 2560, 1, 1},  {"lc c.qkv2 fw", 2560, 3072, 768, 0, 0},  {"lc img emb  ", 6400, 1024, 2048, 0, 0}};
   size_t maxel = (size_t)6400 * 4096;
   unsigned short *A, *B;
   void *C, *Cref;
