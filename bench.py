@@ -61,8 +61,8 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               42: "pp256x128w8s3", 43: "pp64x128w8s3", 44: "pp256x64w8s3", 45: "pp128x128w8s4", 46: "ldr128x64w8+4s3", 47: "ldr128x64w8+4s2",
               48: "ldr128x128w8+4s3", 49: "ldr128x128w8+4s2", 50: "ldr256x128w8+4s3", 51: "ldr128x64w8+4s4", 52: "ldr128x64w8+2s3",
               53: "ldr128x128w4+4s3", 54: "ldr128x64w4+2s3", 55: "ldr256x128w8+4s2", 56: "ldrp128x64w4+2s3", 57: "ldrp128x64w8+4s3",
-              58: "ldrp128x128w4+4s3", 59: "ldrp128x128w8+4s3", 60: "ldrp256x128w8+4s3", 61: "ldrp128x64w4+2s4", 62: "ldrp128x128w4+4s2",
-              63: "ldrp128x64w4+4s3", 64: "ldrp128x64w4+2s2", 65: "ldrp256x128w8+4s2"}
+              58: "ldrp128x128w4+4s3", 59: "ldrp128x128w8+4s3", 61: "ldrp128x64w4+2s4", 62: "ldrp128x128w4+4s2",
+              63: "ldrp128x64w4+4s3", 64: "ldrp128x64w4+2s2", 60: "ldr256x128w4+4s3", 65: "ldr256x128w4+4s2"}
 KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
@@ -116,6 +116,8 @@ def parse():
     ap.add_argument("--adamw-wide-first", type=int, default=-1, help="developer A/B: how many of the first overlapped AdamW launches run unthrottled")
     ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
+    ap.add_argument("--fp8-plain-mfma", action="store_true", help="developer A/B (--dtype fp8): the round-3 fp8 GEMMs (four v_mfma_f32_16x16x32_fp8 per "
+                    "128-deep K tile) instead of one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (crct_gemm_fp8_scaled_mfma)")
     ap.add_argument("--fp8-bf16-forward", action="store_true", help="--dtype fp8 with bf16 FORWARD GEMMs: only the data and weight gradients run on fp8 "
                     "operands (params['fp8_forward'] = False: the high-fidelity fp8 mode, gradient cosine ~0.97 against fp32 instead of ~0.87)")
     ap.add_argument("--fp8-forward-only", action="store_true", help="--dtype fp8 with the round-2 scope: fp8 forward GEMMs, bf16 backward")
@@ -399,6 +401,8 @@ def main():
         L.load().crct_gemm_group_concat(a.wgrad_concat)
     if a.wgrad_cfg >= 0:
         L.load().crct_gemm_group_wgrad_config(a.wgrad_cfg)
+    if a.fp8_plain_mfma:
+        L.load().crct_gemm_fp8_scaled_mfma(0)
     for item in filter(None, a.class_policy.split(",")):
         name, cfg_id = item.split("=")
         L.load().crct_gemm_class_config(L.CLASS_NAMES.index(name), int(cfg_id))
@@ -586,7 +590,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "CRCT fwd+loss+bwd+AdamW, vilbert.json (v_feature_size=%d), batch %d/GPU, %d visual elems x %d-d, "
                                       "%d text tokens, dropout 0.1, L1 regression loss%s" % (a.feat, a.batch, a.vis, a.feat, a.tokens,
-                                      ("; bf16 forward, fp8 backward: data gradient e5m2 x e4m3, weight gradient e5m2 x e4m3 of every encoder Linear" if a.fp8_bf16_forward else
+                                      ("; bf16 forward and weight gradients, fp8 data gradients (e5m2 x e4m3) of every encoder Linear" if (a.fp8_bf16_forward and a.fp8_bf16_wgrad) else
+                                       "; bf16 forward, fp8 backward: data gradient e5m2 x e4m3, weight gradient e5m2 x e4m3 of every encoder Linear" if a.fp8_bf16_forward else
                                        "; fp8 (e4m3) forward GEMMs of every encoder Linear, bf16 backward" if a.fp8_forward_only else
                                        "; every encoder Linear in fp8: forward e4m3 x e4m3, data gradient e5m2 x e4m3" +
                                        (", bf16 weight gradients" if a.fp8_bf16_wgrad else ", weight gradient e5m2 x e4m3"))

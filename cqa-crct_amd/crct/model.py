@@ -41,7 +41,9 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, tensors, step):
-        model._engine.forward(model._flat_p, model._flat_b16, tensors, step)
+        # (fp8 data gradients only: the forward pass is the plain bf16 one -- no fp8 state, no copies -- the backward pass gets it)
+        fwd_step = {k: v for k, v in step.items() if k != "fp8"} if step.get("fp8_backward_only") else step
+        model._engine.forward(model._flat_p, model._flat_b16, tensors, fwd_step)
         ctx.model, ctx.tensors, ctx.step = model, tensors, step
         ctx.set_materialize_grads(False)
         logits, reg_all, stats = model._engine.snapshot(tensors["tokens"].shape[0])    # one copy; the engine reuses its buffer
@@ -567,7 +569,14 @@ class CrctModel(nn.Module):
                     seg_events=self._param_events)
         self._param_events = None
         dev = self._flat_p.device
-        if self.fp8:
+        if self.fp8 and not self.fp8_forward and not self.fp8_wgrad:
+            # fp8 DATA GRADIENTS only: nothing of the forward pass is quantised (no e4m3 copies, no activation maxima); the backward
+            # pass multiplies e5m2 gradients (copies written by the backward kernels themselves) with the transposed e4m3 weight shadow
+            step["fp8"] = self._fp8_step_args(eng)
+            step["fp8_backward_only"] = True
+            if not (train_branch and torch.is_grad_enabled()):
+                del step["fp8"]
+        elif self.fp8:
             step["fp8"] = self._fp8_step_args(eng)
             if not self._fp8["calibrated"]:            # first fp8 forward: one dry pass collects every activation amax
                 eng.forward(self._flat_p, self._flat_b16, tensors, dict(step, seg_events=None, fp8_mode=2))      # bf16 GEMMs, maxima only

@@ -91,11 +91,38 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 // ------------------------------------------------------------------ activations
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LEAKY = 3, ACT_TANH = 4 };
 
+// erf-GELU (vilbert.py:111-117) and its derivative.  erf through Abramowitz & Stegun 7.1.26: for z >= 0
+//   erf(z) = 1 - t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z),  |error| <= 1.5e-7
+// -- branch-free, one v_rcp and one v_exp, about a third of the instructions of the library erff (a two-branch minimax polynomial, both
+// branches executed by a wave).  Every element of every FFN passes through it twice per step (123 M forward, 123 M backward at
+// configs[1]), inside GEMM epilogues whose vector instructions share the SIMDs with other kernels' MFMAs.  The results are rounded to
+// bf16 (2^-9 relative): the approximation error is invisible there.  exp(-z^2) with z = x / sqrt(2) is also the Gaussian of the
+// derivative: gelu'(x) = Phi(x) + x phi(x) needs ONE exponential for both terms.  -DCRCT_GELU_LIBM_ERF restores erff (A/B builds).
+__device__ __forceinline__ float erf_as7126_pos(float z, float e) {      // z >= 0, e = exp(-z * z)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  return fmaf(-poly, e, 1.0f);
+}
+#ifdef CRCT_GELU_LIBM_ERF
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float kInvSqrt2Pi = 0.3989422804014327f;
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
+#else
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float er = copysignf(erf_as7126_pos(z, __expf(-z * z)), x);
+  return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float kInvSqrt2Pi = 0.3989422804014327f;
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-z * z);                      // = exp(-x^2 / 2)
+  const float er = copysignf(erf_as7126_pos(z, e), x);
+  return fmaf(x * kInvSqrt2Pi, e, 0.5f * (1.0f + er));
+}
+#endif
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {
     case ACT_GELU: return gelu_erf(x);

@@ -402,8 +402,15 @@ constexpr int epilogue_passes() {
 // NTH: threads that walk the staged tile (default: the WM x WN compute waves; the loader-wave kernels pass their whole workgroup --
 // waves beyond WM x WN hold no accumulators, their wm is >= WM and they never park anything)
 template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING, int NTH = 0>
-__device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
-                                                     int wm, int wn, int lane, int tid) {
+__device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
+                                                     int wm, int wn, int lane, int tid, int dbg = 0) {
+#ifdef CRCT_GEMM_LAB   // lab ablations (tools/lab/step_ablate.sh): 64 = no activation / derivative / dropout arithmetic, 128 = no side inputs or outputs
+  CrctGemmArgs g = g_in;
+  if (dbg & 64) { g.act = ACT_NONE; g.dact_src = nullptr; g.drop_thr = 0; }
+  if (dbg & 128) { g.preact_out = nullptr; g.addend = nullptr; g.bias = nullptr; g.dact_src = nullptr; g.q_out = nullptr; }
+#else
+  const CrctGemmArgs& g = g_in;
+#endif
   constexpr int P = epilogue_passes<BM, BN, WM, RING>();
   static_assert(P >= 1, "staging tile must fit into the operand ring");
   constexpr int R = BM / P;                  // rows staged per pass (WM / P wave rows of the wave grid)
@@ -901,7 +908,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
       }
     }
   }
-  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid, lab_bits(dbg));
 }
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int PM = 0>
@@ -1165,7 +1172,22 @@ __device__ __forceinline__ unsigned f8_src_offset(int slot, int r0, int R, long 
 }
 
 // A_BF8: the A operand (a GRADIENT: the data-gradient GEMMs dx = dy W against the transposed e4m3 weight shadow) is OCP e5m2
-template <int TM, int TN, int WM, int WN, int NS, bool A_BF8 = false>
+// MX (round 4): the whole 128-deep K tile of a 16 x 16 output tile as ONE v_mfma_scale_f32_16x16x128_f8f6f4 with every block scale
+// 2^0 (e8m0 127) -- gfx950's block-scaled instruction used as a plain fp8 MFMA at TWICE the rate of v_mfma_f32_16x16x32_fp8_fp8
+// (32 cycles for K = 128 against 4 x 16; MI355X_MICROARCH.md, Matrix cores).  With 128-byte rows the plain instruction makes this
+// kernel MFMA-bound (512 cycles per K tile and SIMD against a fill floor of 384).  A lane's operand is the 32 bytes it already reads
+// per K tile -- the 16-byte chunks (lane >> 4) and 4 + (lane >> 4) of its row -- for both operands alike, so the products pair the
+// same k as before; only the order of the fp32 additions inside a K tile differs.  Scaling stays per tensor (gemm_epilogue_staged):
+// block scales would not buy fidelity here (EXPERIMENTS.md round 4, item 9).
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v8i_t f8_pair(const bf8_t& lo, const bf8_t& hi) {
+  const v4i_t a = __builtin_bit_cast(v4i_t, lo), b = __builtin_bit_cast(v4i_t, hi);
+  return v8i_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+constexpr int MX_ONE = 0x7F7F7F7F;       // four e8m0 block scales of 2^0
+
+template <int TM, int TN, int WM, int WN, int NS, bool A_BF8 = false, bool MX = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(const CrctGemmArgs g, const TileMap tmap) {
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
@@ -1256,16 +1278,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(const CrctGemmArg
     FB::template read<0>(cb, fn[0]);
     FA::template read<1>(ca, fm[1]);
     FB::template read<1>(cb, fn[1]);
+    if constexpr (MX) {
+      frag_async_wait<0>();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+      }
+#pragma unroll
+      for (int a = 0; a < WTN; ++a) {
+        const v8i_t bn = f8_pair(fn[0][a], fn[1][a]);
+#pragma unroll
+        for (int b = 0; b < WTM; ++b)     // first source = the weight fragment (e4m3), second = the activation (e4m3) / gradient (e5m2) fragment
+          acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bn, f8_pair(fm[0][b], fm[1][b]), acc[a][b], 0, A_BF8 ? 1 : 0, 0, MX_ONE, 0, MX_ONE);
+      }
+    } else {
     frag_async_wait<(N_HALF <= 15 ? N_HALF : 0)>();
     multiply(0, fm, fn);
     asm volatile("" : "+v"(acc[WTN - 1][WTM - 1]));     // keep the first half's MFMAs in front of the second wait
     frag_async_wait<0>();
     multiply(1, fm, fn);
+    }
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
   }
   gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
+
+static int g_f8_mx = 1;      // crct_gemm_fp8_scaled_mfma: the fp8 GEMMs on v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) instead of 16x16x32
+}  // namespace
+extern "C" int crct_gemm_fp8_scaled_mfma(int on) { const int old = g_f8_mx; if (on >= 0) g_f8_mx = on != 0; return old; }
+namespace {
 
 template <int TM, int TN, int WM, int WN, int NS>
 hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
@@ -1274,9 +1319,9 @@ hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
   const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   hipError_t e = hipSuccess;
-#define CRCT_LAUNCH_F8(BF8_)                                                                                               \
+#define CRCT_LAUNCH_F8(BF8_, MX_)                                                                                          \
   do {                                                                                                                     \
-    auto kern = gemm_f8_kernel<TM, TN, WM, WN, NS, BF8_>;                                                                  \
+    auto kern = gemm_f8_kernel<TM, TN, WM, WN, NS, BF8_, MX_>;                                                             \
     static bool attr_set = false;                                                                                          \
     if (lds > 64 * 1024 && !attr_set) {                                                                                    \
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
@@ -1285,8 +1330,8 @@ hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
     }                                                                                                                      \
     launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                                 \
   } while (0)
-  if (g.fp8 & 2) CRCT_LAUNCH_F8(true);
-  else CRCT_LAUNCH_F8(false);
+  if (g_f8_mx) { if (g.fp8 & 2) CRCT_LAUNCH_F8(true, true); else CRCT_LAUNCH_F8(false, true); }
+  else { if (g.fp8 & 2) CRCT_LAUNCH_F8(true, false); else CRCT_LAUNCH_F8(false, false); }
 #undef CRCT_LAUNCH_F8
   return hipGetLastError();
 }
@@ -1332,7 +1377,7 @@ __device__ __forceinline__ long lds_read_tr8_imm(uint32_t a) {
 }
 __device__ __forceinline__ void frag_async_use(long& f) { asm volatile("" : "+v"(f)); }
 
-template <int TM, int TN, int WM, int WN, int NS>
+template <int TM, int TN, int WM, int WN, int NS, bool MX = false>
 __device__ __forceinline__ void gemm_f8t_body(const CrctGemmArgs& g, int tile_m, int tile_n) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN, KT = 128;
   constexpr int A_BYTES = KT * BM, B_BYTES = KT * BN, STAGE = A_BYTES + B_BYTES;
@@ -1406,6 +1451,34 @@ __device__ __forceinline__ void gemm_f8t_body(const CrctGemmArgs& g, int tile_m,
     if (kt + NS - 1 < nk) issue(kt + NS - 1, st_next);
     const uint32_t stage = smem_base + st * STAGE;
     long fa[4][WTM], fb[4][WTN];
+    if constexpr (MX) {       // the four 32-token steps of the K tile as ONE scaled MFMA per output tile (see gemm_f8_kernel)
+      static_for<4>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        static_for<WTM>([&](auto ic) { constexpr int i = decltype(ic)::value; fa[h][i] = lds_read_tr8_imm<h * 2048 * AW>(stage + bA[i]); });
+        static_for<WTN>([&](auto ic) { constexpr int i = decltype(ic)::value; fb[h][i] = lds_read_tr8_imm<h * 2048 * BW>(stage + bB[i]); });
+      });
+      frag_async_wait<0>();
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fa[h][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fb[h][i]);
+      }
+      auto quad = [](long a, long b, long c, long d) {
+        return v8i_t{(int)a, (int)(a >> 32), (int)b, (int)(b >> 32), (int)c, (int)(c >> 32), (int)d, (int)(d >> 32)};
+      };
+#pragma unroll
+      for (int a = 0; a < WTN; ++a) {
+        const v8i_t xb = quad(fb[0][a], fb[1][a], fb[2][a], fb[3][a]);
+#pragma unroll
+        for (int b = 0; b < WTM; ++b)     // first source = the activation fragment (e4m3), second = the gradient fragment (e5m2)
+          acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xb, quad(fa[0][b], fa[1][b], fa[2][b], fa[3][b]), acc[a][b], 0, 1, 0, MX_ONE, 0, MX_ONE);
+      }
+      st_next = st;
+      st = st + 1 == NS ? 0 : st + 1;
+      continue;
+    }
     static_for<4>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
       static_for<WTM>([&](auto ic) { constexpr int i = decltype(ic)::value; fa[h][i] = lds_read_tr8_imm<h * 2048 * AW>(stage + bA[i]); });
@@ -1439,11 +1512,11 @@ __device__ __forceinline__ void gemm_f8t_body(const CrctGemmArgs& g, int tile_m,
   gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
-template <int TM, int TN, int WM, int WN, int NS>
+template <int TM, int TN, int WM, int WN, int NS, bool MX = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_kernel(const CrctGemmArgs g, const TileMap tmap) {
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
-  gemm_f8t_body<TM, TN, WM, WN, NS>(g, tile_m, tile_n);
+  gemm_f8t_body<TM, TN, WM, WN, NS, MX>(g, tile_m, tile_n);
 }
 
 template <int TM, int TN, int WM, int WN, int NS>
@@ -1452,14 +1525,21 @@ hipError_t launch_f8t(const CrctGemmArgs& g, hipStream_t s) {
   int tiles = 0;
   const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
-  auto kern = gemm_f8t_kernel<TM, TN, WM, WN, NS>;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_F8T(MX_)                                                                                               \
+  do {                                                                                                                     \
+    auto kern = gemm_f8t_kernel<TM, TN, WM, WN, NS, MX_>;                                                                  \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                                 \
+  } while (0)
+  if (g_f8_mx) CRCT_LAUNCH_F8T(true);
+  else CRCT_LAUNCH_F8T(false);
+#undef CRCT_LAUNCH_F8T
   return hipGetLastError();
 }
 
@@ -1633,12 +1713,12 @@ hipError_t launch_group_ldr(const CrctGemmArgs* gs, int n, hipStream_t s) {
 }
 
 // the fp8 weight gradients of a layer in one grid (same block -> (problem, tile) table, gemm_f8t_body per tile)
-template <int TM, int TN, int WM, int WN, int NS>
+template <int TM, int TN, int WM, int WN, int NS, bool MX = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_group_kernel(const GroupArgs ga) {
   const int total = ga.concat ? 8 * ga.per_xcd : ga.tile_begin[ga.n];
   for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
     int pi, tm, tn;
-    if (group_pick(ga, bid, pi, tm, tn)) gemm_f8t_body<TM, TN, WM, WN, NS>(ga.p[pi], tm, tn);
+    if (group_pick(ga, bid, pi, tm, tn)) gemm_f8t_body<TM, TN, WM, WN, NS, MX>(ga.p[pi], tm, tn);
     if (bid + (int)gridDim.x < total) __syncthreads();
   }
 }
@@ -1659,14 +1739,21 @@ hipError_t launch_group_f8t(const CrctGemmArgs* gs, int n, hipStream_t s) {
   ga.tile_begin[n] = total;
   if (g_group_concat) group_concat(ga, &total);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
-  auto kern = gemm_f8t_group_kernel<TM, TN, WM, WN, NS>;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3(WM * WN * 64), lds, s, ga);
+  hipError_t e = hipSuccess;
+#define CRCT_LAUNCH_F8TG(MX_)                                                                                              \
+  do {                                                                                                                     \
+    auto kern = gemm_f8t_group_kernel<TM, TN, WM, WN, NS, MX_>;                                                            \
+    static bool attr_set = false;                                                                                          \
+    if (lds > 64 * 1024 && !attr_set) {                                                                                    \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return e;                                                                                       \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3(WM * WN * 64), lds, s, ga); \
+  } while (0)
+  if (g_f8_mx) CRCT_LAUNCH_F8TG(true);
+  else CRCT_LAUNCH_F8TG(false);
+#undef CRCT_LAUNCH_F8TG
   return hipGetLastError();
 }
 
@@ -1812,9 +1899,11 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 enum { CLS_W, CLS_N, CLS_NL, CLS_PER_BUCKET };
 enum { MB_S, MB_M, MB_L, MB_COUNT };
 constexpr int CLS_COUNT = MB_COUNT * CLS_PER_BUCKET;
-static int g_class_table[CLS_COUNT] = {12, 12, 15,      // S: text rows of configs[1]
-                                       12, 12, 4,       // M: visual rows of configs[1] (vml: 128x128, 3 stages: 7.61 -> 7.56 ms), long-context text rows
-                                       12, 12, 4};      // L: long-context visual rows
+static int g_class_table[CLS_COUNT] = {12, 12, 15,      // S: text rows of configs[1] (and, below, every narrow GEMM of text width)
+                                       12, 12, 4,       // M: visual rows of configs[1] (nl: 128x128, 3 stages: 7.61 -> 7.56 ms)
+                                       12, 50, 50};     // L: long-context visual rows: 256x128 tiles with loader waves for the narrow outputs
+                                                        //    (in-step sweep, profiles/r4_longctx_class_sweep.txt: 12.11 -> 12.04 each, 11.95 -> 11.79 ms
+                                                        //    together with the text-width rule below; every other entry measured neutral or worse)
 extern "C" int crct_gemm_class_config(int cls, int cfg) {
   if (cls < 0 || cls >= CLS_COUNT) return -1;
   const int old = g_class_table[cls];
@@ -1824,8 +1913,11 @@ extern "C" int crct_gemm_class_config(int cls, int cfg) {
 static int pick_pipe_config(const CrctGemmArgs& g) {
   if (g.M <= 96) return 3;                                          // head / regressor GEMMs: B rows
   if (g.ta) return ((long)g.M * g.N <= 1024L * 1024L) ? 3 : 9;      // single weight gradient (grouped ones: crct_gemm_launch_grouped)
-  const int mb = g.M <= 2000 ? MB_S : (g.M <= 4000 ? MB_M : MB_L);
+  int mb = g.M <= 2000 ? MB_S : (g.M <= 4000 ? MB_M : MB_L);
   const bool wide = g.N >= 2304, longk = g.K > 1024;
+  // a narrow output of TEXT width (N < 1024: H = 768) in the M bucket is the long-context text stream (2560 rows), not the visual
+  // stream of configs[1] (2880 rows x 1024): it takes the text entries (the visual nl choice, 128 x 128 tiles, leaves 120 tiles)
+  if (mb == MB_M && !wide && g.N < 1024) mb = MB_S;
   const int t = g_class_table[mb * CLS_PER_BUCKET + (wide ? CLS_W : (longk ? CLS_NL : CLS_N))];
   return (t < 0 || t > 65) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
 }
@@ -2058,6 +2150,8 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 62: e = launch_ldr<4, 4, 2, 2, 2, 4, true>(g, s); break;  // 128x128, 4 + 4 waves, 2 stages (64 KB: two per CU)
       case 63: e = launch_ldr<4, 2, 2, 2, 3, 4, true>(g, s); break;  // 128x64, 4 + 4 waves, 3 stages
       case 64: e = launch_ldr<4, 2, 2, 2, 2, 2, true>(g, s); break;  // 128x64, 4 + 2 waves, 2 stages (48 KB: three per CU)
+      case 60: e = launch_ldr<8, 4, 2, 2, 3, 4>(g, s); break;        // 256x128, 4 (128x64 wave tiles) + 4 waves, 3 stages (144 KB)
+      case 65: e = launch_ldr<8, 4, 2, 2, 2, 4>(g, s); break;        // 256x128, 4 + 4 waves, 2 stages (96 KB)
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
   } else {

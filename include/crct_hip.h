@@ -127,6 +127,12 @@ int crct_lab_xcd_band(int rows_per_band);
  * in-step sweeps (bench.py --class-policy); per-site overrides: crct_engine_set_site_policy. */
 int crct_gemm_class_config(int cls, int cfg);
 
+/* fp8 GEMMs (forward, data gradient, weight gradient): 1 (default) = the 128-deep K tile of an output tile as ONE
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales -- gfx950's block-scaled instruction at twice the rate of the plain fp8
+ * MFMA -- 0 = four v_mfma_f32_16x16x32_fp8_fp8 / _fp8_bf8 (round 3).  Same products, other order of the fp32 additions inside a K
+ * tile.  on < 0 only reads.  Returns the previous setting. */
+int crct_gemm_fp8_scaled_mfma(int on);
+
 /* Tile the launcher would pick for an M x N output (0..3, see CrctGemmArgs.tile). */
 int crct_gemm_pick_tile(int M, int N);
 

@@ -1,7 +1,7 @@
 # End-of-round evidence, collected on the GPU box in one call:  bash tools/collect_profiles.sh <tag>
 # writes gpurun_out/<tag>_*; the PMC tables are also put under profiles/ of the box's copy so that the bench lines that
 # follow read their roofline.traffic from the same build.
-tag=${1:-r3}
+tag=${1:-r4}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline --profile-steps 0 --no-h2d-leg"
@@ -40,6 +40,7 @@ F="RCCL\|HIP ver\|ROCm ver\|Hostname\|Librccl\|amdgpu.ids\|socket.cpp"
 python tools/step_phases.py 2>&1 | grep -v "$F" > $O/${tag}_step_phases.txt
 python tools/step_phases.py --exchange bf16 --stats 1 2>&1 | grep -v "$F" > $O/${tag}_step_phases_forced_exchange.txt
 python tools/step_phases.py --dtype fp8 2>&1 | grep -v "$F" > $O/${tag}_step_phases_fp8.txt
+CRCT_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 10 --warmup 3 --batch 40 --no-cpu-baseline --profile-steps 0 --no-h2d-leg --sustained-s 0 2> $O/${tag}_bench_n2_shared_gpu.err | grep '^{' > $O/${tag}_bench_n2_shared_gpu.json
 python tools/lab/wgrad_fp8_lab.py 2>&1 | grep -v "$F" > $O/${tag}_wgrad_fp8_lab.txt
 python tools/lab/fp8_draws.py 2>&1 | grep -v "$F" > $O/${tag}_fp8_parity_draws.txt
 ./tools/lab/tr8_probe.bin > $O/${tag}_tr8_probe.txt 2>&1
@@ -48,11 +49,12 @@ python bench.py --steps 20 --warmup 5 2> $O/${tag}_bench_n1.err | grep '^{' > $O
 python bench.py --steps 20 --warmup 5 --dtype fp8 --no-cpu-baseline 2> $O/${tag}_bench_n1_fp8.err | grep '^{' > $O/${tag}_bench_n1_fp8.json
 python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-bf16-wgrad --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_bf16_wgrad.json
 python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-forward-only --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_forward_only.json
+python bench.py --steps 20 --warmup 5 --dtype fp8 --fp8-bf16-forward --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_fp8_bf16_forward.json
 python bench.py --steps 20 --warmup 5 $LC --no-cpu-baseline 2> $O/${tag}_bench_n1_longctx.err | grep '^{' > $O/${tag}_bench_n1_longctx.json
 python bench.py --steps 20 --warmup 5 $LC --dtype fp8 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_longctx_fp8.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --exchange-pack-all 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_pack_all.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --dtype fp8 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp8.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange 2> $O/${tag}_bench_n1_forced_exchange.err | grep '^{' > $O/${tag}_bench_n1_forced_exchange.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --grad-dtype fp32 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp32.json
-for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
+for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
 head -45 $O/${tag}_pmc_sites.txt

@@ -19,11 +19,11 @@ import re
 import sys
 from collections import defaultdict
 
-GEMM = re.compile(r"gemm_(pipe|splitk|group|f8|f8t|f8t_group)?_?kernel<")
+GEMM = re.compile(r"gemm_(pipe|splitk|group|ldr|group_ldr|f8|f8t|f8t_group)?_?kernel<")
 
 
 def kind_of_name(name):
-    m = re.search(r"gemm_(pipe|splitk|group)_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
+    m = re.search(r"gemm_(pipe|splitk|group|ldr|group_ldr)_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
     if m:
         return "wgrad" if m.group(6) == "true" else ("dgrad" if m.group(7) == "true" else "fwd")
     m = re.search(r"gemm_kernel<(\d+), (\d+), (true|false), (true|false)>", name)

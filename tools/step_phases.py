@@ -18,12 +18,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--exchange", choices=("none", "bf16", "fp32"), default="none", help="run the data-parallel exchange on a single-rank RCCL communicator")
 ap.add_argument("--thread", type=int, default=1)
 ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16", help="fp8: BASELINE configs[4] (every encoder GEMM on fp8 operands)")
+ap.add_argument("--fp8-bf16-forward", action="store_true", help="--dtype fp8 with bf16 forward GEMMs (params['fp8_forward'] = False)")
 ap.add_argument("--stats", type=int, default=0, help="1: the asynchronous 9-float stats all-reduce of bench.py inside the step")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B = 80
 cfg = CFG.vilbert_config(v_feature_size=2048)
 params = CFG.default_params(device=dev, rank=0, world_size=1, ddp=False, batch_size=B, seed=0, fp8=args.dtype == "fp8")
+if args.fp8_bf16_forward:
+    params["fp8_forward"] = False
 model = VisualDialogEncoder(params, config=cfg)
 core = model.bert_pretrained
 core.sync_stats = False
