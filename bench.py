@@ -62,7 +62,8 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               48: "ldr128x128w8+4s3", 49: "ldr128x128w8+4s2", 50: "ldr256x128w8+4s3", 51: "ldr128x64w8+4s4", 52: "ldr128x64w8+2s3",
               53: "ldr128x128w4+4s3", 54: "ldr128x64w4+2s3", 55: "ldr256x128w8+4s2", 56: "ldrp128x64w4+2s3", 57: "ldrp128x64w8+4s3",
               58: "ldrp128x128w4+4s3", 59: "ldrp128x128w8+4s3", 61: "ldrp128x64w4+2s4", 62: "ldrp128x128w4+4s2",
-              63: "ldrp128x64w4+4s3", 64: "ldrp128x64w4+2s2", 60: "ldr256x128w4+4s3", 65: "ldr256x128w4+4s2"}
+              63: "ldrp128x64w4+4s3", 64: "ldrp128x64w4+2s2", 60: "ldr256x128w4+4s3", 65: "ldr256x128w4+4s2",
+              66: "ldrh256x128w4+4s3", 67: "ldrh256x128w8+4s3", 68: "ldrh128x128w4+4s3", 69: "ldrh128x64w4+2s3", 70: "ldrh128x128w8+4s3", 71: "ldrh256x128w4+4s2"}
 KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
 
 
@@ -155,7 +156,7 @@ def gemm_profile(run_step, n_steps):
         return dict(kernel=label, launches_per_step=cnt / n_steps, gflop_per_launch=fl / cnt / 1e9, us_per_launch=ms * 1e3 / cnt,
                     ms_per_step=ms / n_steps, tflops=fl / (ms * 1e-3) / 1e12, frac_of_bf16_peak=fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, **extra)
 
-    for v in range(210):
+    for v in range(225):
         cnt, fl, ms = C.c_long(), C.c_double(), C.c_double()
         if lib.crct_prof_read(v, C.byref(cnt), C.byref(fl), C.byref(ms)) != 0 or cnt.value == 0 or ms.value <= 0:
             continue

@@ -1586,7 +1586,7 @@ extern "C" int crct_engine_set_prefetch(crct_engine_t* e, int workgroups) {
 extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind, int phase, int cfg, int split_k) {
   CRCT_REQUIRE(e && site > 0 && site < CRCT_SITE_COUNT && kind >= CRCT_KIND_FWD && kind <= CRCT_KIND_WGRAD && phase <= 1,
                "set_site_policy: bad site / kind / phase (%d, %d, %d)", site, kind, phase);
-  CRCT_REQUIRE(cfg >= -1 && cfg <= 65 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
+  CRCT_REQUIRE(cfg >= -1 && cfg <= 71 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
   for (int ph = 0; ph < 2; ++ph)
     if (phase < 0 || phase == ph) { e->policy[site][kind][ph].cfg = cfg; e->policy[site][kind][ph].split_k = split_k; }
   return 0;

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(const CrctGem
 // and then multiply tile k - 1 out of the other set, so the LDS round trip of a K step hides behind the MFMAs of the previous one
 // (what PM = 1 of the plain kernel could not deliver while the same waves also had to issue the DMA).  A stage is then free one
 // barrier earlier, the ring holds all NS tiles at the start and the loaders keep NS - 1 in flight.
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE = false>
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, int PIPE = 0>
 __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg = 0) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN, NTH = (NW + NL) * 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -993,7 +993,7 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
       for (int i = 0; i < PBL; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NL * 1024), 16, (int)offB[i], kt * stepB, 0, 0);
     };
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 1) {
       const int npre = nk < NS ? nk : NS;
       for (int t = 0; t < npre; ++t) issue(t, t);
       int st_next = 0;                      // the barrier of K step kt (>= 1) frees the stage of tile kt - 1
@@ -1038,7 +1038,55 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
     bf8_t ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 2) {
+      // half-step pipelining, no extra registers: the two 32-deep halves of a K tile live in the two halves of ONE fragment set.
+      // While the MFMAs of half 0 run the reads of half 1 are in flight, and while those of half 1 run the reads of the NEXT tile's
+      // half 0 are -- issued right behind the barrier that says the next tile has landed, which therefore sits between the two MFMA
+      // groups of a K tile (a wave reaches it with 512+ cycles of MFMAs still in the pipe).  For the large wave tiles (128 x 64:
+      // 32 MFMAs per half) whose fragment sets leave no room for a second copy (PIPE = 1 spills at 256 x 128).
+      bf8_t fm[2][WTM], fn[2][WTN];
+      auto reads = [&](int stg, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        uint32_t ca[FragBase<TA, TM, WTM>::NB], cb[FragBase<TB, TN, WTN>::NB];
+        fbA.at(smem_base + stg * STAGE, ca);
+        fbB.at(smem_base + stg * STAGE, cb);
+        FragBase<TA, TM, WTM>::template read<h>(ca, fm[h]);
+        FragBase<TB, TN, WTN>::template read<h>(cb, fn[h]);
+      };
+      auto mul = [&](int kt, int h) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
+#pragma unroll
+        for (int a = 0; a < WTN; ++a)
+#pragma unroll
+          for (int b = 0; b < WTM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[h][a], fm[h][b], acc[a][b], 0, 0, 0);
+        if (do_rs && (((kt << 1) + h) & (WN - 1)) == wn) {
+#pragma unroll
+          for (int b = 0; b < WTM; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[h][b], accb[b], 0, 0, 0);
+        }
+      };
+      __builtin_amdgcn_s_barrier();                      // tile 0 has landed
+      asm volatile("" ::: "memory");
+      reads(0, std::integral_constant<int, 0>{});
+      int stg = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        frag_async_wait<0>();                             // half 0 of tile kt is in registers (requested one MFMA group ago)
+        reads(stg, std::integral_constant<int, 1>{});
+        mul(kt, 0);
+        frag_async_wait<0>();                             // ... and half 1: this wave is done with the stage
+        const int nxt = stg + 1 == NS ? 0 : stg + 1;
+        if (kt + 1 < nk) {
+          __builtin_amdgcn_s_barrier();                   // tile kt + 1 has landed (the loaders waited for it)
+          asm volatile("" ::: "memory");
+          reads(nxt, std::integral_constant<int, 0>{});
+        }
+        mul(kt, 1);
+        stg = nxt;
+      }
+    } else if constexpr (PIPE == 1) {
       bf8_t fmA[2][WTM], fnA[2][WTN], fmB[2][WTM], fnB[2][WTN];
       auto mul = [&](int kt, bf8_t (&fm)[2][WTM], bf8_t (&fn)[2][WTN]) {
 #pragma unroll
@@ -1150,7 +1198,7 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
   gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE, NTH>(g, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE = false>
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, int PIPE = 0>
 __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ldr_kernel(const CrctGemmArgs g, const TileMap tmap) {
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
@@ -1612,7 +1660,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(const GroupArg
 }
 
 // the same with the loader-wave body (configurations 48 / 53 / 58 / 59: 128 x 128 tiles)
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, bool PIPE>
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, int PIPE>
 __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_group_ldr_kernel(const GroupArgs ga) {
   const int total = ga.concat ? 8 * ga.per_xcd : ga.tile_begin[ga.n];
   for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
@@ -1633,7 +1681,7 @@ extern "C" int crct_gemm_group_concat(int on) { g_group_concat = on != 0; return
 // configuration of the grouped weight-gradient launches (4 / 39 / 48 / 53 / 58 / 59: all 128 x 128 tiles); returns the previous one
 extern "C" int crct_gemm_group_wgrad_config(int cfg) {
   const int old = g_group_wgrad_cfg;
-  if (cfg == 4 || cfg == 39 || cfg == 48 || cfg == 53 || cfg == 58 || cfg == 59) g_group_wgrad_cfg = cfg;
+  if (cfg == 4 || cfg == 39 || cfg == 48 || cfg == 53 || cfg == 58 || cfg == 59 || cfg == 68) g_group_wgrad_cfg = cfg;
   return old;
 }
 extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
@@ -1675,7 +1723,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int TM, int TN, int WM, int WN, int NS, int NL, bool PIPE>
+template <int TM, int TN, int WM, int WN, int NS, int NL, int PIPE>
 hipError_t launch_group_ldr(const CrctGemmArgs* gs, int n, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   GroupArgs ga = {};
@@ -1809,7 +1857,7 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int TM, int TN, int WM, int WN, int NS, int NL, bool PIPE = false>
+template <int TM, int TN, int WM, int WN, int NS, int NL, int PIPE = 0>
 hipError_t launch_ldr(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
@@ -1907,7 +1955,7 @@ static int g_class_table[CLS_COUNT] = {12, 12, 15,      // S: text rows of confi
 extern "C" int crct_gemm_class_config(int cls, int cfg) {
   if (cls < 0 || cls >= CLS_COUNT) return -1;
   const int old = g_class_table[cls];
-  if (cfg >= 0 && cfg <= 65) g_class_table[cls] = cfg;
+  if (cfg >= 0 && cfg <= 71) g_class_table[cls] = cfg;
   return old;
 }
 static int pick_pipe_config(const CrctGemmArgs& g) {
@@ -1919,7 +1967,7 @@ static int pick_pipe_config(const CrctGemmArgs& g) {
   // stream of configs[1] (2880 rows x 1024): it takes the text entries (the visual nl choice, 128 x 128 tiles, leaves 120 tiles)
   if (mb == MB_M && !wide && g.N < 1024) mb = MB_S;
   const int t = g_class_table[mb * CLS_PER_BUCKET + (wide ? CLS_W : (longk ? CLS_NL : CLS_N))];
-  return (t < 0 || t > 65) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
+  return (t < 0 || t > 71) ? ((g.N <= 1024 && g.K >= 2048) ? 15 : 12) : t;
 }
 
 // ---- optional live profiling: begin / end stamps of every GEMM kernel, on the launch stream ----------
@@ -1930,7 +1978,7 @@ struct Prof {
   bool on = false;
   std::vector<ProfSlot> slots;
   size_t used = 0;
-  static constexpr int NV = 210;       // (66 LDS-DMA / fp8 / register-staged configuration ids + spare) x {fwd, dgrad, wgrad}
+  static constexpr int NV = 225;       // (72 LDS-DMA / fp8 / register-staged configuration ids + spare) x {fwd, dgrad, wgrad}
   double flops[NV] = {0}; long count[NV] = {0};
   bool log_on = false;
   std::vector<CrctLaunchRec> log;
@@ -2068,7 +2116,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g.q_out && !(pipe && g.q_scale && g.ld_q % 8 == 0)) return hipErrorInvalidValue;      // the fp8 output copy lives in the staged epilogue
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 15 && !(((t >= 22 && t <= 35) || (t >= 38 && t <= 65)) && pipe && !is_f8)) t = 12;
+  if (t > 15 && !(((t >= 22 && t <= 35) || (t >= 38 && t <= 71)) && pipe && !is_f8)) t = 12;
   // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21)
   if (is_f8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
@@ -2151,6 +2199,13 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 63: e = launch_ldr<4, 2, 2, 2, 3, 4, true>(g, s); break;  // 128x64, 4 + 4 waves, 3 stages
       case 64: e = launch_ldr<4, 2, 2, 2, 2, 2, true>(g, s); break;  // 128x64, 4 + 2 waves, 2 stages (48 KB: three per CU)
       case 60: e = launch_ldr<8, 4, 2, 2, 3, 4>(g, s); break;        // 256x128, 4 (128x64 wave tiles) + 4 waves, 3 stages (144 KB)
+      // loader waves + half-step pipelining in the compute waves (PIPE = 2: no extra registers)
+      case 66: e = launch_ldr<8, 4, 2, 2, 3, 4, 2>(g, s); break;     // 256x128, 4 + 4 waves, 3 stages (144 KB)
+      case 67: e = launch_ldr<8, 4, 4, 2, 3, 4, 2>(g, s); break;     // 256x128, 8 + 4 waves, 3 stages
+      case 68: e = launch_ldr<4, 4, 2, 2, 3, 4, 2>(g, s); break;     // 128x128, 4 + 4 waves, 3 stages (96 KB)
+      case 69: e = launch_ldr<4, 2, 2, 2, 3, 2, 2>(g, s); break;     // 128x64, 4 + 2 waves, 3 stages (72 KB)
+      case 70: e = launch_ldr<4, 4, 2, 4, 3, 4, 2>(g, s); break;     // 128x128, 8 + 4 waves, 3 stages
+      case 71: e = launch_ldr<8, 4, 2, 2, 2, 4, 2>(g, s); break;     // 256x128, 4 + 4 waves, 2 stages (96 KB)
       case 65: e = launch_ldr<8, 4, 2, 2, 2, 4>(g, s); break;        // 256x128, 4 + 4 waves, 2 stages (96 KB)
       default: e = launch_pipe<4, 2, 4, 2, 2>(g, s); break;    // 128x64, 8 waves (4x2), 2 stages
     }
@@ -2197,7 +2252,7 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
   // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages; CrctGemmArgs.tile of the first
   // problem may pick the other one (crct_engine_set_site_policy: A/B runs)
   const int t0 = gs[0].tile;
-  const int cfg = (t0 == 4 || t0 == 9 || t0 == 39 || t0 == 48 || t0 == 53 || t0 == 58 || t0 == 59) ? t0 : (gs[0].ta ? g_group_wgrad_cfg : 9);
+  const int cfg = (t0 == 4 || t0 == 9 || t0 == 39 || t0 == 48 || t0 == 53 || t0 == 58 || t0 == 59 || t0 == 68) ? t0 : (gs[0].ta ? g_group_wgrad_cfg : 9);
   prof_begin(cfg * 3 + kind_of(gs[0]), gs, n);
   hipError_t e;
   switch (cfg) {
@@ -2207,6 +2262,7 @@ hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s
     case 53: e = launch_group_ldr<4, 4, 2, 2, 3, 4, false>(gs, n, s); break;
     case 58: e = launch_group_ldr<4, 4, 2, 2, 3, 4, true>(gs, n, s); break;
     case 59: e = launch_group_ldr<4, 4, 2, 4, 3, 4, true>(gs, n, s); break;
+    case 68: e = launch_group_ldr<4, 4, 2, 2, 3, 4, 2>(gs, n, s); break;
     default: e = launch_group<4, 4, 2, 4, 3>(gs, n, s); break;
   }
   g_time_start = g_time_stop = nullptr;

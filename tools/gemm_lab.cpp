@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     if (f32) { hr.resize(nout); hipMemcpy(hr.data(), Cref, nout * 4, hipMemcpyDeviceToHost); }
     else { hrb.resize(nout); hipMemcpy(hrb.data(), Cref, nout * 2, hipMemcpyDeviceToHost); }
-    for (int tile = first_tile; tile < 66; ++tile)
+    for (int tile = first_tile; tile < 72; ++tile)
      for (int sk = 1; sk <= max_sk; ++sk) {
       if ((tile >= 16 && tile < 20) || tile == 36 || tile == 37) continue;
       if (only_tile >= 0 && tile != only_tile) continue;
