@@ -219,6 +219,8 @@ def pmc_traffic(site_labels, workload, dtype="bf16"):
             continue
         if table.get("_source_hash") != source_hash() or table.get("_workload") != list(workload) or table.get("_dtype", "bf16") != dtype:
             continue
+        if table.get("_mismatched_dispatches", 0):            # a pass that did not line up with the launch log: not a measurement
+            continue
         cand = [table["sites"][k] for k in site_labels if k in table.get("sites", {}) and table["sites"][k].get("bytes_per_launch")]
         if cand:
             tot = sum(v["launches"] for v in cand)

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r3_bench_n1.json, written by `python bench.py` on the GPU box) keeps the
+"""The committed bench line (profiles/r4_bench_n1.json, written by `python bench.py` on the GPU box) keeps the
 contract the driver parses: metric / unit of BASELINE.json, whole-job value, and the `roofline` and `cpu_baseline`
 objects.  Runs on CPU: it checks the artifact, not the GPU."""
 import json
@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r3_bench_n1.json")
+LINE = os.path.join(ROOT, "profiles", "r4_bench_n1.json")
 for _old in ("r2_bench_n1.json", "r1_bench_n1.json"):
     if not os.path.exists(LINE):
         LINE = os.path.join(ROOT, "profiles", _old)

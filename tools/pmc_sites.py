@@ -31,7 +31,7 @@ def kind_of_name(name):
         return "wgrad" if m.group(3) == "true" else ("dgrad" if m.group(4) == "true" else "fwd")
     if "gemm_f8t" in name:
         return "wgrad"        # token-major fp8 weight gradients
-    m = re.search(r"gemm_f8_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    m = re.search(r"gemm_f8_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)[,>]", name)
     return "dgrad" if (m and m.group(6) == "true") else "fwd"          # gemm_f8_kernel: A_BF8 = an e5m2 gradient operand
 
 
@@ -103,6 +103,9 @@ def main():
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1)
     print("matched %d launches per pass, %d mismatches" % (len(recs), mismatches))
+    if mismatches:
+        print("TABLE INVALID: the dispatches of at least one pass do not line up with the launch log (kernels launched after the logged "
+              "region? dropped records?) -- bench.py ignores a table with _mismatched_dispatches > 0")
     hdr = "%-18s %5s %6s %6s %6s %4s %7s %7s %7s %7s %6s %6s %6s %6s" % ("site", "n", "M", "N", "K", "cfg", "GFLOP", "us(ser)", "rd MB", "wr MB", "L2hit", "wait", "stall", "mfma")
     print(hdr)
     for key, e in sites.items():
