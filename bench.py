@@ -352,7 +352,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rccl_log = None
-    if (world > 1 or a.force_exchange) and rank == 0 and "NCCL_DEBUG" not in os.environ and not os.environ.get("CRCT_BENCH_SHARE_GPU"):
+    if ((world > 1 or a.force_exchange) and rank == 0 and os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN")
+            and "NCCL_DEBUG_FILE" not in os.environ and not os.environ.get("CRCT_BENCH_SHARE_GPU")):
         # RCCL has no getter for the channel count it chose: let rank 0 log its communicator INIT (only) into a file and read it
         # back for config.gradient_allreduce.rccl (crct/rccl.py: channels_from_debug_log)
         import tempfile
@@ -535,13 +536,17 @@ def main():
     h2d = None
     if a.input == "resident" and not a.no_h2d_leg:
         cur["feed"] = feed_of("prefetch")
-        for _ in range(max(3, a.warmup // 2)):
+        for _ in range(max(5, a.warmup // 2)):       # both slots' pinned / device buffers and the worker thread exist after two batches
             run_step()
-        dt2, _ = timed(a.steps)
+        # K steps, twice; the lower is reported and both are listed: this leg shares the host with a packing thread, and a single
+        # host hiccup (58 ms once in a round-4 collection: 10.5 instead of 7.7 ms per step) otherwise lands in a 0.15 s sample
+        reps2 = [timed(a.steps)[0] for _ in range(2)]
+        dt2 = min(reps2)
         feat_bytes = 2 if a.host_feat == "bf16" else 4
         h2d = {"input": "pageable host batches -> DevicePrefetcher (pinned staging, one async copy per batch on a copy stream, 2 slots), "
                         "image_feat shipped as %s" % a.host_feat,
                "ms_per_step": dt2 / a.steps * 1e3, "qa_pairs_per_s": a.batch * world * a.steps / dt2,
+               "ms_per_step_of_each_repeat": [d / a.steps * 1e3 for d in reps2],
                "bytes_per_step_per_gpu": int(sum(v.numel() * (feat_bytes if k == "image_feat" else v.element_size())
                                                  for k, v in host_pool[0].items()))}
         cur["feed"] = feed_of("resident")
@@ -573,7 +578,8 @@ def main():
         from crct import rccl as RC
         comm = {"rccl": {"version": RC.version()[1], "env": RC.env_seen(), "route": "direct ncclAllReduce (crct/rccl.py)" if rc is not None else "torch.distributed",
                          "collectives_issued": getattr(rc, "collectives", None), "world": world,
-                         "channels_logged_at_init": RC.channels_from_debug_log(rccl_log) if rccl_log else None},
+                         "channels_logged_at_init": RC.channels_from_debug_log(rccl_log) if rccl_log else None,
+                         "init_log_enabled_by_bench": bool(rccl_log)},      # NCCL_DEBUG=INFO / SUBSYS=INIT / DEBUG_FILE in env are then bench.py's
                 "allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
                 "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9,
                 "step_payload": {"dtype": a.grad_dtype, "bytes_per_step": used * (2 if a.grad_dtype == "bf16" else 4),
