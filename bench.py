@@ -108,6 +108,7 @@ def parse():
     ap.add_argument("--wgrad-concat", type=int, default=-1, help="developer A/B: 0 = per-problem XCD rectangles for the grouped weight gradients (crct_gemm_group_concat)")
     ap.add_argument("--wgrad-defer-sim", type=int, default=0, help="TIMING ONLY (wrong gradients): drop the co-attention-phase layers' weight-gradient "
                     "launches and run the text-only tail's 1 + N times (prices a deferral policy; crct_engine_set_wgrad_defer_sim)")
+    ap.add_argument("--wgrad-flush", type=int, default=-1, help="developer A/B: flush points of a layer's queued weight gradients (crct_engine_set_wgrad_flush)")
     ap.add_argument("--wgrad-cfg", type=int, default=-1, help="developer A/B: kernel configuration of the grouped weight-gradient launches (crct_gemm_group_wgrad_config)")
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
@@ -417,6 +418,8 @@ def main():
     if a.prefetch_wgs >= 0:
         core.prefetch_workgroups = a.prefetch_wgs
     core.wgrad_defer_sim = a.wgrad_defer_sim
+    if a.wgrad_flush >= 0:
+        core.wgrad_flush = a.wgrad_flush
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = not a.no_opt_overlap               # AdamW + gradient memset of step n overlap the forward of step n+1

@@ -143,6 +143,8 @@ struct crct_engine {
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
   int defer_sim = 0;                   // timing experiment (crct_engine_set_wgrad_defer_sim): see Run::flush_wgrads
+  int wgrad_flush = 1;                 // crct_engine_set_wgrad_flush: extra flush points of a layer's queued weight gradients (Run::ffn_bwd).
+                                       // 1 (round 4): FFN group 0.075 -> 0.081 of peak in the step, step -0.02 (bf16) / -0.06 (fp8) / -0.08 ms (long context)
   int prefetch_wgs = 0;                // workgroups of the weight prefetch one schedule step ahead (crct_engine_set_prefetch).  OFF: measured 7.79-8.04 vs 7.62-7.65 ms
                                        // per step (the lab gain of 2.4 us per GEMM does not survive in the step)
   bool one_wgrad_stream = false;       // both data streams' weight gradients on ONE side stream (frees a hardware queue for the exchange)
@@ -606,6 +608,7 @@ struct Run {
     lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M, false, w8);
     if (f8b_lin(p.dense)) lin_dgrad_f8(dlq, a.g_dl, A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
     else lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
+    if ((e->wgrad_flush & 2) && !defer) flush_wgrads();      // bit 1: the projection's weight gradient leaves behind its data gradient
   }
   // y = LN(dropout(down(gelu(up(x)))) + x)   vilbert.py:454-471 / :585-602 / :782-786
   // xq / site_x: the e4m3 copy of x and its scale site (the LayerNorm that produced x wrote both)
@@ -636,6 +639,11 @@ struct Run {
     Opt o2; o2.addend = A(sc.dres_a); o2.ld_add = H;
     if (q_dn && q_up) lin_dgrad_f8(sc.duq, a.g_du, A(sc.du), I, p.up, M, A(gx), H, o2);
     else lin_dgrad(A(sc.du), I, p.up, M, A(gx), H, o2);
+    // wgrad_flush & 1: the FFN block's two weight gradients (and the LayerNorm column pass) leave for the side stream HERE, behind
+    // the FFN-up data gradient, instead of at the end of the layer with the projection's and the QKV's: the grouped launch then runs
+    // beside this layer's LayerNorm backward / attention-output dgrad / attention backward / QKV dgrad -- kernels of <= 156
+    // workgroups -- and not beside the next layer's FFN data gradients.  Same kernels per problem, same sums: bit-identical.
+    if ((e->wgrad_flush & 1) && !defer) flush_wgrads();
   }
 
   // ---------------------------------------------------------------- self-attention layer
@@ -1571,6 +1579,11 @@ extern "C" crct_stream_t crct_engine_aux_stream(crct_engine_t* e, crct_stream_t 
   return e->aux;
 }
 
+extern "C" int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode) {
+  if (!e) return 1;
+  e->wgrad_flush = mode;
+  return 0;
+}
 extern "C" int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps) {
   if (!e || extra_reps < 0 || extra_reps > 8) return 1;
   e->defer_sim = extra_reps;

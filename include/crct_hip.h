@@ -617,6 +617,11 @@ int crct_engine_set_pairing(crct_engine_t*, int on);
 /* TIMING EXPERIMENT ONLY (wrong gradients; bench.py --wgrad-defer-sim): the grouped weight-gradient launches of the layers that
  * run beside the visual stream are dropped and those of the text-only tail of backward are launched 1 + extra_reps times -- the
  * side-stream work of a deferral policy without its buffers, to price it before building it.  0 = off. */
+// Where a layer's queued weight-gradient GEMMs leave for the side stream (default 1).  0: one grouped launch at the end of the layer.  Bit 0: the
+// FFN block's two (with its LayerNorm column pass) right behind the FFN-up data gradient, the rest at the end of the layer.  Bit 1:
+// the attention-output projection's right behind its data gradient.
+// Scheduling only: the gradients are bit-identical in every mode.
+int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode);
 int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps);
 
 /* Weight prefetch: while a schedule step runs, the bf16 weights of the NEXT step (forward) / the previous one (backward) are
