@@ -111,6 +111,9 @@ def parse():
     ap.add_argument("--wgrad-flush", type=int, default=-1, help="developer A/B: flush points of a layer's queued weight gradients (crct_engine_set_wgrad_flush)")
     ap.add_argument("--wgrad-cfg", type=int, default=-1, help="developer A/B: kernel configuration of the grouped weight-gradient launches (crct_gemm_group_wgrad_config)")
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
+    ap.add_argument("--wgrad-target-wgs", type=int, default=-1, help="developer A/B: target size of the persistent grid of the engine's grouped bf16 "
+                    "weight-gradient launches (crct_engine_set_wgrad_workgroups; 0 = one workgroup per tile, the engine's default is 96)")
+    ap.add_argument("--wgrad-target-rows", type=int, default=3000, help="developer A/B: ... for data streams of at most this many token rows")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
     ap.add_argument("--exchange-pack-all", action="store_true", help="developer A/B: the exchange packs every gradient from fp32 (the weight-gradient "
@@ -402,6 +405,8 @@ def main():
     # hardware queue to itself -- a collective that really moves data must not sit in a compute stream's queue
     if a.wgrad_wgs >= 0:
         L.load().crct_gemm_group_max_workgroups(a.wgrad_wgs)
+    if a.wgrad_target_wgs >= 0:
+        core.wgrad_workgroups = (a.wgrad_target_wgs, a.wgrad_target_rows)
     if a.wgrad_concat >= 0:
         L.load().crct_gemm_group_concat(a.wgrad_concat)
     if a.wgrad_cfg >= 0:

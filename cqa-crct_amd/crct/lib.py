@@ -107,6 +107,7 @@ PROTOTYPES = {
     "crct_gemm_bf16_grouped": (C.c_int, [C.POINTER(GemmArgs), C.c_int, vp]),
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_group_max_workgroups": (C.c_int, [C.c_int]),
+    "crct_gemm_group_target_workgroups": (C.c_int, [C.c_int]),
     "crct_gemm_group_concat": (C.c_int, [C.c_int]),
     "crct_embed_scatter_split": (None, [C.c_int]),
     "crct_gemm_force_generic": (C.c_int, [C.c_int]),
@@ -143,6 +144,7 @@ PROTOTYPES = {
     "crct_lab_xcd_band": (C.c_int, [C.c_int]),
     "crct_engine_set_wgrad_defer_sim": (C.c_int, [vp, C.c_int]),
     "crct_engine_set_wgrad_flush": (C.c_int, [vp, C.c_int]),
+    "crct_engine_set_wgrad_workgroups": (C.c_int, [vp, C.c_int, C.c_int]),
     "crct_gemm_class_config": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_fp8_scaled_mfma": (C.c_int, [C.c_int]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),

@@ -22,6 +22,8 @@ void crct_set_error(const char* fmt, ...);
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g, hipStream_t s);
 hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s);
+// target_wgs > 0: a grouped bf16 weight-gradient launch runs as a persistent grid of about that many workgroups (gemm.hip, group_grid)
+hipError_t crct_gemm_launch_grouped_wgs(const CrctGemmArgs* gs, int n, hipStream_t s, int target_wgs);
 // streams.hip: three streams on hardware queues other than main's (+ a second one on the last queue), found by probing
 int crct_streams_place(hipStream_t main, hipStream_t out[4], int* n_classes);
 

@@ -57,7 +57,8 @@ extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   return 0;
 }
 
-extern "C" int crct_gemm_bf16_grouped(const CrctGemmArgs* a, int n, crct_stream_t stream) {
+// target_wgs < 0: the library's default (crct_gemm_group_target_workgroups)
+static int gemm_grouped_checked(const CrctGemmArgs* a, int n, crct_stream_t stream, int target_wgs) {
   CRCT_REQUIRE(a != nullptr && n >= 1, "gemm_grouped: bad arguments");
   for (int i = 0; i < n; ++i) {
     CRCT_REQUIRE(a[i].A && a[i].B && a[i].C, "gemm_grouped: null operand in problem %d", i);
@@ -65,9 +66,11 @@ extern "C" int crct_gemm_bf16_grouped(const CrctGemmArgs* a, int n, crct_stream_
     CRCT_REQUIRE((a[i].ta && a[i].tb) || a[i].K % 8 == 0, "gemm_grouped: K of problem %d", i);
     CRCT_REQUIRE(!(a[i].ta && !a[i].tb) && (!a[i].ta || a[i].M % 8 == 0) && (!a[i].tb || a[i].N % 8 == 0), "gemm_grouped: layout of problem %d", i);
   }
-  CRCT_CHECK_HIP(crct_gemm_launch_grouped(a, n, (hipStream_t)stream));
+  if (target_wgs < 0) CRCT_CHECK_HIP(crct_gemm_launch_grouped(a, n, (hipStream_t)stream));
+  else CRCT_CHECK_HIP(crct_gemm_launch_grouped_wgs(a, n, (hipStream_t)stream, target_wgs));
   return 0;
 }
+extern "C" int crct_gemm_bf16_grouped(const CrctGemmArgs* a, int n, crct_stream_t stream) { return gemm_grouped_checked(a, n, stream, -1); }
 
 namespace {
 
@@ -143,6 +146,7 @@ struct crct_engine {
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
   int defer_sim = 0;                   // timing experiment (crct_engine_set_wgrad_defer_sim): see Run::flush_wgrads
+  int wgrad_target = 96, wgrad_target_rows = 3000;      // crct_engine_set_wgrad_workgroups (Run::flush_wgrads)
   int wgrad_flush = 1;                 // crct_engine_set_wgrad_flush: extra flush points of a layer's queued weight gradients (Run::ffn_bwd).
                                        // 1 (round 4): FFN group 0.075 -> 0.081 of peak in the step, step -0.02 (bf16) / -0.06 (fp8) / -0.08 ms (long context)
   int prefetch_wgs = 0;                // workgroups of the weight prefetch one schedule step ahead (crct_engine_set_prefetch).  OFF: measured 7.79-8.04 vs 7.62-7.65 ms
@@ -501,9 +505,15 @@ struct Run {
     // layers' weight gradients into the text-only tail of backward buy?  Their grouped launches are dropped where they are and the
     // tail layers' groups are launched (1 + defer_sim) times instead -- the same amount of side-stream work, moved.
     const int reps = (e->defer_sim > 0 && c->training) ? (phase == 1 ? 0 : 1 + e->defer_sim) : 1;
+    // a persistent grid for the group (gemm.hip, group_grid) where the throttled side stream stays off the critical path: a side
+    // stream per data stream, and not the 2560 / 6400-row streams of the long-context configuration, whose data-gradient GEMMs fill the
+    // chip themselves (measured there: 11.90 - 11.94 ms with the text stream's groups throttled, 11.96 - 12.04 with both, 11.80 - 11.86 without)
+    const int target = (sw != s && !e->one_wgrad_stream && !pending.empty() && pending[0].K <= e->wgrad_target_rows) ? e->wgrad_target : 0;
     for (int rep = 0; rep < reps; ++rep)
-      for (size_t i = 0; i < pending.size() && !rc; i += 8)
-        fail(crct_gemm_bf16_grouped(pending.data() + i, (int)std::min<size_t>(8, pending.size() - i), sw));
+      for (size_t i = 0; i < pending.size() && !rc; i += 8) {
+        const int ng = (int)std::min<size_t>(8, pending.size() - i);
+        fail(gemm_grouped_checked(pending.data() + i, ng, sw, target));
+      }
     pending.clear();
     for (size_t i = 0; i < pending_f8.size() && !rc; i += 8)
       fail(crct_gemm_bf16_grouped(pending_f8.data() + i, (int)std::min<size_t>(8, pending_f8.size() - i), sw));
@@ -1579,6 +1589,12 @@ extern "C" crct_stream_t crct_engine_aux_stream(crct_engine_t* e, crct_stream_t 
   return e->aux;
 }
 
+extern "C" int crct_engine_set_wgrad_workgroups(crct_engine_t* e, int target_wgs, int max_rows) {
+  if (!e) return 1;
+  e->wgrad_target = target_wgs > 0 ? target_wgs : 0;
+  e->wgrad_target_rows = max_rows;
+  return 0;
+}
 extern "C" int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode) {
   if (!e) return 1;
   e->wgrad_flush = mode;

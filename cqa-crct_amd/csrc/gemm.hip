@@ -1685,6 +1685,23 @@ extern "C" int crct_gemm_group_wgrad_config(int cfg) {
   return old;
 }
 extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
+// Workgroups of a grouped bf16 weight-gradient launch (round 4).  The groups run on a side stream BESIDE the data-gradient chain, and
+// with one workgroup per tile (288 for a text layer's FFN pair) they take every CU the chain's 156-workgroup GEMMs leave and a share
+// of the ones they use.  A persistent grid of about `target` workgroups that walks the tile list in whole rounds -- rounds =
+// ceil(tiles / target), grid = ceil(tiles / rounds) rounded up to the 8 XCDs -- leaves the chain ~150 CUs: 7.45 -> 7.30 - 7.39 ms at
+// configs[1] with 96 workgroups for 288 tiles (3 rounds; 88 = 4 rounds: 7.48, 104 / 112 = 3 rounds on more CUs: 7.39 / 7.43, 128:
+// 7.55; profiles/r4_wgrad_workgroups_ab.txt).  0 = off.  An explicit crct_gemm_group_max_workgroups overrides it.  The step engine
+// decides per launch (engine.cpp, Run::flush_wgrads): only where a throttled side stream cannot become the critical path.
+static int g_group_target_wgs = 0;       // the library's default for direct callers; the step engine passes its own (crct_gemm_launch_grouped_wgs)
+static int g_group_target_now = 0;       // the target of the launch in progress
+extern "C" int crct_gemm_group_target_workgroups(int n) { const int old = g_group_target_wgs; g_group_target_wgs = n > 0 ? n : 0; return old; }
+static int group_grid(int total, bool wgrad_bf16) {
+  if (g_group_max_wgs > 0) return g_group_max_wgs < total ? g_group_max_wgs : total;
+  if (!wgrad_bf16 || g_group_target_now <= 0 || total <= g_group_target_now) return total;
+  const int rounds = (total + g_group_target_now - 1) / g_group_target_now;
+  const int grid = ((total + rounds - 1) / rounds + 7) / 8 * 8;
+  return grid < total ? grid : total;
+}
 
 template <int TM, int TN, int WM, int WN, int NS, int PM = 0>
 hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
@@ -1713,7 +1730,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3(WM * WN * 64), lds, s, ga); \
+    launch_kernel(kern, dim3(group_grid(total, gs[0].ta && gs[0].tb && !gs[0].fp8)), dim3(WM * WN * 64), lds, s, ga); \
   } while (0)
   if (gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(true, true);
   else if (!gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP(false, true);
@@ -1750,7 +1767,7 @@ hipError_t launch_group_ldr(const CrctGemmArgs* gs, int n, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3((WM * WN + NL) * 64), lds, s, ga); \
+    launch_kernel(kern, dim3(group_grid(total, gs[0].ta && gs[0].tb && !gs[0].fp8)), dim3((WM * WN + NL) * 64), lds, s, ga); \
   } while (0)
   if (gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP_LDR(true, true);
   else if (!gs[0].ta && gs[0].tb) CRCT_LAUNCH_GROUP_LDR(false, true);
@@ -1797,7 +1814,7 @@ hipError_t launch_group_f8t(const CrctGemmArgs* gs, int n, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(g_group_max_wgs > 0 && g_group_max_wgs < total ? g_group_max_wgs : total), dim3(WM * WN * 64), lds, s, ga); \
+    launch_kernel(kern, dim3(group_grid(total, false)), dim3(WM * WN * 64), lds, s, ga); \
   } while (0)
   if (g_f8_mx) CRCT_LAUNCH_F8TG(true);
   else CRCT_LAUNCH_F8TG(false);
@@ -2226,7 +2243,9 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
 // requirements; anything else is launched one by one.  Two uses: the weight gradients of a layer (ta = tb = 1), and the
 // forward / data-gradient GEMMs of the text and the visual side of a co-attention layer or of two independent layers
 // (n = 2): one grid, one ramp, the tiles of both problems packed over the CUs.
-hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s) {
+hipError_t crct_gemm_launch_grouped(const CrctGemmArgs* gs, int n, hipStream_t s) { return crct_gemm_launch_grouped_wgs(gs, n, s, g_group_target_wgs); }
+hipError_t crct_gemm_launch_grouped_wgs(const CrctGemmArgs* gs, int n, hipStream_t s, int target_wgs) {
+  g_group_target_now = target_wgs;
   bool all_f8t = n >= 2 && n <= GROUP_MAX;
   for (int i = 0; all_f8t && i < n; ++i) all_f8t = (gs[i].fp8 & 1) && gs[i].ta && f8t_ok(gs[i]);
   if (all_f8t) {                    // the fp8 weight gradients of a layer

@@ -102,6 +102,11 @@ int crct_gemm_bf16_grouped(const CrctGemmArgs* args, int n, crct_stream_t stream
  * a layer's weight gradients occupy at most that many CUs at a time beside the data-gradient chain.  Process-wide knob of the
  * developer tools (bench.py --wgrad-wgs); results are identical for every value. */
 int crct_gemm_group_max_workgroups(int n);
+// Target size of the persistent grid of a grouped bf16 weight-gradient launch issued through crct_gemm_bf16_grouped (default 0 = one
+// workgroup per tile; the step engine has its own policy, crct_engine_set_wgrad_workgroups): the grid is
+// ceil(tiles / ceil(tiles / target)) workgroups, rounded up to a multiple of 8, each walking whole rounds of the tile list.  Returns
+// the previous target.  Placement only: results are bit-identical.
+int crct_gemm_group_target_workgroups(int n);
 /* Block -> tile placement of a grouped weight-gradient launch.  0 (default): every problem is cut into 8 rectangles, one per XCD
  * (each XCD touches every problem: 2.5 - 3.6 x the distinct operand bytes at the fabric).  on != 0: the tiles of all problems form
  * one list and each XCD takes one run of consecutive tiles, i.e. a compact part of one or two problems, so that its private L2
@@ -622,6 +627,10 @@ int crct_engine_set_pairing(crct_engine_t*, int on);
 // the attention-output projection's right behind its data gradient.
 // Scheduling only: the gradients are bit-identical in every mode.
 int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode);
+// Persistent-grid policy of the engine's grouped bf16 weight-gradient launches: target_wgs workgroups (0 = one per tile) for the
+// groups of a data stream with at most max_rows token rows, and only while every data stream has a side stream of its own (a
+// shared side stream -- the mode a gradient exchange uses -- would become the critical path).  Defaults 96 / 3000.
+int crct_engine_set_wgrad_workgroups(crct_engine_t* e, int target_wgs, int max_rows);
 int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps);
 
 /* Weight prefetch: while a schedule step runs, the bf16 weights of the NEXT step (forward) / the previous one (backward) are
