@@ -113,6 +113,7 @@ def parse():
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-target-wgs", type=int, default=-1, help="developer A/B: target size of the persistent grid of the engine's grouped bf16 "
                     "weight-gradient launches (crct_engine_set_wgrad_workgroups; 0 = one workgroup per tile, the engine's default is 96)")
+    ap.add_argument("--wgrad-target-shared", type=int, default=-1, help="developer A/B: the same target while the weight gradients share one side stream (the exchange mode)")
     ap.add_argument("--wgrad-target-rows", type=int, default=3000, help="developer A/B: ... for data streams of at most this many token rows")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
@@ -405,6 +406,8 @@ def main():
     # hardware queue to itself -- a collective that really moves data must not sit in a compute stream's queue
     if a.wgrad_wgs >= 0:
         L.load().crct_gemm_group_max_workgroups(a.wgrad_wgs)
+    if a.wgrad_target_shared >= 0:
+        core.wgrad_workgroups_shared = a.wgrad_target_shared
     if a.wgrad_target_wgs >= 0:
         core.wgrad_workgroups = (a.wgrad_target_wgs, a.wgrad_target_rows)
     if a.wgrad_concat >= 0:

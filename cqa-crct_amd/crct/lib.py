@@ -145,6 +145,7 @@ PROTOTYPES = {
     "crct_engine_set_wgrad_defer_sim": (C.c_int, [vp, C.c_int]),
     "crct_engine_set_wgrad_flush": (C.c_int, [vp, C.c_int]),
     "crct_engine_set_wgrad_workgroups": (C.c_int, [vp, C.c_int, C.c_int]),
+    "crct_engine_set_wgrad_workgroups_shared": (C.c_int, [vp, C.c_int]),
     "crct_gemm_class_config": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_fp8_scaled_mfma": (C.c_int, [C.c_int]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),

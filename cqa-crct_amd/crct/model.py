@@ -437,6 +437,8 @@ class CrctModel(nn.Module):
                 L.check(self._engine.lib.crct_engine_set_prefetch(self._engine.handle, int(self.prefetch_workgroups)), "set_prefetch")
             if getattr(self, "wgrad_workgroups", None) is not None:      # (target, max rows) of crct_engine_set_wgrad_workgroups
                 L.check(self._engine.lib.crct_engine_set_wgrad_workgroups(self._engine.handle, int(self.wgrad_workgroups[0]), int(self.wgrad_workgroups[1])), "set_wgrad_workgroups")
+            if getattr(self, "wgrad_workgroups_shared", None) is not None:
+                L.check(self._engine.lib.crct_engine_set_wgrad_workgroups_shared(self._engine.handle, int(self.wgrad_workgroups_shared)), "set_wgrad_workgroups_shared")
             if getattr(self, "wgrad_flush", None) is not None:    # where a layer's weight gradients leave for the side stream (crct_engine_set_wgrad_flush)
                 L.check(self._engine.lib.crct_engine_set_wgrad_flush(self._engine.handle, int(self.wgrad_flush)), "set_wgrad_flush")
             if getattr(self, "wgrad_defer_sim", 0):               # developer timing experiment (bench.py --wgrad-defer-sim)

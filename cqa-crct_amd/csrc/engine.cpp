@@ -147,6 +147,7 @@ struct crct_engine {
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
   int defer_sim = 0;                   // timing experiment (crct_engine_set_wgrad_defer_sim): see Run::flush_wgrads
   int wgrad_target = 96, wgrad_target_rows = 3000;      // crct_engine_set_wgrad_workgroups (Run::flush_wgrads)
+  int wgrad_target_shared = 0;                           // ... when both data streams' groups share ONE side stream (crct_engine_set_wgrad_workgroups_shared)
   int wgrad_flush = 1;                 // crct_engine_set_wgrad_flush: extra flush points of a layer's queued weight gradients (Run::ffn_bwd).
                                        // 1 (round 4): FFN group 0.075 -> 0.081 of peak in the step, step -0.02 (bf16) / -0.06 (fp8) / -0.08 ms (long context)
   int prefetch_wgs = 0;                // workgroups of the weight prefetch one schedule step ahead (crct_engine_set_prefetch).  OFF: measured 7.79-8.04 vs 7.62-7.65 ms
@@ -508,7 +509,7 @@ struct Run {
     // a persistent grid for the group (gemm.hip, group_grid) where the throttled side stream stays off the critical path: a side
     // stream per data stream, and not the 2560 / 6400-row streams of the long-context configuration, whose data-gradient GEMMs fill the
     // chip themselves (measured there: 11.90 - 11.94 ms with the text stream's groups throttled, 11.96 - 12.04 with both, 11.80 - 11.86 without)
-    const int target = (sw != s && !e->one_wgrad_stream && !pending.empty() && pending[0].K <= e->wgrad_target_rows) ? e->wgrad_target : 0;
+    const int target = (sw != s && !pending.empty() && pending[0].K <= e->wgrad_target_rows) ? (e->one_wgrad_stream ? e->wgrad_target_shared : e->wgrad_target) : 0;
     for (int rep = 0; rep < reps; ++rep)
       for (size_t i = 0; i < pending.size() && !rc; i += 8) {
         const int ng = (int)std::min<size_t>(8, pending.size() - i);
@@ -1593,6 +1594,11 @@ extern "C" int crct_engine_set_wgrad_workgroups(crct_engine_t* e, int target_wgs
   if (!e) return 1;
   e->wgrad_target = target_wgs > 0 ? target_wgs : 0;
   e->wgrad_target_rows = max_rows;
+  return 0;
+}
+extern "C" int crct_engine_set_wgrad_workgroups_shared(crct_engine_t* e, int target_wgs) {
+  if (!e) return 1;
+  e->wgrad_target_shared = target_wgs > 0 ? target_wgs : 0;
   return 0;
 }
 extern "C" int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode) {

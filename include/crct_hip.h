@@ -631,6 +631,8 @@ int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode);
 // groups of a data stream with at most max_rows token rows, and only while every data stream has a side stream of its own (a
 // shared side stream -- the mode a gradient exchange uses -- would become the critical path).  Defaults 96 / 3000.
 int crct_engine_set_wgrad_workgroups(crct_engine_t* e, int target_wgs, int max_rows);
+// ... the target while both data streams' groups share one side stream (crct_engine_set_streams(.., 2): the mode a gradient exchange uses)
+int crct_engine_set_wgrad_workgroups_shared(crct_engine_t* e, int target_wgs);
 int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps);
 
 /* Weight prefetch: while a schedule step runs, the bf16 weights of the NEXT step (forward) / the previous one (backward) are
