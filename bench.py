@@ -588,6 +588,7 @@ def main():
         ar = (time.perf_counter() - t1) / 5
         from crct import rccl as RC
         comm = {"rccl": {"version": RC.version()[1], "env": RC.env_seen(), "route": "direct ncclAllReduce (crct/rccl.py)" if rc is not None else "torch.distributed",
+                         "direct_route_fallback_reason": getattr(ddp, "rccl_fallback", None),
                          "collectives_issued": getattr(rc, "collectives", None), "world": world,
                          "channels_logged_at_init": RC.channels_from_debug_log(rccl_log) if rccl_log else None,
                          "init_log_enabled_by_bench": bool(rccl_log)},      # NCCL_DEBUG=INFO / SUBSYS=INIT / DEBUG_FILE in env are then bench.py's

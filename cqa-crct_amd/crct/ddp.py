@@ -162,7 +162,8 @@ class FlatGradDDP(object):
         self.issued_inside_engine_call = 0      # collectives launched from the engine's callback during the last pass
         self._grad_source_valid = False
         self._materialized_last = False
-        self._rccl = None
+        self._rccl = None                    # None: not created yet; False: creation failed somewhere, torch.distributed carries the collectives
+        self.rccl_fallback = None            # why (communicator())
         self.direct_bf16_wgrad = True       # bf16 payload: the engine writes the Linear weight gradients into the communication buffer itself
         self.packed_runs_only = False
         if broadcast:      # DDP constructor semantics: rank 0's parameters win (train.py:139)
@@ -192,8 +193,26 @@ class FlatGradDDP(object):
         one (the gloo-on-one-GPU tests: the collectives then go through torch.distributed)."""
         if self._rccl is None and self.core.flat_grads.is_cuda and dist.get_backend(self.group) == "nccl":
             from .rccl import Communicator
-            self._rccl = Communicator(self.core.flat_grads.device, self.group)
-        return self._rccl
+            comm, err = None, None
+            try:
+                comm = Communicator(self.core.flat_grads.device, self.group)
+            except Exception as e:              # a failed bootstrap must not take a multi-GPU job down: torch's own RCCL group still works
+                err = e
+            # every rank takes the same route: one rank on the direct communicator and its peers on torch's group would wait for ever
+            ok = torch.tensor([0 if comm is None else 1], device=self.core.flat_grads.device, dtype=torch.int32)
+            if dist.get_world_size(self.group) > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 1:
+                self._rccl = comm
+            else:
+                if comm is not None:
+                    comm.destroy()
+                self._rccl = False
+                self.rccl_fallback = repr(err) if err is not None else "a peer rank could not create its communicator"
+                import warnings
+                warnings.warn("crct.ddp: direct RCCL communicator unavailable (%s); the gradient exchange falls back to torch.distributed's "
+                              "RCCL process group (collectives on a stream of torch's choosing: slower, same results)" % self.rccl_fallback)
+        return self._rccl or None
 
     # ------------------------------------------------------------------ what the optimizer reads
     def grad_source(self):

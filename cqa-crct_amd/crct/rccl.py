@@ -95,13 +95,18 @@ class Communicator(object):
         lib = _load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         uid = _UniqueId()
+        box = [None]
         if self.rank == 0:
-            _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]      # the raw 128 bytes (.internal would stop at a NUL)
+            rc = lib.ncclGetUniqueId(C.byref(uid))
+            # a failure here is BROADCAST (as a string) instead of raised at once: the peers are about to wait in the broadcast below
+            box = [C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if rc == 0      # the raw 128 bytes (.internal would stop at a NUL)
+                   else "ncclGetUniqueId failed on rank 0: %s" % lib.ncclGetErrorString(rc).decode()]
         if self.world > 1:
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
         raw = box[0]
+        if not isinstance(raw, bytes):
+            raise RuntimeError("RCCL %s" % raw)
         if len(raw) != NCCL_UNIQUE_ID_BYTES:       # c_char arrays stop at the first NUL when read as .value: take the raw buffer
             raise RuntimeError("ncclUniqueId has %d bytes" % len(raw))
         C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
