@@ -1964,9 +1964,12 @@ extern "C" int crct_gemm_pick_tile(int M, int N) {
 enum { CLS_W, CLS_N, CLS_NL, CLS_PER_BUCKET };
 enum { MB_S, MB_M, MB_L, MB_COUNT };
 constexpr int CLS_COUNT = MB_COUNT * CLS_PER_BUCKET;
-static int g_class_table[CLS_COUNT] = {12, 12, 15,      // S: text rows of configs[1] (and, below, every narrow GEMM of text width)
-                                       12, 12, 4,       // M: visual rows of configs[1] (nl: 128x128, 3 stages: 7.61 -> 7.56 ms)
-                                       12, 50, 50};     // L: long-context visual rows: 256x128 tiles with loader waves for the narrow outputs
+// 128 x 64 tiles everywhere they were, now with 3 stages (15) instead of 2 (12): re-swept in the step AFTER the weight gradients
+// became a persistent grid of ~96 workgroups (the data-gradient chain then has ~160 CUs to itself and a deeper ring pays): 7.43 - 7.45 ->
+// 7.31 - 7.33 ms at configs[1], 11.74 -> 11.68 long context, forced exchange 8.04 -> 7.87 (profiles/r4_class_resweep.txt)
+static int g_class_table[CLS_COUNT] = {15, 15, 15,      // S: text rows of configs[1] (and, below, every narrow GEMM of text width)
+                                       15, 15, 4,       // M: visual rows of configs[1] (nl: 128x128, 3 stages: 7.61 -> 7.56 ms)
+                                       15, 50, 50};     // L: long-context visual rows: 256x128 tiles with loader waves for the narrow outputs
                                                         //    (in-step sweep, profiles/r4_longctx_class_sweep.txt: 12.11 -> 12.04 each, 11.95 -> 11.79 ms
                                                         //    together with the text-width rule below; every other entry measured neutral or worse)
 extern "C" int crct_gemm_class_config(int cls, int cfg) {
