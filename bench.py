@@ -49,6 +49,7 @@ from crct import synthetic as S           # noqa: E402
 from crct import lib as L                 # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP8_SCALED_TFLOPS = 5000.0           # ... ~5 PF dense fp8 through the block-scaled MFMA the fp8 GEMMs issue (the plain fp8 MFMA runs at the bf16 rate)
 FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9}   # SURVEY.md 8d, fwd+bwd
 VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
@@ -57,8 +58,7 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               18: "reg64x128", 19: "reg64x64", 20: "f8e4m3_128x64w8s2", 21: "f8e4m3_128x64w8s3", 22: "dma160x128w4s2", 23: "dma160x128w4s3",
               24: "dma160x96w4s3", 25: "dma160x96w4s2", 26: "dma96x64w4s3", 27: "dma96x64w4s4", 28: "dma160x64w4s3", 29: "dma64x96w4s4", 30: "dma160x128w4s3p", 31: "dma160x128w4s2p",
               32: "dma128x128w4s3p", 33: "dma128x128w8s3p", 34: "dma256x128w8s3p", 35: "dma160x96w4s3p",
-              36: "f8t_128x128w8s3", 37: "f8t_128x128w8s2", 38: "pp128x64w8s3", 39: "pp128x128w8s3", 40: "pp128x64w8s4", 41: "pp128x128w8s3b",
-              42: "pp256x128w8s3", 43: "pp64x128w8s3", 44: "pp256x64w8s3", 45: "pp128x128w8s4", 46: "ldr128x64w8+4s3", 47: "ldr128x64w8+4s2",
+              36: "f8t_128x128w8s3", 37: "f8t_128x128w8s2", 46: "ldr128x64w8+4s3", 47: "ldr128x64w8+4s2",
               48: "ldr128x128w8+4s3", 49: "ldr128x128w8+4s2", 50: "ldr256x128w8+4s3", 51: "ldr128x64w8+4s4", 52: "ldr128x64w8+2s3",
               53: "ldr128x128w4+4s3", 54: "ldr128x64w4+2s3", 55: "ldr256x128w8+4s2", 56: "ldrp128x64w4+2s3", 57: "ldrp128x64w8+4s3",
               58: "ldrp128x128w4+4s3", 59: "ldrp128x128w8+4s3", 61: "ldrp128x64w4+2s4", 62: "ldrp128x128w4+4s2",
@@ -102,18 +102,14 @@ def parse():
                     "ranks would draw (batch R x --batch): the run a data-parallel R-rank run must agree with (config.global_loss)")
     ap.add_argument("--no-dropout", action="store_true", help="test hook: dropout probabilities 0 (run-to-run and rank-count independent losses)")
     ap.add_argument("--exchange-skip", default="", help="timing experiment: comma list of exchange parts to leave out (pack, collective, stats)")
-    ap.add_argument("--prefetch-wgs", type=int, default=-1, help="workgroups of the engine's weight prefetch (0 = off; default: the engine's)")
     ap.add_argument("--vis-stream", type=int, default=1, help="0: the visual stream's layers on the caller's stream (developer timing experiment)")
     ap.add_argument("--embed-scatter-split", action="store_true", help="developer A/B: the text embedding's backward sums and scatter as two launches")
     ap.add_argument("--wgrad-concat", type=int, default=-1, help="developer A/B: 0 = per-problem XCD rectangles for the grouped weight gradients (crct_gemm_group_concat)")
-    ap.add_argument("--wgrad-defer-sim", type=int, default=0, help="TIMING ONLY (wrong gradients): drop the co-attention-phase layers' weight-gradient "
-                    "launches and run the text-only tail's 1 + N times (prices a deferral policy; crct_engine_set_wgrad_defer_sim)")
     ap.add_argument("--wgrad-flush", type=int, default=-1, help="developer A/B: flush points of a layer's queued weight gradients (crct_engine_set_wgrad_flush)")
     ap.add_argument("--wgrad-cfg", type=int, default=-1, help="developer A/B: kernel configuration of the grouped weight-gradient launches (crct_gemm_group_wgrad_config)")
     ap.add_argument("--wgrad-wgs", type=int, default=-1, help="cap on the workgroups of a layer's grouped weight-gradient launch (0 = one per tile)")
     ap.add_argument("--wgrad-target-wgs", type=int, default=-1, help="developer A/B: target size of the persistent grid of the engine's grouped bf16 "
                     "weight-gradient launches (crct_engine_set_wgrad_workgroups; 0 = one workgroup per tile, the engine's default is 96)")
-    ap.add_argument("--wgrad-target-shared", type=int, default=-1, help="developer A/B: the same target while the weight gradients share one side stream (the exchange mode)")
     ap.add_argument("--wgrad-target-rows", type=int, default=3000, help="developer A/B: ... for data streams of at most this many token rows")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="weight-gradient side streams of the engine: 1 = one per data stream, 2 = ONE shared "
                     "stream (default: 1 without a gradient exchange, 2 with one -- the exchange then has a hardware queue to itself)")
@@ -133,6 +129,9 @@ def parse():
                     "(crct_gemm_class_config; classes S.w S.n S.nl M.w M.n M.nl L.w L.n L.nl), e.g. L.w=9,L.n=9; reported in config.class_policy")
     ap.add_argument("--launch-log", default="", help="developer tooling: write the GEMM launch log of the timed region to this JSON file "
                     "(tools/pmc_sites.py matches it against a rocprofv3 counter collection)")
+    ap.add_argument("--rank-timeout-s", type=float, default=600.0, help="`python bench.py --gpus N` as its own launcher: seconds after which the parent "
+                    "ends every rank it started and exits non-zero (a rank stuck in the RCCL bootstrap would otherwise hold the job until the "
+                    "driver's own limit); each rank's last stderr lines are relayed")
     ap.add_argument("--launch-check", action="store_true", help="test hook: every rank reports its rendezvous environment (rank 0 as the JSON line) and "
                     "exits before touching a GPU -- the self-launch path of `python bench.py --gpus N` checked on a box without GPUs")
     ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
@@ -176,27 +175,84 @@ def gemm_profile(run_step, n_steps):
     return rows, sites
 
 
+def critical_path(run_step, core, n_steps):
+    """config.critical_path: what the step's launch structure looks like from inside the process.  During `n_steps` extra steps EVERY
+    kernel the library launches carries a start / stop event pair (crct_prof_enable(2): hipExtLaunchKernelGGL stamps, the figures
+    rocprofv3's kernel trace reports) and is remembered with its HIP stream: launches per step, kernels and busy time per stream
+    (= hardware queue: the engine places its streams on distinct queues, csrc/streams.hip), and how long k kernels were in flight at
+    once.  The text data stream is the step's dependent chain (282 of ~625 launches in round 4): its kernel count and busy time are
+    what a fusion has to shorten.  Stock-torch kernels of the step (the output snapshot, autograd's seed) are not stamped."""
+    lib = L.load()
+    lib.crct_prof_reset()
+    torch.cuda.synchronize()
+    lib.crct_prof_enable(2)
+    for _ in range(n_steps):
+        run_step()
+    torch.cuda.synchronize()
+    lib.crct_prof_enable(0)
+    n = lib.crct_prof_stamp_count()
+    names = {torch.cuda.current_stream().cuda_stream: "text (caller's stream)"}
+    eng = core._engine
+    if eng is not None:
+        arr = (C.c_void_p * 4)()
+        if lib.crct_engine_streams(eng.handle, arr) == 0:
+            for ptr, nm in zip(arr, ("visual", "weight gradients (text)", "weight gradients (visual)", "auxiliary (AdamW / exchange)")):
+                if ptr:
+                    names.setdefault(ptr, nm)
+    per, edges = {}, []
+    st, t0, t1 = C.c_void_p(), C.c_double(), C.c_double()
+    for i in range(n):
+        if lib.crct_prof_stamp_read(i, C.byref(st), C.byref(t0), C.byref(t1)) != 0:
+            continue
+        q = per.setdefault(names.get(st.value, "stream %#x" % (st.value or 0)), dict(kernels=0, busy_ms=0.0, first=t0.value, last=t1.value))
+        q["kernels"] += 1
+        q["busy_ms"] += t1.value - t0.value
+        q["first"], q["last"] = min(q["first"], t0.value), max(q["last"], t1.value)
+        edges += [(t0.value, 1), (t1.value, -1)]
+    lib.crct_prof_reset()
+    edges.sort()
+    in_flight, depth, prev = {}, 0, None
+    for t, d in edges:
+        if prev is not None and t > prev:
+            in_flight[depth] = in_flight.get(depth, 0.0) + (t - prev)
+        depth += d
+        prev = t
+    span = (edges[-1][0] - edges[0][0]) if edges else 0.0
+    return {"steps_profiled": n_steps, "launches_per_step": n / max(n_steps, 1),
+            "queues": {k: {"kernels_per_step": v["kernels"] / n_steps, "busy_ms_per_step": v["busy_ms"] / n_steps} for k, v in sorted(per.items())},
+            "ms_with_k_kernels_in_flight_per_step": {str(k): v / n_steps for k, v in sorted(in_flight.items())},
+            "span_ms_per_step": span / max(n_steps, 1),
+            "note": "library kernels only (every launch stamped with hipExtLaunchKernelGGL start / stop events on its own stream); the stamped "
+                    "steps are host-bound (an event pair per launch), so kernels of different streams overlap less than in the timed step"}
+
+
 FFN_SITES = ("t.ffn_up", "t.ffn_down", "v.ffn_up", "v.ffn_down")
 
 
-def ffn_roofline(sites, n_profiled):
-    """fraction of the FFN-GEMM roofline = sum of FFN GEMM FLOPs / sum of their kernel time / peak."""
+def ffn_roofline(sites, n_profiled, kind_peak=None):
+    """fraction of the FFN-GEMM roofline = sum of FFN GEMM FLOPs / sum of their kernel time / peak.
+    kind_peak: dense MFMA peak (TFLOP/s) of the instruction each pass issues -- 2500 for bf16 (and the plain fp8 MFMA, which runs at the
+    bf16 rate), 5000 where the fp8 GEMMs issue v_mfma_scale_f32_16x16x128_f8f6f4 (twice the rate; MI355X_MICROARCH.md).  A group that
+    mixes instructions is priced by the time its FLOPs would take at each kernel's own peak."""
     by = {r["kernel"]: r for r in sites}
+    kind_peak = kind_peak or {}
+    pk = lambda k: kind_peak.get(k, PEAK_BF16_TFLOPS)      # noqa: E731
 
     def group(kinds):
-        sel = [by["%s.%s" % (s, k)] for s in FFN_SITES for k in kinds if "%s.%s" % (s, k) in by]
+        sel = [(by["%s.%s" % (s, k)], k) for s in FFN_SITES for k in kinds if "%s.%s" % (s, k) in by]
         if not sel:
             return None
-        fl = sum(r["gflop_per_launch"] * r["launches_per_step"] for r in sel)        # GFLOP per step
-        ms = sum(r["ms_per_step"] for r in sel)
-        n = sum(r["launches_per_step"] for r in sel)
-        return dict(gflop_per_step=fl, ms_per_step=ms, launches_per_step=n, tflops=fl / ms, frac=fl / ms / PEAK_BF16_TFLOPS)
+        fl = sum(r["gflop_per_launch"] * r["launches_per_step"] for r, _ in sel)        # GFLOP per step
+        ms = sum(r["ms_per_step"] for r, _ in sel)
+        n = sum(r["launches_per_step"] for r, _ in sel)
+        ideal_ms = sum(r["gflop_per_launch"] * r["launches_per_step"] / pk(k) for r, k in sel)      # GFLOP / (TFLOP/s) = ms
+        return dict(gflop_per_step=fl, ms_per_step=ms, launches_per_step=n, tflops=fl / ms, frac=ideal_ms / ms, peak=fl / ideal_ms)
     out = dict(fwd_dgrad=group(("fwd", "dgrad")), with_wgrad_apportioned=group(("fwd", "dgrad", "wgrad")))
     for s in FFN_SITES:
         for k in ("fwd", "dgrad", "wgrad"):
             r = by.get("%s.%s" % (s, k))
             if r:
-                out["%s.%s" % (s, k)] = dict(gflop=r["gflop_per_launch"], us=r["us_per_launch"], frac=r["frac_of_bf16_peak"])
+                out["%s.%s" % (s, k)] = dict(gflop=r["gflop_per_launch"], us=r["us_per_launch"], frac=r["tflops"] / pk(k), peak=pk(k))
     return out
 
 
@@ -272,38 +328,54 @@ def cpu_baseline(core, cfg, params, B, T, V, Fv, budget_s=20.0, max_threads=16):
                        % (reps, Bs, probe, budget_s, V, T, Fv, dt, threads, os.cpu_count() or 1, cpu_model()))
 
 
-def launch_ranks(n):
+def launch_ranks(n, timeout_s=600.0):
     """``python bench.py --gpus N`` without a launcher: start one fresh child process per GPU -- what the reference does with
     ``mp.spawn(run_training_DDP, nprocs=num_proc)`` (CRCT/train.py:356-363) -- each running this same command line with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, exit with the worst child's code.  The parent
     never touches a GPU and never exec()s: the children are ordinary subprocesses (a process that has initialised the GPU
-    must not be replaced, and this one has not even done that)."""
+    must not be replaced, and this one has not even done that).  ``timeout_s``: after that long the parent ends every rank it
+    started (exactly those PIDs) and returns 124 -- ranks blocked in the RCCL bootstrap never return by themselves.  Every rank's
+    stderr passes through the parent (line by line, as it comes), which keeps the last lines of each to say who was where."""
+    import collections
     import socket
     import subprocess
+    import threading
     with socket.socket() as sock:                    # a free rendezvous port on the loopback interface
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
-    procs = []
+    procs, tails, pumps = [], [], []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         # rank 0's stdout carries the ONE JSON line; the other ranks' stdout goes to our stderr (they print nothing by design)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    import threading
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=subprocess.PIPE))
+        tails.append(collections.deque(maxlen=12))
 
-    def relay():                                     # rank 0's stdout, line by line as it comes (bytes: no decoding surprises)
+    def relay_out():                                 # rank 0's stdout, line by line as it comes (bytes: no decoding surprises)
         for line in procs[0].stdout:
             sys.stdout.buffer.write(line)
             sys.stdout.buffer.flush()
-    pump = threading.Thread(target=relay, daemon=True)
-    pump.start()
-    worst = 0
+
+    def relay_err(r):
+        for line in procs[r].stderr:
+            tails[r].append(line)
+            sys.stderr.buffer.write(line)
+            sys.stderr.buffer.flush()
+    pumps.append(threading.Thread(target=relay_out, daemon=True))
+    pumps += [threading.Thread(target=relay_err, args=(r,), daemon=True) for r in range(n)]
+    for t in pumps:
+        t.start()
+    worst, timed_out = 0, False
+    t_end = time.monotonic() + timeout_s if timeout_s and timeout_s > 0 else None
     try:
         live = list(procs)
         while live:                                  # a rank that dies takes the job down: its peers would wait in a collective for ever
             time.sleep(0.05)
+            if t_end is not None and time.monotonic() > t_end:
+                timed_out = True
+                break
             for p in list(live):
                 rc = p.poll()
                 if rc is None:
@@ -314,15 +386,27 @@ def launch_ranks(n):
                         worst = rc
                     for q in live:
                         q.terminate()
-        pump.join(timeout=10)
     finally:
-        for p in procs:                              # a rank that outlived a failed peer: end exactly the PIDs started here
+        for p in procs:                              # a rank that outlived a failed peer / the time limit: end exactly the PIDs started here
             if p.poll() is None:
                 p.terminate()
                 try:
                     p.wait(timeout=10)
                 except subprocess.TimeoutExpired:
                     p.kill()
+        for t in pumps:
+            t.join(timeout=10)
+    if timed_out or worst != 0:
+        why = "no result after --rank-timeout-s %.0f s: every rank ended by the launcher" % timeout_s if timed_out else "a rank failed (exit code %d)" % worst
+        sys.stderr.write("bench.py launcher: %s\n" % why)
+        for r in range(n):
+            rc = procs[r].poll()
+            sys.stderr.write("  rank %d (exit %s), last stderr lines:\n" % (r, rc))
+            for line in tails[r]:
+                sys.stderr.write("    | " + line.decode(errors="replace").rstrip() + "\n")
+        sys.stderr.flush()
+    if timed_out:
+        return 124
     return worst if 0 <= worst < 256 else 1
 
 
@@ -331,7 +415,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us (the driver's 1-GPU command shape, `python bench.py --gpus N ...`): be the launcher.  Nothing
         # above this line touches a GPU (importing torch does not; the library is only dlopen()ed later, in the ranks).
-        sys.exit(launch_ranks(a.gpus))
+        sys.exit(launch_ranks(a.gpus, a.rank_timeout_s))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -341,6 +425,10 @@ def main():
     if a.launch_check:
         if os.environ.get("CRCT_LAUNCH_CHECK_FAIL_RANK") == str(rank):       # (only read under --launch-check: a rank that dies must take the job down)
             raise SystemExit(7)
+        if os.environ.get("CRCT_LAUNCH_CHECK_HANG_RANK") == str(rank):       # (... and one that never comes back must run into --rank-timeout-s)
+            sys.stderr.write("rank %d: waiting for a peer that never comes\n" % rank)
+            sys.stderr.flush()
+            time.sleep(3600)
         info = dict(rank=rank, local_rank=local, world=world, master="%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
                     ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
         print(json.dumps(info) if rank == 0 else "rank %d: %s" % (rank, info), flush=True)
@@ -406,8 +494,6 @@ def main():
     # hardware queue to itself -- a collective that really moves data must not sit in a compute stream's queue
     if a.wgrad_wgs >= 0:
         L.load().crct_gemm_group_max_workgroups(a.wgrad_wgs)
-    if a.wgrad_target_shared >= 0:
-        core.wgrad_workgroups_shared = a.wgrad_target_shared
     if a.wgrad_target_wgs >= 0:
         core.wgrad_workgroups = (a.wgrad_target_wgs, a.wgrad_target_rows)
     if a.wgrad_concat >= 0:
@@ -423,9 +509,6 @@ def main():
         L.load().crct_embed_scatter_split(1)
     wg_mode = a.wgrad_streams if a.wgrad_streams >= 0 else (2 if (world > 1 or a.force_exchange) else 1)
     core.stream_mode = (a.vis_stream, wg_mode)
-    if a.prefetch_wgs >= 0:
-        core.prefetch_workgroups = a.prefetch_wgs
-    core.wgrad_defer_sim = a.wgrad_defer_sim
     if a.wgrad_flush >= 0:
         core.wgrad_flush = a.wgrad_flush
     model.train()
@@ -604,6 +687,18 @@ def main():
 
     # profiled steps run on EVERY rank (they contain the collectives of a normal step); only rank 0 reads the stamps
     rows, sites = gemm_profile(run_step, a.profile_steps) if a.profile_steps > 0 else ([], [])
+    # ... and so do the stamped steps behind config.critical_path (every library kernel with its own begin / end stamps)
+    crit = critical_path(run_step, core, min(a.profile_steps, 2)) if a.profile_steps > 0 else None
+    # the instruction each pass of the fp8 mode issues decides the peak its GEMMs are priced against: the block-scaled fp8 MFMA
+    # (v_mfma_scale_f32_16x16x128_f8f6f4, unit scales) runs at twice the bf16 rate -- 5 PFLOP/s dense (MI355X_MICROARCH.md)
+    kind_peak = {}
+    if a.dtype == "fp8" and not a.fp8_plain_mfma:
+        if not a.fp8_bf16_forward:
+            kind_peak["fwd"] = PEAK_FP8_SCALED_TFLOPS
+        if not a.fp8_forward_only:
+            kind_peak["dgrad"] = PEAK_FP8_SCALED_TFLOPS
+            if not a.fp8_bf16_wgrad:
+                kind_peak["wgrad"] = PEAK_FP8_SCALED_TFLOPS
     if rank == 0:
         flop_qa = FLOP_PER_QA.get((a.vis, a.tokens, a.feat))
         out = {"metric": "QA-pairs/sec training step (whole node)", "value": qa_per_s, "unit": "QA-pairs/s", "n_gpus": world,
@@ -620,24 +715,37 @@ def main():
                           "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                           "global_loss": global_loss, "input": a.input, "host_enqueue_ms_per_step": host_ms,
                           "sustained": sustained, "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None, "class_policy": a.class_policy or None,
+                          "critical_path": crit,
+                          # every developer switch that changes what the step launches (all defaults: the measured step is the product)
+                          "schedule": {"weight_gradient_streams": wg_mode, "visual_stream": a.vis_stream, "wgrad_flush": a.wgrad_flush if a.wgrad_flush >= 0 else "default (1)",
+                                       "wgrad_cfg": a.wgrad_cfg if a.wgrad_cfg >= 0 else "default (4)", "wgrad_max_workgroups": a.wgrad_wgs if a.wgrad_wgs >= 0 else None,
+                                       "wgrad_target_workgroups": [a.wgrad_target_wgs, a.wgrad_target_rows] if a.wgrad_target_wgs >= 0 else "default (96, 3000)",
+                                       "wgrad_concat": a.wgrad_concat if a.wgrad_concat >= 0 else 0, "optimizer_overlap": not a.no_opt_overlap, "optimizer_early": bool(a.opt_early),
+                                       "adamw_workgroups": a.adamw_wgs if a.adamw_wgs >= 0 else "default (256)", "eager_zero_grad": bool(a.eager_zero_grad),
+                                       "fuse_zero_grad": bool(a.fuse_zero_grad), "exchange_skip": a.exchange_skip or None, "ln_fold": core.ln_fold,
+                                       "fused_heads": core.fused_heads},
                           "gemm_sites": sites, "gemm_variants": rows}}
+        if h2d is not None:      # the PCIe-inclusive rate next to `value` (SURVEY.md 8d defines the step with its H2D copy; the bench contract's `value` is HBM-resident)
+            out["value_h2d_inclusive"] = h2d["qa_pairs_per_s"]
+            out["ms_per_step_h2d_inclusive"] = h2d["ms_per_step"]
         if flop_qa:
             out["config"]["step_model_flops_frac_of_bf16_peak"] = qa_per_s * flop_qa / (world * PEAK_BF16_TFLOPS * 1e12)
         if sites:
-            ffn = ffn_roofline(sites, a.profile_steps)
+            ffn = ffn_roofline(sites, a.profile_steps, kind_peak)
             grp = ffn["fwd_dgrad"]
             dom = max(rows, key=lambda r: r["ms_per_step"])
             traffic = pmc_traffic(["%s.%s" % (s, k) for s in FFN_SITES for k in ("fwd", "dgrad")], (a.batch, a.vis, a.tokens, a.feat), a.dtype)
             out["roofline"] = {"bound": "mfma", "kernel": "FFN GEMMs: text / visual FFN-up + FFN-down, forward + data gradient (%d launches per step)"
                                                              % round(grp["launches_per_step"]),
-                               "achieved": grp["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": grp["frac"], "traffic": traffic,
+                               "achieved": grp["tflops"], "peak": grp["peak"], "unit": "TFLOP/s", "frac": grp["frac"], "traffic": traffic,
+                               "peak_by_pass": {k: kind_peak.get(k, PEAK_BF16_TFLOPS) for k in ("fwd", "dgrad", "wgrad")},
                                "gflop_per_launch": grp["gflop_per_step"] / grp["launches_per_step"],
                                "us_per_launch": grp["ms_per_step"] * 1e3 / grp["launches_per_step"], "ffn": ffn,
                                "largest_kernel_class": {"kernel": dom["kernel"], "tflops": dom["tflops"], "frac": dom["tflops"] / PEAK_BF16_TFLOPS,
                                                         "ms_per_step": dom["ms_per_step"]},
                                "timing": "kernel begin / end stamps (hipExtLaunchKernelGGL start / stop events), %d profiled steps, in the step "
                                          "(other streams' kernels run beside each launch)" % a.profile_steps}
-        if world == 1 and not a.no_cpu_baseline:
+        if not a.no_cpu_baseline:      # rank 0 only, after the timed region (its peers wait at the closing barrier meanwhile)
             out["cpu_baseline"] = cpu_baseline(core, cfg, params, a.cpu_batch, a.tokens, a.vis, a.feat)
         print(json.dumps(out), flush=True)
     if prefetcher is not None:

@@ -186,7 +186,11 @@ class FlatGradDDP(object):
         ``grad_source()``).  Decided per pass: the optimizer may be built before or after this object (train.py:85 / :139)."""
         if self.materialize_grads is not None:
             return self.materialize_grads
-        return getattr(self.core, "_fused_optimizer", None) is None
+        # the optimizer that actually steps: FusedAdamW registers itself as a weak reference (an optimizer that was built and
+        # thrown away does not count) and only one that updates EVERY gradient-receiving tensor may leave the fp32 views unwritten
+        ref = getattr(self.core, "_fused_optimizer", None)
+        opt = ref() if callable(ref) else None
+        return not (opt is not None and opt.covers_every_gradient())
 
     def communicator(self):
         """The RCCL communicator of the exchange (crct/rccl.py), created on first use; None when the process group is not an RCCL
@@ -292,6 +296,7 @@ class FlatGradDDP(object):
         self._grad_source_valid = False
         if not self.require_sync or (self.world == 1 and not self.force_exchange):
             self.last_exchange = None
+            self._poisoned_at = None      # this pass writes LOCAL fp32 gradients into the owned views: a later exchange must refill the NaNs
             self._place_wgrad_streams(core, eng, False)
             eng.backward(core.flat_params, core.flat_shadow, core.flat_grads, tensors, step, -1)
             return

@@ -115,6 +115,9 @@ PROTOTYPES = {
     "crct_prof_reset": (C.c_int, []),
     "crct_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "crct_prof_read_site": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "crct_prof_stamp_count": (C.c_int, []),
+    "crct_prof_stamp_read": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "crct_engine_streams": (C.c_int, [vp, C.POINTER(vp)]),
     "crct_launch_log_enable": (C.c_int, [C.c_int]),
     "crct_launch_log_count": (C.c_int, []),
     "crct_launch_log_read": (C.c_int, [C.c_int, C.POINTER(LaunchRec)]),
@@ -132,20 +135,14 @@ PROTOTYPES = {
     "crct_softmax_rows_f32_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_softmax_rows_bf16_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_layernorm_fwd_q": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp, vp, vp, vp]),
-    "crct_layernorm_fwd_pair": (C.c_int, [C.POINTER(LnFwdArgs), C.POINTER(LnFwdArgs), vp]),
-    "crct_layernorm_bwd_rows_pair": (C.c_int, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), vp]),
     "crct_layernorm_bwd_rows_args": (C.c_int, [C.POINTER(LnBwdArgs), vp]),
     "crct_fp8_transpose_weights": (C.c_int, [vp] * 6 + [C.c_int, c_i64, C.c_int, vp]),
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
     "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, c_f32, vp]),
     "crct_fp8_quantize_weights": (C.c_int, [vp] * 7 + [c_i64, vp, vp, C.c_int, vp]),
-    "crct_prefetch": (C.c_int, [vp, c_i64, C.c_int, vp]),
     "crct_gemm_group_wgrad_config": (C.c_int, [C.c_int]),
-    "crct_lab_xcd_band": (C.c_int, [C.c_int]),
-    "crct_engine_set_wgrad_defer_sim": (C.c_int, [vp, C.c_int]),
     "crct_engine_set_wgrad_flush": (C.c_int, [vp, C.c_int]),
     "crct_engine_set_wgrad_workgroups": (C.c_int, [vp, C.c_int, C.c_int]),
-    "crct_engine_set_wgrad_workgroups_shared": (C.c_int, [vp, C.c_int]),
     "crct_gemm_class_config": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_fp8_scaled_mfma": (C.c_int, [C.c_int]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
@@ -183,8 +180,6 @@ PROTOTYPES = {
     "crct_stream_wait_event": (C.c_int, [vp, vp]),
     "crct_event_synchronize": (C.c_int, [vp]),
     "crct_event_query": (C.c_int, [vp]),
-    "crct_engine_set_pairing": (C.c_int, [vp, C.c_int]),
-    "crct_engine_set_prefetch": (C.c_int, [vp, C.c_int]),
     "crct_engine_wgrad_owned": (C.c_int, [vp, vp, vp, C.c_int]),
     "crct_engine_fp8_sites": (C.c_int, [vp]),
     "crct_engine_fp8_grad_sites": (C.c_int, [vp]),

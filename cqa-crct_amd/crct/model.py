@@ -135,6 +135,10 @@ class CrctModel(nn.Module):
         self._grad_waits = None
         self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
+        # launch-count levers of round 5: LayerNorm forward folded into the neighbouring GEMMs, the 13-Linear head
+        # chain as one kernel per pass.  params['ln_fold'] / params['fused_heads'] = False restore one launch per operator (A/B, tests).
+        self.ln_fold = False
+        self.fused_heads = False
         self.init_weights(int(params.get("seed", 0)))
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate_shadow())
 
@@ -433,16 +437,10 @@ class CrctModel(nn.Module):
             self._engine = StepEngine(self.config, self.params, mb, mt, mv, self._flat_p.device, self.cls_dropout)
             for pol in getattr(self, "site_policy", ()):          # developer / test overrides of the per-site launch policy
                 self._engine.set_site_policy(**pol)
-            if getattr(self, "prefetch_workgroups", None) is not None:
-                L.check(self._engine.lib.crct_engine_set_prefetch(self._engine.handle, int(self.prefetch_workgroups)), "set_prefetch")
             if getattr(self, "wgrad_workgroups", None) is not None:      # (target, max rows) of crct_engine_set_wgrad_workgroups
                 L.check(self._engine.lib.crct_engine_set_wgrad_workgroups(self._engine.handle, int(self.wgrad_workgroups[0]), int(self.wgrad_workgroups[1])), "set_wgrad_workgroups")
-            if getattr(self, "wgrad_workgroups_shared", None) is not None:
-                L.check(self._engine.lib.crct_engine_set_wgrad_workgroups_shared(self._engine.handle, int(self.wgrad_workgroups_shared)), "set_wgrad_workgroups_shared")
             if getattr(self, "wgrad_flush", None) is not None:    # where a layer's weight gradients leave for the side stream (crct_engine_set_wgrad_flush)
                 L.check(self._engine.lib.crct_engine_set_wgrad_flush(self._engine.handle, int(self.wgrad_flush)), "set_wgrad_flush")
-            if getattr(self, "wgrad_defer_sim", 0):               # developer timing experiment (bench.py --wgrad-defer-sim)
-                L.check(self._engine.lib.crct_engine_set_wgrad_defer_sim(self._engine.handle, int(self.wgrad_defer_sim)), "set_wgrad_defer_sim")
             mode = getattr(self, "stream_mode", None)             # (use_visual_stream, use_wgrad_streams) of crct_engine_set_streams
             if mode is not None:
                 L.check(self._engine.lib.crct_engine_set_streams(self._engine.handle, int(mode[0]), int(mode[1])), "set_streams")

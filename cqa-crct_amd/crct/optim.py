@@ -82,7 +82,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step_dev, self._amp_arg, self._amp_keep = None, None, None
         self._fp8_keep = None
         self._g16 = None                     # bf16 gradient source of the running update (data-parallel bf16 exchange), else None
-        core._fused_optimizer = self         # crct/ddp.py: with this optimizer attached a bf16 exchange need not write the weight gradients back to fp32
+        # crct/ddp.py: while THIS optimizer is alive and covers every gradient, a bf16 exchange need not write the weight gradients
+        # back to fp32 (a weak reference: an optimizer that was built and discarded must not change what .grad holds)
+        import weakref
+        core._fused_optimizer = weakref.ref(self)
         # overlap mode: the update runs as one launch per engine backward-segment on its own stream, in first-use
         # order, each followed by an event; the next forward waits for segment s right before it needs it, so
         # AdamW (HBM-bound, ~1.2 ms) and the gradient memset overlap the next step's forward
@@ -113,6 +116,11 @@ class FusedAdamW(torch.optim.Optimizer):
             self.state[p] = dict(step=torch.tensor(0.0), exp_avg=self._m[e.offset:e.offset + e.numel].view(e.shape),
                                  exp_avg_sq=self._v[e.offset:e.offset + e.numel].view(e.shape))
         self._byname = byname
+
+    def covers_every_gradient(self):
+        """Does this optimizer update every tensor that receives a gradient?  (One built over a parameter subset leaves the rest to
+        somebody who reads ``.grad``.)"""
+        return len(self._segs) == len(self._used)
 
     def set_early(self, on=True):
         """Overlap the update with the rest of backward (needs ``overlap``); see ``early`` above."""

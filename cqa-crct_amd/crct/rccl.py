@@ -92,8 +92,26 @@ class Communicator(object):
     """One RCCL communicator over the ranks of ``group`` (default: the world), created on ``device``."""
 
     def __init__(self, device, group=None):
-        lib = _load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device(device)
+        # Every stage that can fail on ONE rank is agreed on by ALL ranks before anyone enters the next collective: a rank that
+        # raised here while its peers went on into the broadcast / ncclCommInitRank below would leave them waiting for ever.
+        # Stage 1: the library loads everywhere (MIN over an ok flag).  Stage 2: rank 0's ncclGetUniqueId result travels in the
+        # broadcast itself (the id, or the error text).  Stage 3, ncclCommInitRank, is itself the rendezvous: a failure of only
+        # SOME ranks inside it cannot be recovered from here (the others block in RCCL's bootstrap until its own timeout).
+        lib, load_err = None, None
+        try:
+            lib = _load()
+        except Exception as e:              # noqa: BLE001 -- reported to every rank below
+            load_err = e
+        if self.world > 1:
+            flag_dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            ok = torch.tensor([0 if lib is None else 1], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) != 1:
+                raise RuntimeError("RCCL could not be loaded on %s: %r" % ("this rank" if lib is None else "a peer rank", load_err))
+        elif lib is None:
+            raise load_err
         uid = _UniqueId()
         box = [None]
         if self.rank == 0:
@@ -111,12 +129,12 @@ class Communicator(object):
             raise RuntimeError("ncclUniqueId has %d bytes" % len(raw))
         C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self.comm = C.c_void_p()
-        self.device = torch.device(device)
         with torch.cuda.device(self.device):
             _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
         n = C.c_int(-1)
         _check(lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
         if n.value != self.world:
+            self.destroy()                  # not leaked: the caller falls back to torch.distributed's group
             raise RuntimeError("RCCL communicator spans %d ranks, expected %d" % (n.value, self.world))
         self.collectives = 0
 

@@ -374,7 +374,7 @@ hipError_t launch_one(const AttnArgs& a, size_t lds, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_lds = 160 * 1024;
   }
-  hipLaunchKernelGGL(kern, dim3(a.B * a.heads), dim3(256), lds, s, a);
+  crct_launch(kern, dim3(a.B * a.heads), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

@@ -557,7 +557,7 @@ hipError_t launch_sp(const AttnArgs& a, hipStream_t s) {
     raised = true;
   }
   const int total = a.B * a.heads;
-  hipLaunchKernelGGL(kern, dim3((total + W - 1) / W), dim3(64 * W * SP), BYTES * W, s, a);
+  crct_launch(kern, dim3((total + W - 1) / W), dim3(64 * W * SP), BYTES * W, s, a);
   return hipGetLastError();
 }
 // Waves per (batch, head): 4 when both sides have at least four tiles, 2 with at least two (each wave then owns whole query

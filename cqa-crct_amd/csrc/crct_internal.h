@@ -1,6 +1,7 @@
 // Internal declarations shared by the kernel translation units and the step engine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "../../include/crct_hip.h"
 
 void crct_set_error(const char* fmt, ...);
@@ -27,12 +28,20 @@ hipError_t crct_gemm_launch_grouped_wgs(const CrctGemmArgs* gs, int n, hipStream
 // streams.hip: three streams on hardware queues other than main's (+ a second one on the last queue), found by probing
 int crct_streams_place(hipStream_t main, hipStream_t out[4], int* n_classes);
 
-// Lab hook (crct_lab_xcd_band): > 0 = rows per XCD band.  The GEMM tile maps then give XCD x (= block % 8)
-// the row tiles of band x and ALL column tiles, and the LayerNorm forward maps workgroup b to rows of band b % 8 -- an
-// activation row is produced and consumed on one XCD (its private L2) through a LayerNorm -> GEMM -> GEMM chain.  0 (the product):
-// the rectangle maps of make_tile_map / rows dealt round-robin.  Placement only ever affects speed.
-extern int g_crct_lab_band_rows;
-
 // upper bound of the workgroup count of the LayerNorm-backward style kernels (4 rows per workgroup and pass):
 // sizes the column-partials scratch [partials][blocks][H]
 #define CRCT_LN_BWD_MAX_BLOCKS 256
+
+// ---- live stamps of EVERY kernel the library launches (crct_prof_enable(2); bench.py config.critical_path): while armed, a launch is
+// dispatched with a start / stop event pair (hipExtLaunchKernelGGL: the begin / end stamps of that kernel, what rocprofv3's kernel
+// trace reports) and remembered with its stream.  Off (the product): one predictable branch per launch.
+bool crct_stamp_begin(hipStream_t s, hipEvent_t* start, hipEvent_t* stop);      // streams.hip; false = stamping is off
+void crct_stamp_adopt(hipStream_t s, hipEvent_t start, hipEvent_t stop);        // a GEMM launch that carries its own event pair (gemm.hip)
+void crct_stamp_enable(int on);
+void crct_stamp_reset(void);
+template <class K, class... A>
+inline void crct_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... a) {
+  hipEvent_t e0, e1;
+  if (crct_stamp_begin(s, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, e0, e1, 0u, a...);
+  else hipLaunchKernelGGL(kern, grid, block, lds, s, a...);
+}

@@ -145,19 +145,10 @@ struct crct_engine {
   // internal concurrency: the visual stream's layers and all weight-gradient GEMMs run on side HIP
   // streams, ordered against the caller's stream by events (fork / join inside every call)
   bool use_vis_stream = true, use_wgrad_stream = true, streams_forced = false;
-  int defer_sim = 0;                   // timing experiment (crct_engine_set_wgrad_defer_sim): see Run::flush_wgrads
   int wgrad_target = 96, wgrad_target_rows = 3000;      // crct_engine_set_wgrad_workgroups (Run::flush_wgrads)
-  int wgrad_target_shared = 0;                           // ... when both data streams' groups share ONE side stream (crct_engine_set_wgrad_workgroups_shared)
   int wgrad_flush = 1;                 // crct_engine_set_wgrad_flush: extra flush points of a layer's queued weight gradients (Run::ffn_bwd).
                                        // 1 (round 4): FFN group 0.075 -> 0.081 of peak in the step, step -0.02 (bf16) / -0.06 (fp8) / -0.08 ms (long context)
-  int prefetch_wgs = 0;                // workgroups of the weight prefetch one schedule step ahead (crct_engine_set_prefetch).  OFF: measured 7.79-8.04 vs 7.62-7.65 ms
-                                       // per step (the lab gain of 2.4 us per GEMM does not survive in the step)
   bool one_wgrad_stream = false;       // both data streams' weight gradients on ONE side stream (frees a hardware queue for the exchange)
-  // paired mode (off by default -- measured 1 ms per step slower in situ; CRCT_PAIR=1 or crct_engine_set_pairing(e, 1)
-  // turn it on): from the first co-attention layer on, the
-  // text and the visual side run on ONE stream as grouped / pair launches instead of two concurrent streams (Run::pair_flush);
-  // the bf16 step only -- the fp8 forward keeps the two-stream schedule
-  bool pair_mode = false, pair_forced = false;
   int first_conn = -1;                  // schedule index of the first co-attention layer
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // visual, text-wgrad, visual-wgrad
   // hardware-queue placement (streams.hip): the four streams below sit on queues other than the caller's stream's -- visual and
@@ -299,15 +290,6 @@ struct Run {
     }
     parity ^= 1;
   }
-  // ---- paired mode (crct_engine_set_pairing): the text and the visual Run share ONE data stream; inside the co-attention
-  // part of the schedule their launches are queued here instead of issued, and pair_flush() zips the two queues: GEMMs of
-  // the same kind leave as ONE grouped launch with both epilogues, LayerNorm passes as one pair launch, everything else
-  // back to back.  Q_SYNC marks the points where one side needs what the other has produced (the cross attention).
-  enum { Q_GEMM, Q_LNF, Q_LNB, Q_CALL, Q_SYNC };
-  struct QOp { int kind; CrctGemmArgs g; CrctLnFwdArgs lf; CrctLnBwdArgs lb; std::function<int(hipStream_t)> call; };
-  std::vector<QOp> q;
-  bool defer = false;
-  bool end_pending = false;            // a queued backward layer whose layer_end() has to follow the flush
   std::vector<CrctGemmArgs> pending;   // weight-gradient GEMMs of the current layer, launched as ONE grouped grid
   bool defer_wgrad = true;             // false: launch every weight gradient immediately on s (buffers are recycled)
   struct FinJob { const float* part; float* dg; float* db; float* dlb; int M, H; };
@@ -361,18 +343,15 @@ struct Run {
     if (!ta && st == s && o.site > 0 && o.site < CRCT_SITE_COUNT) {      // forward / data gradient on the data stream: the site's policy
       const crct_engine::SitePolicy& pol = e->policy[o.site][tb ? 1 : 0][phase];
       if (pol.cfg >= 0) g.tile = pol.cfg;
-      if (pol.split_k > 1 && !defer && crct_gemm_splitk_ws_elems(M, N, pol.split_k) <= (int64_t)e->sk_ws_elems[which] &&
+      if (pol.split_k > 1 && crct_gemm_splitk_ws_elems(M, N, pol.split_k) <= (int64_t)e->sk_ws_elems[which] &&
           crct_gemm_splitk_tickets(M, N) <= e->sk_tickets) {
         g.split_k = pol.split_k; g.splitk_ws = F(e->sk_ws[which]); g.splitk_cnt = W<uint32_t>(e->sk_cnt[which]);
       }
     }
-    if (defer && st == s) { QOp op; op.kind = Q_GEMM; op.g = g; q.push_back(op); return; }
     fail(crct_gemm_bf16(&g, st));
   }
-  void queue_call(std::function<int(hipStream_t)> f) { QOp op; op.kind = Q_CALL; op.call = std::move(f); q.push_back(op); }
-  // both sides reach this point before either goes on (immediate mode: order the two data streams against each other)
+  // both sides reach this point before either goes on: the two data streams are ordered against each other
   void cross_sync(Run& V) {
-    if (defer) { QOp op; op.kind = Q_SYNC; q.push_back(op); V.q.push_back(op); return; }
     if (!rc) fail(order_streams(e, V.s, s));
     if (!V.rc) V.fail(order_streams(e, s, V.s));
   }
@@ -417,7 +396,6 @@ struct Run {
     if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][1][phase].cfg >= 0) g.tile = e->policy[l.site][1][phase].cfg;
     g.scale_a = gscale(g_in); g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w);
     if (g_out >= 0) { g.fp8 |= 4; g.q_out = W<uint8_t>(q_out); g.ld_q = l.in; g.q_scale = gscale(g_out); g.q_amax = gamax(g_out); }
-    if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
     fail(crct_gemm_bf16(&g, s));
   }
   // x: the bf16 input (leading dimension l.in), read instead of xq by the calibration pass
@@ -442,7 +420,6 @@ struct Run {
     g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w); g.site = l.site;
     if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][0][phase].cfg >= 0) g.tile = e->policy[l.site][0][phase].cfg;
     if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; }
-    if (defer) { queue_call([g](hipStream_t st) { return crct_gemm_bf16(&g, st); }); return; }
     fail(crct_gemm_bf16(&g, s));
   }
   // dW[out][in] += dy^T x
@@ -483,7 +460,7 @@ struct Run {
     // queued also without a side stream (sw == s): the same groups, hence the same kernels and summation orders,
     // in every stream mode -- results stay bit-identical across modes
     pending.push_back(g);
-    if (pending.size() == 8 && !defer) flush_wgrads();
+    if (pending.size() == 8) flush_wgrads();
   }
   // dx[M][in] = dy W (+ epilogue)
   void lin_dgrad(const void* dy, int64_t lddy, const LinearP& l, int M, void* dx, int64_t lddx, Opt o) {
@@ -502,19 +479,15 @@ struct Run {
     for (const FinJob& f : pending_fin)
       if (!rc) fail(crct_layernorm_bwd_finalize(f.part, f.dg, f.db, f.dlb, f.M, f.H, 1, sw));
     pending_fin.clear();
-    // defer_sim (crct_engine_set_wgrad_defer_sim, TIMING ONLY, wrong gradients): what would a deferral of the co-attention-phase
-    // layers' weight gradients into the text-only tail of backward buy?  Their grouped launches are dropped where they are and the
-    // tail layers' groups are launched (1 + defer_sim) times instead -- the same amount of side-stream work, moved.
-    const int reps = (e->defer_sim > 0 && c->training) ? (phase == 1 ? 0 : 1 + e->defer_sim) : 1;
     // a persistent grid for the group (gemm.hip, group_grid) where the throttled side stream stays off the critical path: a side
     // stream per data stream, and not the 2560 / 6400-row streams of the long-context configuration, whose data-gradient GEMMs fill the
     // chip themselves (measured there: 11.90 - 11.94 ms with the text stream's groups throttled, 11.96 - 12.04 with both, 11.80 - 11.86 without)
-    const int target = (sw != s && !pending.empty() && pending[0].K <= e->wgrad_target_rows) ? (e->one_wgrad_stream ? e->wgrad_target_shared : e->wgrad_target) : 0;
-    for (int rep = 0; rep < reps; ++rep)
-      for (size_t i = 0; i < pending.size() && !rc; i += 8) {
-        const int ng = (int)std::min<size_t>(8, pending.size() - i);
-        fail(gemm_grouped_checked(pending.data() + i, ng, sw, target));
-      }
+    // (not on the exchange mode's shared side stream, which would become the critical path: 8.0 -> 8.9 - 9.1 ms at 96 workgroups)
+    const int target = (sw != s && !pending.empty() && pending[0].K <= e->wgrad_target_rows && !e->one_wgrad_stream) ? e->wgrad_target : 0;
+    for (size_t i = 0; i < pending.size() && !rc; i += 8) {
+      const int ng = (int)std::min<size_t>(8, pending.size() - i);
+      fail(gemm_grouped_checked(pending.data() + i, ng, sw, target));
+    }
     pending.clear();
     for (size_t i = 0; i < pending_f8.size() && !rc; i += 8)
       fail(crct_gemm_bf16_grouped(pending_f8.data() + i, (int)std::min<size_t>(8, pending_f8.size() - i), sw));
@@ -536,7 +509,6 @@ struct Run {
     ++tick;
     CrctLnFwdArgs a = {A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, nullptr, nullptr, nullptr};
     if (f8()) { a.q_out = W<uint8_t>(yq); a.q_scale = c->fp8_act_scale + site; a.q_amax = c->fp8_act_amax + (int64_t)site * CRCT_FP8_AMAX_LANES; }
-    if (defer) { QOp op; op.kind = Q_LNF; op.lf = a; q.push_back(op); return; }
     fail(launch_ln_fwd(a, s));
   }
   static int launch_ln_fwd(const CrctLnFwdArgs& a, hipStream_t st) {
@@ -555,8 +527,7 @@ struct Run {
     CrctLnBwdArgs a = {A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
                        0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, nullptr, nullptr, nullptr};
     if (g_site >= 0 && f8b() && f8b_lin(lin)) { a.q_out = W<uint8_t>(dlq); a.q_scale = gscale(g_site); a.q_amax = gamax(g_site); }
-    if (defer) { QOp op; op.kind = Q_LNB; op.lb = a; q.push_back(op); }
-    else fail(launch_ln_bwd(a, s));
+    fail(launch_ln_bwd(a, s));
     // the column pass is queued like the weight gradients: ONE ordering event per layer covers all of them
     if (defer_wgrad) pending_fin.push_back(FinJob{F(part), G(ln.g), G(ln.b), G(lin.b), M, H});
     else { wgrad_after_main(); if (!rc) fail(crct_layernorm_bwd_finalize(F(part), G(ln.g), G(ln.b), G(lin.b), M, H, 1, sw)); }
@@ -573,11 +544,7 @@ struct Run {
     if (ctxq != (size_t)-1 && site_ctx >= 0) {
       qz.ctx_q = W<uint8_t>(ctxq); qz.ctx_scale = c->fp8_act_scale + site_ctx; qz.ctx_amax = c->fp8_act_amax + (int64_t)site_ctx * CRCT_FP8_AMAX_LANES;
     }
-    auto f = [=](hipStream_t st) {
-      return crct_attention_fwd_q(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, seed, &qz, st);
-    };
-    if (defer) queue_call(f);
-    else fail(f(s));
+    fail(crct_attention_fwd_q(q, k, v, km, ctx, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, dr.thr, dr.scale, dr.site, seed, &qz, s));
   }
   // dqq / g_dq, dkq / dvq / g_dkv: also e5m2 copies of dq and of dk / dv (columns of fused dqkv buffers: one scale site per buffer)
   void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
@@ -591,12 +558,8 @@ struct Run {
     memset(&qz, 0, sizeof(qz));
     if (dqq && g_dq >= 0) { qz.dq_q = dqq; qz.dq_scale = gscale(g_dq); qz.dq_amax = gamax(g_dq); }
     if (dkq && dvq && g_dkv >= 0) { qz.dk_q = dkq; qz.dv_q = dvq; qz.dkv_scale = gscale(g_dkv); qz.dkv_amax = gamax(g_dkv); }
-    auto f = [=](hipStream_t st) {
-      return crct_attention_bwd_q(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr, dr.scale,
-                                  dr.site, seed, &qz, st);
-    };
-    if (defer) queue_call(f);
-    else fail(f(s));
+    fail(crct_attention_bwd_q(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr, dr.scale,
+                              dr.site, seed, &qz, s));
   }
   // the attention kernels that write fp8 copies cover this shape (MFMA kernels: include/crct_hip.h, CrctAttnQuant)
   static bool attn_q_ok(int Tq, int Tk, int d) { return crct_attention_quant_ok(Tq, Tk, d) != 0; }
@@ -619,7 +582,7 @@ struct Run {
     lin_wgrad(A(dl), p.dense.out, A(ctx), p.dense.in, p.dense, M, false, w8);
     if (f8b_lin(p.dense)) lin_dgrad_f8(dlq, a.g_dl, A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
     else lin_dgrad(A(dl), p.dense.out, p.dense, M, A(dctx), p.dense.in, Opt());
-    if ((e->wgrad_flush & 2) && !defer) flush_wgrads();      // bit 1: the projection's weight gradient leaves behind its data gradient
+    if (e->wgrad_flush & 2) flush_wgrads();      // bit 1: the projection's weight gradient leaves behind its data gradient
   }
   // y = LN(dropout(down(gelu(up(x)))) + x)   vilbert.py:454-471 / :585-602 / :782-786
   // xq / site_x: the e4m3 copy of x and its scale site (the LayerNorm that produced x wrote both)
@@ -654,7 +617,7 @@ struct Run {
     // the FFN-up data gradient, instead of at the end of the layer with the projection's and the QKV's: the grouped launch then runs
     // beside this layer's LayerNorm backward / attention-output dgrad / attention backward / QKV dgrad -- kernels of <= 156
     // workgroups -- and not beside the next layer's FFN data gradients.  Same kernels per problem, same sums: bit-identical.
-    if ((e->wgrad_flush & 1) && !defer) flush_wgrads();
+    if (e->wgrad_flush & 1) flush_wgrads();
   }
 
   // ---------------------------------------------------------------- self-attention layer
@@ -670,7 +633,6 @@ struct Run {
   }
   // xq / site_x: the e4m3 copy of the layer input (fp8 weight gradient of the QKV projection)
   void self_bwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t xq, int site_x, size_t g, size_t gx, const uint8_t* km, int B, int T) {
-    // (paired mode: the launches are only queued here, so the layer's weight-gradient flush waits for pair_flush -- end_pending)
     const int M = B * T, H = p.H, d = H / p.heads;
     const StreamScratch& sc = layer_begin();
     ffn_bwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, g, sc.gc, sc, M, drop(p.p_hid, p.site + 2));
@@ -688,8 +650,7 @@ struct Run {
     Opt o; o.addend = A(sc.dres_b); o.ld_add = H;
     if (gq) lin_dgrad_f8(sc.dqkvq, a.g_dqkv, A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
     else lin_dgrad(A(sc.dqkv), 3 * H, p.qkv, M, A(gx), H, o);
-    if (defer) end_pending = true;
-    else layer_end();
+    layer_end();
   }
 
   // ---------------------------------------------------------------- connection layer (vilbert.py:774-788)
@@ -739,7 +700,7 @@ struct Run {
     // layer's end is marked by the set's free event (recorded on the side stream behind everything the layer enqueued):
     // each data stream also waits for the OTHER side's event -- long signalled, so the wait is free, where a fresh
     // two-way hand-off costs 10+ us on the critical stream (tools/handoff_lab.cpp).  Without side streams: a full ordering.
-    if (!defer && sw != s && V.sw != V.s) {
+    if (sw != s && V.sw != V.s) {
       if (free_v && !rc && hipStreamWaitEvent(s, free_v, 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); rc = 1; }
       if (free_t && !V.rc && hipStreamWaitEvent(V.s, free_t, 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); V.rc = 1; }
     } else cross_sync(V);
@@ -765,60 +726,8 @@ struct Run {
     Opt ot; ot.addend = A(st.dres_b); ot.ld_add = D.H;
     if (gq) lin_dgrad_f8(st.dqkvq, a.g_dqkv2, A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
     else lin_dgrad(A(st.dqkv), 3 * Hb, p.qkv2, Mt, A(gxt), D.H, ot);
-    if (defer) { end_pending = true; V.end_pending = true; return; }
     V.layer_end();
     layer_end();
-  }
-
-  // ---------------------------------------------------------------- paired mode: issue the two queues
-  // Per-queue order is kept and nothing passes a Q_SYNC before BOTH sides have reached it; between two syncs the sides are
-  // independent, so heads of the queues that match in kind leave as one launch.  Same kernels, same per-element summation
-  // order as the unpaired schedule: results are bit-identical (test_internal_streams_do_not_change_results).
-  static int issue_one(const QOp& o, hipStream_t st) {
-    switch (o.kind) {
-      case Q_GEMM: return crct_gemm_bf16(&o.g, st);
-      case Q_LNF: return launch_ln_fwd(o.lf, st);
-      case Q_LNB: return launch_ln_bwd(o.lb, st);
-      case Q_CALL: return o.call(st);
-      default: return 0;
-    }
-  }
-  void pair_flush(Run& V) {
-    Run& T = *this;
-    size_t i = 0, j = 0;
-    const size_t n = T.q.size(), m = V.q.size();
-    hipStream_t st = T.s;
-    while ((i < n || j < m) && !T.rc && !V.rc) {
-      const QOp* a = i < n ? &T.q[i] : nullptr;
-      const QOp* b = j < m ? &V.q[j] : nullptr;
-      const bool sa = a && a->kind == Q_SYNC, sb = b && b->kind == Q_SYNC;
-      if ((sa || !a) && (sb || !b)) { if (a) ++i; if (b) ++j; continue; }       // both sides at the rendezvous (or one side done)
-      if (sa) a = nullptr;                                                     // the text side waits for the visual side
-      if (sb) b = nullptr;
-      if (a && b && a->kind == b->kind && a->kind != Q_CALL) {
-        int r = 0;
-        if (a->kind == Q_GEMM) {
-          if (a->g.ta == b->g.ta && a->g.tb == b->g.tb) { CrctGemmArgs pr[2] = {a->g, b->g}; r = crct_gemm_bf16_grouped(pr, 2, st); }
-          else { r = issue_one(*a, st); if (!r) r = issue_one(*b, st); }
-        } else if (a->kind == Q_LNF) r = crct_layernorm_fwd_pair(&a->lf, &b->lf, st);
-        else r = crct_layernorm_bwd_rows_pair(&a->lb, &b->lb, st);
-        T.fail(r);
-        ++i; ++j;
-        continue;
-      }
-      // kinds differ (or two attention calls): one launch from the side that is not holding a pairable GEMM, so that
-      // the queues fall back into step
-      if (a && b) {
-        const bool a_first = a->kind == Q_CALL || b->kind != Q_CALL;
-        if (a_first) { T.fail(issue_one(*a, st)); ++i; } else { V.fail(issue_one(*b, st)); ++j; }
-        continue;
-      }
-      if (a) { T.fail(issue_one(*a, st)); ++i; }
-      else { V.fail(issue_one(*b, st)); ++j; }
-    }
-    T.q.clear(); V.q.clear();
-    if (T.end_pending) { T.end_pending = false; T.layer_end(); }
-    if (V.end_pending) { V.end_pending = false; V.layer_end(); }
   }
 
   // ---------------------------------------------------------------- embeddings
@@ -1281,16 +1190,10 @@ int ensure_streams(crct_engine* e, hipStream_t main) {
   return 0;
 }
 
-bool pairing_on(crct_engine* e, const CrctStepCfg* cfg) {
-  const bool f8 = cfg->fp8 && cfg->params_fp8 && cfg->fp8_w_scale && cfg->fp8_act_scale && cfg->fp8_act_amax;
-  return e->pair_mode && !f8 && e->first_conn >= 0;
-}
-
 // two drivers over one workspace: Rt = text stream on the caller's stream, Rv = visual stream
 void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, void* ws, hipStream_t main, const CrctBatch* batch,
                const CrctStepCfg* cfg, Run& Rt, Run& Rv) {
-  const bool paired = pairing_on(e, cfg);
-  hipStream_t vis = (e->use_vis_stream && !paired) ? e->side[0] : main;
+  hipStream_t vis = e->use_vis_stream ? e->side[0] : main;
   Rt = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, main, batch, cfg, e->use_wgrad_stream ? e->side[1] : main,
            e->partials[0], e->colsum_part[0], e->colsum_part[2]};
   Rv = Run{e, p32, (const bf16_t*)p16, g32, (char*)ws, vis, batch, cfg, e->use_wgrad_stream ? e->side[e->one_wgrad_stream ? 1 : 2] : vis,
@@ -1298,23 +1201,6 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
   Rt.sets[0] = &e->st; Rt.sets[1] = &e->st2;
   Rv.sets[0] = &e->sv; Rv.sets[1] = &e->sv2;
   Rt.which = 0; Rv.which = 1;
-}
-
-// Weights are HBM-cold when a GEMM of the step reaches them (each is read once per pass, 476 MB against 256 MB of Infinity
-// Cache), and a GEMM with one or two K tiles in flight per workgroup then pays an HBM round trip per K step: +2.4 us on the
-// 10 us text attention-output GEMM (tools/coldstart_lab.py).  While schedule step i runs, the bf16 weights of step `next` are
-// touched by a few workgroups on a weight-gradient side stream (idle in forward, between two layers' groups in backward).
-void prefetch_step(crct_engine* e, Run& R, const void* p16, int next, const CrctStepCfg* cfg, bool forward) {
-  if (e->prefetch_wgs <= 0 || R.rc || R.sw == R.s || next < 0 || next >= (int)e->sched.size()) return;
-  const int seg = (int)e->sched.size() - next;              // backward segment = gradient / parameter range of that schedule step
-  const auto& r = e->seg_range[seg];
-  if (r.second <= r.first) return;
-  if (forward && cfg->seg_ready_events && cfg->seg_ready_events[seg]) {       // not before the optimizer has rewritten them
-    if (hipStreamWaitEvent(R.sw, (hipEvent_t)cfg->seg_ready_events[seg], 0) != hipSuccess) { crct_set_error("engine: stream wait failed"); R.rc = 1; return; }
-  }
-  const char* base = (const char*)p16 + (size_t)(r.first & ~(int64_t)7) * 2;
-  R.fail(crct_prefetch(base, (int64_t)(r.second - (r.first & ~(int64_t)7)) * 2, e->prefetch_wgs, R.sw));
-  R.sw_dirty = true;
 }
 
 // the split-K ticket words of both data streams start every engine call at zero (an aborted launch must not poison the next)
@@ -1366,17 +1252,14 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   size_t xt = e->eta.y, xv = e->eva.y;
   size_t xtq = e->eta.yq, xvq = e->eva.yq;               // e4m3 copies of the running hidden states and their scale sites (fp8 forward)
   int site_t = e->eta.site, site_v = e->eva.site;
-  const bool paired = pairing_on(e, cfg);
   int step_i = 0;
   for (const Step& st : e->sched) {
     const int seg = (int)e->sched.size() - step_i;       // backward segment of this schedule step
-    Rt.defer = Rv.defer = paired && step_i >= e->first_conn;
     Rt.phase = (e->first_conn < 0 || step_i < e->first_conn) ? 0 : 1;      // text-only prefix: nothing else on the data path
     ++step_i;
     if (st.kind == 't') wait_params(Rt, seg);
     else if (st.kind == 'v') wait_params(Rv, seg);
     else { wait_params(Rt, seg); wait_params(Rv, seg); }
-    prefetch_step(e, st.kind == 'v' ? Rv : Rt, params_bf16, step_i, cfg, true);      // step_i is already the NEXT schedule step
     if (st.kind == 't') {
       const SelfLayerA& a = e->tla[st.idx];
       Rt.self_fwd(e->tl[st.idx], a, xt, xtq, site_t, batch->text_keymask, batch->B, batch->T);
@@ -1391,10 +1274,7 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
       xv = a.ffn_v.y; xvq = a.ffn_v.yq; site_v = a.ffn_v.site_y;
       xt = a.ffn_t.y; xtq = a.ffn_t.yq; site_t = a.ffn_t.site_y;
     }
-    // paired mode: a co-attention layer is issued at once; a visual layer waits for the text layer the schedule runs beside it
-    if (Rt.defer && (st.kind != 'v' || step_i == (int)e->sched.size() || e->sched[step_i].kind != 't')) Rt.pair_flush(Rv);
   }
-  Rt.defer = Rv.defer = false;
   Rt.phase = 1;
   wait_params(Rt, 0);
   wait_params(Rv, 0);
@@ -1444,15 +1324,11 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
   if (int r = reset_tickets(e, workspace, (hipStream_t)stream)) return r;
   // fork: every internal stream starts after the caller's prior work (previous segment, optimizer, ...)
   Rv.fail(order_streams(e, Rt.s, Rv.s));
-  const bool paired = pairing_on(e, cfg);
   int ev_from = s0;                                      // segments enqueued completely but not yet marked for the data-parallel caller
   for (int sgi = s0; sgi < s1 && !Rt.rc && !Rv.rc; ++sgi) {
     const bool in_sched = sgi != 0 && sgi != nseg - 1;
     const size_t si = in_sched ? e->sched.size() - (size_t)sgi : 0;
-    Rt.defer = Rv.defer = paired && in_sched && (int)si >= e->first_conn;
     Rt.phase = (in_sched && (e->first_conn < 0 || (int)si < e->first_conn)) ? 0 : 1;      // backward tail through the text-only layers
-    if (in_sched && si >= 1) prefetch_step(e, e->sched[si].kind == 'v' ? Rv : Rt, params_bf16, (int)si - 1, cfg, false);
-    else if (sgi == 0) prefetch_step(e, Rt, params_bf16, (int)e->sched.size() - 1, cfg, false);
     if (sgi == 0) {
       e->cur_t = 0; e->cur_v = 0;
       Rt.heads_bwd(Rv, e->final_t, e->final_v, e->st.dy[0], e->sv.dy[0], logits, reg, stats);
@@ -1473,14 +1349,6 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
         e->cur_t ^= 1; e->cur_v ^= 1;
       }
     }
-    if (Rt.defer) {
-      // paired mode: a text layer waits for the visual layer that follows it in backward order (the pair the forward ran side
-      // by side); everything else is issued at the end of its segment
-      const bool hold = in_sched && e->sched[si].kind == 't' && sgi + 1 < s1 && sgi + 1 < nseg - 1 && e->sched[si - 1].kind == 'v' &&
-                        (int)(si - 1) >= e->first_conn;
-      if (hold) continue;
-      Rt.pair_flush(Rv);
-    }
     if (seg < 0 && cfg->seg_done_events && !Rt.rc && !Rv.rc) {
       // segments ev_from .. sgi are completely enqueued: mark that point on every internal stream for the data-parallel caller
       Rt.flush_wgrads();
@@ -1498,8 +1366,6 @@ static int engine_backward_impl(crct_engine_t* e, const float* params_f32, const
     }
     ev_from = sgi + 1;
   }
-  if (!Rt.q.empty() || !Rv.q.empty()) Rt.pair_flush(Rv);
-  Rt.defer = Rv.defer = false;
   // join: everything this call enqueued anywhere is ordered before later work on the caller's stream
   Rt.main_after_wgrad();
   Rv.main_after_wgrad();
@@ -1590,31 +1456,21 @@ extern "C" crct_stream_t crct_engine_aux_stream(crct_engine_t* e, crct_stream_t 
   return e->aux;
 }
 
+extern "C" int crct_engine_streams(crct_engine_t* e, crct_stream_t out[4]) {
+  if (!e || !out) return 1;
+  out[0] = e->side[0]; out[1] = e->side[1]; out[2] = e->side[2]; out[3] = e->aux;
+  return 0;
+}
+
 extern "C" int crct_engine_set_wgrad_workgroups(crct_engine_t* e, int target_wgs, int max_rows) {
   if (!e) return 1;
   e->wgrad_target = target_wgs > 0 ? target_wgs : 0;
   e->wgrad_target_rows = max_rows;
   return 0;
 }
-extern "C" int crct_engine_set_wgrad_workgroups_shared(crct_engine_t* e, int target_wgs) {
-  if (!e) return 1;
-  e->wgrad_target_shared = target_wgs > 0 ? target_wgs : 0;
-  return 0;
-}
 extern "C" int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode) {
   if (!e) return 1;
   e->wgrad_flush = mode;
-  return 0;
-}
-extern "C" int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps) {
-  if (!e || extra_reps < 0 || extra_reps > 8) return 1;
-  e->defer_sim = extra_reps;
-  return 0;
-}
-
-extern "C" int crct_engine_set_prefetch(crct_engine_t* e, int workgroups) {
-  if (!e || workgroups < 0 || workgroups > 1024) return 1;
-  e->prefetch_wgs = workgroups;
   return 0;
 }
 
@@ -1624,13 +1480,6 @@ extern "C" int crct_engine_set_site_policy(crct_engine_t* e, int site, int kind,
   CRCT_REQUIRE(cfg >= -1 && cfg <= 71 && split_k >= 0 && split_k <= 4, "set_site_policy: cfg %d / split_k %d out of range", cfg, split_k);
   for (int ph = 0; ph < 2; ++ph)
     if (phase < 0 || phase == ph) { e->policy[site][kind][ph].cfg = cfg; e->policy[site][kind][ph].split_k = split_k; }
-  return 0;
-}
-
-extern "C" int crct_engine_set_pairing(crct_engine_t* e, int on) {
-  if (!e) return 1;
-  e->pair_mode = on != 0;
-  e->pair_forced = true;
   return 0;
 }
 

@@ -41,8 +41,8 @@ namespace {
 thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
 template <class K, class... A>
 inline void launch_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... a) {
-  if (g_time_start) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, g_time_start, g_time_stop, 0u, a...);
-  else hipLaunchKernelGGL(kern, grid, block, lds, s, a...);
+  if (g_time_start) { crct_stamp_adopt(s, g_time_start, g_time_stop); hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, g_time_start, g_time_stop, 0u, a...); }
+  else crct_launch(kern, grid, block, lds, s, a...);
 }
 
 constexpr int BK = 64;
@@ -221,18 +221,12 @@ __device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int
   return true;
 }
 
-}  // namespace
-int g_crct_lab_band_rows = 0;
-extern "C" int crct_lab_xcd_band(int rows_per_band) { g_crct_lab_band_rows = rows_per_band > 0 ? rows_per_band : 0; return 0; }
-namespace {
-
 inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid) {
   TileMap t;
   t.tiles_m = (M + BM - 1) / BM; t.tiles_n = (N + BN - 1) / BN;
   long best = -1;
   int bgm = 1;
-  const bool banded = g_crct_lab_band_rows > 0 && g_crct_lab_band_rows % BM == 0 && (long)g_crct_lab_band_rows * 8 >= M;
-  for (int gm = banded ? 8 : 1; gm <= 8; gm *= 2) {
+  for (int gm = 1; gm <= 8; gm *= 2) {
     const int gn = 8 / gm;
     const int rm = (t.tiles_m + gm - 1) / gm, rn = (t.tiles_n + gn - 1) / gn;
     // panel rows held per XCD, plus a penalty for padded (idle) blocks
@@ -769,65 +763,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
         }
     }
   };
-  if constexpr (PM == 2) {
-  // Two-phase ("ping-pong") loop, round 4.  tools/lab/fill_probe.hip measured what the L2 -> LDS path delivers to a CU whose
-  // waves do nothing but stream operand tiles: 124 - 135 GB/s (all 256 CUs, L2-hot, this kernel's swizzled 128-byte rows), not
-  // the ~70 GB/s the plain loop below takes in -- the plain loop is not fill-bound, it is serial: all eight waves pass "barrier,
-  // issue DMA, read fragments, wait, multiply" in lock step, so the two waves of a SIMD wait for the LDS together and then
-  // want the matrix pipe together (round 1's ablation: ~890 cycles per K step with the DMA switched off).  Here the waves of
-  // a workgroup form two groups that sit on the same four SIMDs (wave w and wave w + NW / 2 share one) and run half a K step
-  // apart: while group 0 reads the fragments of tile k and issues its DMA pieces, group 1 multiplies tile k - 1, and vice
-  // versa -- two workgroup barriers per K step, each wave's MFMA burst beside its partner's LDS / DMA phase
-  // (MI355X_MICROARCH.md, "Two waves per SIMD").  Stage of tile t = t % NS; a stage is refilled one barrier after BOTH groups
-  // have finished reading it, so NS >= 3 keeps a tile in flight for a whole K step.  Same MFMAs on the same fragments in the
-  // same order per accumulator as the plain loop: bit-identical results.
-    static_assert(NS >= 3 && (NW % 2) == 0, "ping-pong loop: three stages, an even number of waves");
-    const bool grp1 = wave >= NW / 2;
-    bf8_t fm[2][WTM], fn[2][WTN];
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    auto read_phase = [&](int kt) {
-      if (kt + NS - 1 < nk && !(lab_bits(dbg) & 2)) issue(kt + NS - 1, (kt + NS - 1) % NS);
-      request(kt % NS, fm, fn);
-      frag_async_wait<0>();
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int i = 0; i < WTM; ++i) frag_async_use(fm[h][i]);
-#pragma unroll
-        for (int i = 0; i < WTN; ++i) frag_async_use(fn[h][i]);
-      }
-    };
-    auto mfma_phase = [&](int kt) {
-      multiply(0, fm, fn);
-      multiply(1, fm, fn);
-      rowsums(kt, fm);
-    };
-    auto phase_end = [&](int kt_next) {       // tile kt_next (this wave's pieces) has landed before the barrier that opens its first read
-      if (kt_next < nk) wait_tile(kt_next);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    if (!grp1) {
-      for (int kt = 0; kt < nk; ++kt) {
-        read_phase(kt);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        mfma_phase(kt);
-        phase_end(kt + 1);
-      }
-    } else {
-      for (int kt = 0; kt < nk; ++kt) {
-        if (kt > 0) mfma_phase(kt - 1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read_phase(kt);
-        phase_end(kt + 1);
-      }
-      mfma_phase(nk - 1);
-    }
-  } else if constexpr (PM == 1) {
+  if constexpr (PM == 1) {
   // register-pipelined: while the MFMAs of tile kt run from one register set, the reads of tile kt+1 fill the other;
   // tile t lives in stage t % NS and its stage goes back to the DMA one barrier after its reads have completed
     bf8_t fmA[2][WTM], fnA[2][WTN], fmB[2][WTM], fnB[2][WTN];
@@ -1675,13 +1611,13 @@ __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_group_ldr_kernel(con
 }
 
 static int g_group_max_wgs = 0;        // crct_gemm_group_max_workgroups: 0 = one workgroup per tile
-static int g_group_wgrad_cfg = 4;      // configuration of a layer's grouped weight gradients: 4 = 128 x 128 plain loop, 39 = the same tile, two-phase loop
+static int g_group_wgrad_cfg = 4;      // configuration of a layer's grouped weight gradients: 4 = 128 x 128 plain loop (48 / 53 / 58 / 59 / 68: loader-wave variants)
 static int g_group_concat = 0;         // crct_gemm_group_concat: grouped weight gradients as ONE tile list over the XCDs (GroupArgs.concat); measured: no gain
 extern "C" int crct_gemm_group_concat(int on) { g_group_concat = on != 0; return 0; }
-// configuration of the grouped weight-gradient launches (4 / 39 / 48 / 53 / 58 / 59: all 128 x 128 tiles); returns the previous one
+// configuration of the grouped weight-gradient launches (4 / 48 / 53 / 58 / 59 / 68: all 128 x 128 tiles); returns the previous one
 extern "C" int crct_gemm_group_wgrad_config(int cfg) {
   const int old = g_group_wgrad_cfg;
-  if (cfg == 4 || cfg == 39 || cfg == 48 || cfg == 53 || cfg == 58 || cfg == 59 || cfg == 68) g_group_wgrad_cfg = cfg;
+  if (cfg == 4 || cfg == 48 || cfg == 53 || cfg == 58 || cfg == 59 || cfg == 68) g_group_wgrad_cfg = cfg;
   return old;
 }
 extern "C" int crct_gemm_group_max_workgroups(int n) { g_group_max_wgs = n > 0 ? (n + 7) / 8 * 8 : 0; return 0; }
@@ -2048,11 +1984,13 @@ static bool g_force_generic = false;
 // test hook: route every GEMM through the register-staged kernel (parity of both code paths)
 extern "C" int crct_gemm_force_generic(int on) { g_force_generic = on != 0; return 0; }
 
-extern "C" int crct_prof_enable(int on) {
+extern "C" int crct_prof_enable(int on) {      // 1: the GEMM kernels (per configuration / per site); 2: also every other kernel of the library (crct_prof_stamp_*)
   g_prof.on = on != 0;
+  crct_stamp_enable(on == 2);
   return 0;
 }
 extern "C" int crct_prof_reset(void) {
+  crct_stamp_reset();
   g_prof.used = 0;
   for (int i = 0; i < Prof::NV; ++i) { g_prof.flops[i] = 0; g_prof.count[i] = 0; }
   return 0;
@@ -2136,7 +2074,7 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g.q_out && !(pipe && g.q_scale && g.ld_q % 8 == 0)) return hipErrorInvalidValue;      // the fp8 output copy lives in the staged epilogue
   if (g.rowsum_out && !pipe) return hipErrorNotSupported;       // row sums exist in the LDS-DMA kernel only
   int t = g.tile >= 0 ? g.tile : (pipe ? pick_pipe_config(g) : crct_gemm_pick_tile(g.M, g.N));
-  if (t > 15 && !(((t >= 22 && t <= 35) || (t >= 38 && t <= 71)) && pipe && !is_f8)) t = 12;
+  if (t > 15 && !(((t >= 22 && t <= 35) || (t >= 46 && t <= 71)) && pipe && !is_f8)) t = 12;
   // fp8 forward: the tile of the bf16 kernel, 2 stages (id 20) or 3 for the narrow long-K GEMMs (id 21)
   if (is_f8) t = (g.tile == 20 || g.tile == 21) ? g.tile : ((g.N <= 1024 && g.K >= 2048) ? 21 : 20);
   if (t > 3 && !pipe) t = crct_gemm_pick_tile(g.M, g.N);
@@ -2189,15 +2127,6 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 33: e = launch_pipe<4, 4, 2, 4, 3, 1>(g, s); break; // 128x128, 8 waves, 3 stages
       case 34: e = launch_pipe<8, 4, 4, 2, 3, 1>(g, s); break; // 256x128, 8 waves, 3 stages
       case 35: e = launch_pipe<5, 3, 2, 2, 3, 1>(g, s); break; // 160x96, 4 waves, 3 stages
-      // two-phase ("ping-pong") main loop (PM = 2, round 4): the two waves of a SIMD run half a K step apart
-      case 38: e = launch_pipe<4, 2, 4, 2, 3, 2>(g, s); break; // 128x64, 8 waves (4x2), 3 stages (72 KB: two per CU)
-      case 39: e = launch_pipe<4, 4, 2, 4, 3, 2>(g, s); break; // 128x128, 8 waves (2x4: 64x32 wave tiles), 3 stages (96 KB)
-      case 40: e = launch_pipe<4, 2, 4, 2, 4, 2>(g, s); break; // 128x64, 8 waves (4x2), 4 stages (96 KB)
-      case 41: e = launch_pipe<4, 4, 4, 2, 3, 2>(g, s); break; // 128x128, 8 waves (4x2: 32x64 wave tiles), 3 stages
-      case 42: e = launch_pipe<8, 4, 4, 2, 3, 2>(g, s); break; // 256x128, 8 waves (4x2: 64x64 wave tiles), 3 stages (144 KB)
-      case 43: e = launch_pipe<2, 4, 2, 4, 3, 2>(g, s); break; // 64x128, 8 waves (2x4), 3 stages
-      case 44: e = launch_pipe<8, 2, 4, 2, 3, 2>(g, s); break; // 256x64, 8 waves (4x2: 64x32 wave tiles), 3 stages (120 KB)
-      case 45: e = launch_pipe<4, 4, 2, 4, 4, 2>(g, s); break; // 128x128, 8 waves (2x4), 4 stages (128 KB)
       // loader waves (round 4): WM x WN compute waves + NL waves that own the LDS-DMA ring
       case 46: e = launch_ldr<4, 2, 4, 2, 3, 4>(g, s); break;  // 128x64, 8 + 4 waves, 3 stages (72 KB)
       case 47: e = launch_ldr<4, 2, 4, 2, 2, 4>(g, s); break;  // 128x64, 8 + 4 waves, 2 stages (48 KB)
@@ -2274,12 +2203,11 @@ hipError_t crct_gemm_launch_grouped_wgs(const CrctGemmArgs* gs, int n, hipStream
   // weight gradients: 128x128, 8 waves, 3 stages; forward / dgrad pairs: 128x128, 8 waves, 2 stages; CrctGemmArgs.tile of the first
   // problem may pick the other one (crct_engine_set_site_policy: A/B runs)
   const int t0 = gs[0].tile;
-  const int cfg = (t0 == 4 || t0 == 9 || t0 == 39 || t0 == 48 || t0 == 53 || t0 == 58 || t0 == 59 || t0 == 68) ? t0 : (gs[0].ta ? g_group_wgrad_cfg : 9);
+  const int cfg = (t0 == 4 || t0 == 9 || t0 == 48 || t0 == 53 || t0 == 58 || t0 == 59 || t0 == 68) ? t0 : (gs[0].ta ? g_group_wgrad_cfg : 9);
   prof_begin(cfg * 3 + kind_of(gs[0]), gs, n);
   hipError_t e;
   switch (cfg) {
     case 9: e = launch_group<4, 4, 2, 4, 2>(gs, n, s); break;
-    case 39: e = launch_group<4, 4, 2, 4, 3, 2>(gs, n, s); break;
     case 48: e = launch_group_ldr<4, 4, 2, 4, 3, 4, false>(gs, n, s); break;
     case 53: e = launch_group_ldr<4, 4, 2, 2, 3, 4, false>(gs, n, s); break;
     case 58: e = launch_group_ldr<4, 4, 2, 2, 3, 4, true>(gs, n, s); break;

@@ -246,7 +246,7 @@ extern "C" int crct_eval_select(const float* logits, const float* reg_out, const
                "eval_select: null argument");
   CRCT_REQUIRE(Q >= 0 && N >= 0, "eval_select: bad sizes");
   if (Q == 0) return 0;
-  hipLaunchKernelGGL(eval_select_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, logits, reg_out, reg_err, reg_terr, num_ans,
+  crct_launch(eval_select_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, logits, reg_out, reg_err, reg_terr, num_ans,
                      forced_answers, Q, (long)N, prob0, answers, sel_out, sel_err, sel_terr);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -256,10 +256,10 @@ extern "C" int crct_head_loss(const CrctHeadArgs* args, crct_stream_t stream) {
   CRCT_REQUIRE(args && args->B > 0 && args->Hb > 0, "head_loss: bad sizes");
   CRCT_REQUIRE(args->scratch, "head_loss: scratch (fp32 [B][8]) is required");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(head_rows_kernel, dim3(args->B), dim3(256), 0, s, *args, args->scratch);
+  crct_launch(head_rows_kernel, dim3(args->B), dim3(256), 0, s, *args, args->scratch);
   CRCT_CHECK_HIP(hipGetLastError());
   const int nb = ((args->Hb > 256 ? args->Hb : 256) + 31) / 32;
-  hipLaunchKernelGGL(head_reduce_kernel, dim3(nb), dim3(256), 0, s, *args, (const float*)args->scratch);
+  crct_launch(head_reduce_kernel, dim3(nb), dim3(256), 0, s, *args, (const float*)args->scratch);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

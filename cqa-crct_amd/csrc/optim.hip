@@ -172,7 +172,7 @@ extern "C" int crct_zero_runs(float* base, const int64_t* off, const int64_t* le
   CRCT_REQUIRE(base && off && len && blk_seg && blk_off, "zero_runs: null argument");
   if (n_blk <= 0) return 0;
   const long grid = n_blk > 1024 ? 1024 : n_blk;
-  hipLaunchKernelGGL(zero_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, base, off, len, blk_seg, blk_off,
+  crct_launch(zero_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, base, off, len, blk_seg, blk_off,
                      (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -205,7 +205,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   // forward on its own stream is throttled this way (256 = one workgroup per CU): at full width it saturates HBM for
   // 1.4 ms and the first layers of the forward crawl (measured: 10.25-10.36 -> 10.03 ms per step).
   const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+  crct_launch(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      seg_off, seg_len, seg_lr, seg_wd, blk_seg, blk_off, beta1, beta2, eps, (float)(1.0 / bc1),
                      (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, f8, (int)n_blk, zero_grads, (const bf16_t*)g_bf16);
   CRCT_CHECK_HIP(hipGetLastError());
@@ -214,7 +214,7 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
 
 extern "C" int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_stream_t stream) {
   CRCT_REQUIRE(step_dev, "adamw_advance: null step counter");
-  hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, found_inf_dev);
+  crct_launch(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, found_inf_dev);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }

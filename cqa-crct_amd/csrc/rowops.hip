@@ -546,7 +546,6 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
 struct LnFwdP {
   const bf16_t* x; const float* gamma; const float* beta; bf16_t* y; float* mean_o; float* rstd_o; int M, H; float eps;
   uint32_t thr; float scale; uint32_t site; uint64_t seed; uint8_t* q_out; const float* q_scale; float* q_amax;
-  int band;      // lab hook (crct_lab_xcd_band): > 0 = rows per XCD band, workgroup b serves rows of band b % 8
 };
 template <int NCH>
 __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, const int nblk) {
@@ -557,15 +556,8 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, cons
   row_load_f32(b, a.beta, H, lane);
   const float qs = a.q_out ? a.q_scale[0] : 0.f;
   float amax = 0.f;
-  long row0 = (long)blk * ROWS_PER_BLOCK + wave, stride = (long)nblk * ROWS_PER_BLOCK, row_end = M;
-  if (a.band > 0) {            // band x = blk % 8 is walked by the workgroups blk = x, x + 8, ...
-    const int x = blk & 7, j = blk >> 3, per = nblk >> 3;
-    row0 = (long)x * a.band + (long)j * ROWS_PER_BLOCK + wave;
-    stride = (long)(per > 0 ? per : 1) * ROWS_PER_BLOCK;
-    row_end = (long)(x + 1) * a.band < M ? (long)(x + 1) * a.band : M;
-    if (j >= per) row0 = row_end;
-  }
-  for (long row = row0; row < row_end; row += stride) {
+  const long stride = (long)nblk * ROWS_PER_BLOCK;
+  for (long row = (long)blk * ROWS_PER_BLOCK + wave; row < M; row += stride) {
     Row<NCH> r;
     row_load_bf16(r, a.x + row * H, H, lane);
     float mean, rstd;
@@ -582,12 +574,6 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, cons
 }
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdP a) { ln_fwd_body<NCH>(a, blockIdx.x, gridDim.x); }
-// workgroups [0, nb0) serve problem a, the rest problem b: same arithmetic per row as two single launches
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const LnFwdP a, const LnFwdP b, const int nb0) {
-  if ((int)blockIdx.x < nb0) ln_fwd_body<NCH>(a, blockIdx.x, nb0);
-  else ln_fwd_body<NCH>(b, blockIdx.x - nb0, gridDim.x - nb0);
-}
 
 // ------------------------------------------------------------------------------ LayerNorm bwd
 // COMBINE: the four waves of a workgroup add their column partials through LDS and store ONE partial row set per
@@ -673,12 +659,6 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, cons
 
 template <int NCH, bool COMBINE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP a) { ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, gridDim.x); }
-// workgroups [0, nb0) serve problem a, the rest problem b; each problem keeps its own partial-row geometry ([3][nblk][H])
-template <int NCH, bool COMBINE>
-__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(const LnBwdP a, const LnBwdP b, const int nb0) {
-  if ((int)blockIdx.x < nb0) ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, nb0);
-  else ln_bwd_body<NCH, COMBINE>(b, blockIdx.x - nb0, gridDim.x - nb0);
-}
 
 // out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
 // dimension (ldo) > 1 column group: out index = c*stride_q
@@ -1084,7 +1064,7 @@ inline int row_grid(long M, int cap) {
   }
 
 int launch_finalize(const FinalizeArgs& fa, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_partials_kernel, dim3((fa.H + 31) / 32, fa.Q), dim3(256), 0, s, fa);
+  crct_launch(finalize_partials_kernel, dim3((fa.H + 31) / 32, fa.Q), dim3(256), 0, s, fa);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -1094,8 +1074,7 @@ extern "C" {
 
 static LnFwdP ln_fwd_problem(const CrctLnFwdArgs& a) {
   return LnFwdP{(const bf16_t*)a.x, a.gamma, a.beta, (bf16_t*)a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale,
-                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax,
-                (g_crct_lab_band_rows > 0 && (long)g_crct_lab_band_rows * 8 >= a.M) ? g_crct_lab_band_rows : 0};
+                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax};
 }
 static int ln_fwd_check(const CrctLnFwdArgs& a) {
   CRCT_REQUIRE(a.H % 8 == 0 && a.H > 0, "layernorm: H=%d must be a positive multiple of 8", a.H);
@@ -1106,7 +1085,7 @@ static int ln_fwd_launch(const CrctLnFwdArgs& a, hipStream_t s) {
   if (int r = ln_fwd_check(a)) return r;
   if (a.M <= 0) return 0;
   const LnFwdP p = ln_fwd_problem(a);
-  DISPATCH_NCH(a.H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(row_grid(a.M, 2048)), dim3(256), 0, s, p));
+  DISPATCH_NCH(a.H, crct_launch((ln_fwd_kernel<NCH>), dim3(row_grid(a.M, 2048)), dim3(256), 0, s, p));
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1124,24 +1103,6 @@ int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, v
   CRCT_REQUIRE(q_out && q_scale, "layernorm_fwd_q: q_out and q_scale are required");
   const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, q_out, q_scale, q_amax};
   return ln_fwd_launch(a, (hipStream_t)stream);
-}
-
-// Two independent LayerNorms (the text and the visual side of a layer pair) in ONE launch; rows of different widths are fine
-// as long as both take the same number of 512-column register chunks, otherwise two launches.
-int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct_stream_t stream) {
-  CRCT_REQUIRE(a && b, "layernorm_fwd_pair: null argument");
-  hipStream_t s = (hipStream_t)stream;
-  if (int r = ln_fwd_check(*a)) return r;
-  if (int r = ln_fwd_check(*b)) return r;
-  if (a->M <= 0 || b->M <= 0 || nch_for(a->H) != nch_for(b->H)) {
-    if (int r = ln_fwd_launch(*a, s)) return r;
-    return ln_fwd_launch(*b, s);
-  }
-  const LnFwdP pa = ln_fwd_problem(*a), pb = ln_fwd_problem(*b);
-  const int nb0 = row_grid(a->M, 2048), nb1 = row_grid(b->M, 2048);
-  DISPATCH_NCH(a->H, hipLaunchKernelGGL((ln_fwd_pair_kernel<NCH>), dim3(nb0 + nb1), dim3(256), 0, s, pa, pb, nb0));
-  CRCT_CHECK_HIP(hipGetLastError());
-  return 0;
 }
 
 // the embedding backward kernels write 7 partial rows per wave: fewer, longer-running waves than the LayerNorm backward
@@ -1168,9 +1129,9 @@ static int ln_bwd_launch(const CrctLnBwdArgs& a, hipStream_t s) {
   const int nb = crct_layernorm_bwd_blocks(a.M);
   const LnBwdP p = ln_bwd_problem(a);
   if (ln_bwd_combines(a.H)) {
-    DISPATCH_NCH(a.H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, p));
+    DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, p));
   } else {
-    DISPATCH_NCH(a.H, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, p));
+    DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, p));
   }
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1187,30 +1148,6 @@ int crct_layernorm_bwd_rows_args(const CrctLnBwdArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a && (!a->q_out || a->q_scale), "layernorm_bwd_rows_args: bad arguments");
   return ln_bwd_launch(*a, (hipStream_t)stream);
 }
-// The rows passes of two independent LayerNorm backwards in ONE launch (see crct_layernorm_fwd_pair); every problem keeps
-// the partial-row geometry of its own single launch, so crct_layernorm_bwd_finalize is unchanged.
-int crct_layernorm_bwd_rows_pair(const CrctLnBwdArgs* a, const CrctLnBwdArgs* b, crct_stream_t stream) {
-  CRCT_REQUIRE(a && b, "layernorm_bwd_rows_pair: null argument");
-  hipStream_t s = (hipStream_t)stream;
-  const bool same = a->M > 0 && b->M > 0 && a->H % 8 == 0 && b->H % 8 == 0 && a->H > 0 && b->H > 0 && nch_for(a->H) == nch_for(b->H) &&
-                    ln_bwd_combines(a->H) == ln_bwd_combines(b->H);
-  if (!same) {
-    if (int r = ln_bwd_launch(*a, s)) return r;
-    return ln_bwd_launch(*b, s);
-  }
-  const LnBwdP pa = ln_bwd_problem(*a), pb = ln_bwd_problem(*b);
-  const int nb0 = crct_layernorm_bwd_blocks(a->M), nb1 = crct_layernorm_bwd_blocks(b->M);
-  const int Hmax = a->H > b->H ? a->H : b->H;
-  if (ln_bwd_combines(a->H)) {
-    DISPATCH_NCH(a->H, hipLaunchKernelGGL((ln_bwd_pair_kernel<NCH, true>), dim3(nb0 + nb1), dim3(256),
-                                          (size_t)3 * ROWS_PER_BLOCK * Hmax * 4, s, pa, pb, nb0));
-  } else {
-    DISPATCH_NCH(a->H, hipLaunchKernelGGL((ln_bwd_pair_kernel<NCH, false>), dim3(nb0 + nb1), dim3(256), 0, s, pa, pb, nb0));
-  }
-  CRCT_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 // column pass: dgamma / dbeta / dbias_lin (+)= sum over the workgroup partials; may run on another stream
 int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin, int M, int H,
                                 int accumulate, crct_stream_t stream) {
@@ -1240,7 +1177,7 @@ int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int
   if (N <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int nb = crct_colsum_blocks(M);
-  hipLaunchKernelGGL(colsum_kernel, dim3((N / 4 + 255) / 256, nb), dim3(256), 0, s, (const bf16_t*)x, (long)ld, partials, M, N);
+  crct_launch(colsum_kernel, dim3((N / 4 + 255) / 256, nb), dim3(256), 0, s, (const bf16_t*)x, (long)ld, partials, M, N);
   CRCT_CHECK_HIP(hipGetLastError());
   FinalizeArgs fa = {};
   fa.out[0] = out; fa.stride[0] = 1; fa.Q = 1; fa.nblk = nb; fa.H = N; fa.accumulate = accumulate; fa.partials = partials;
@@ -1250,7 +1187,7 @@ int crct_colsum_bf16(const void* x, int64_t ld, float* out, float* partials, int
 int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_stream_t stream) {
   CRCT_REQUIRE(F % 4 == 0, "softmax_rows: F=%d must be a multiple of 4", F);
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_kernel<false>, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, (const void*)x, (bf16_t*)y, M, F);
+  crct_launch(softmax_rows_kernel<false>, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, (const void*)x, (bf16_t*)y, M, F);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1258,7 +1195,7 @@ int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_strea
 int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_stream_t stream) {
   CRCT_REQUIRE(F % 4 == 0, "softmax_rows: F=%d must be a multiple of 4", F);
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, M, F);
+  crct_launch(softmax_rows_kernel<true>, dim3(row_grid(M, 4096)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, M, F);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1287,7 +1224,7 @@ extern "C" int crct_build_keymasks(const int64_t* sep_indices, const int64_t* hi
   CRCT_REQUIRE(!km_v || image_mask, "build_keymasks: image_mask is required for the visual mask");
   if (!km_t && !km_v) return 0;
   const int n = B * (T > V ? T : V);
-  hipLaunchKernelGGL(build_keymasks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sep_indices, hist_len, sep_stride,
+  crct_launch(build_keymasks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sep_indices, hist_len, sep_stride,
                      image_mask, km_t, km_v, B, T, V);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1417,14 +1354,14 @@ int crct_fp8_quantize_bf16(const void* x, void* q, const float* scale, float* am
   if (n <= 0) return 0;
   long blocks = (n / 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(fp8_quantize_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (uint8_t*)q, scale, amax, (long)n);
+  crct_launch(fp8_quantize_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (uint8_t*)q, scale, amax, (long)n);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int crct_fp8_update_scales(float* scale, float* amax, int n, int reset, const float* skip_if, float fmax, crct_stream_t stream) {
   CRCT_REQUIRE(scale && amax && n >= 0, "fp8_update_scales: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset, skip_if,
+  crct_launch(fp8_update_scales_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scale, amax, n, reset, skip_if,
                      fmax > 0.f ? fmax : 448.0f);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1437,10 +1374,10 @@ int crct_fp8_quantize_weights(const float* p, void* q, const int64_t* seg_off, c
   hipStream_t s = (hipStream_t)stream;
   const int grid = n_blk > 2048 ? 2048 : (int)n_blk;
   CRCT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)n_slots * CRCT_FP8_AMAX_LANES * 4, s));
-  hipLaunchKernelGGL(fp8_weights_kernel<0>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
+  crct_launch(fp8_weights_kernel<0>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0, (const float*)nullptr, 448.0f);
-  hipLaunchKernelGGL(fp8_weights_kernel<1>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
+  crct_launch(fp8_update_scales_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, scale, amax, n_slots, 0, (const float*)nullptr, 448.0f);
+  crct_launch(fp8_weights_kernel<1>, dim3(grid), dim3(256), 0, s, p, (uint8_t*)q, seg_off, seg_len, seg_slot, blk_seg, blk_off,
                      (const float*)scale, amax, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1452,7 +1389,7 @@ int crct_fp8_transpose_weights(const void* q, void* qt, const int64_t* w_off, co
   if (n_w <= 0 || n_tiles <= 0) return 0;
   long grid = n_tiles < 1048576 ? n_tiles : 1048576;
   if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
-  hipLaunchKernelGGL(fp8_transpose_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)q, (uint8_t*)qt,
+  crct_launch(fp8_transpose_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)q, (uint8_t*)qt,
                      w_off, w_out, w_in, tile_begin, n_w, (long)n_tiles);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1463,7 +1400,7 @@ int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream)
   long blocks = (n / 8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(cast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
+  crct_launch(cast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)n);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1474,7 +1411,7 @@ int crct_cast_runs_f32_bf16(const float* x, void* y, const int64_t* off, const i
   CRCT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cast_runs: 16-byte aligned buffers");
   if (n_blk <= 0) return 0;
   const long grid = n_blk > 2048 ? 2048 : n_blk;
-  hipLaunchKernelGGL(cast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, off, len, blk_seg, blk_off, (int)n_blk);
+  crct_launch(cast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, off, len, blk_seg, blk_off, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1485,7 +1422,7 @@ int crct_cast_runs_bf16_f32(const void* x, float* y, const int64_t* off, const i
   CRCT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cast_runs: 16-byte aligned buffers");
   if (n_blk <= 0) return 0;
   const long grid = n_blk > 2048 ? 2048 : n_blk;
-  hipLaunchKernelGGL(uncast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, off, len, blk_seg, blk_off, (int)n_blk);
+  crct_launch(uncast_runs_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, off, len, blk_seg, blk_off, (int)n_blk);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1496,7 +1433,7 @@ int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream)
   long blocks = (n / 8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(uncast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, (long)n);
+  crct_launch(uncast_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, (long)n);
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1509,7 +1446,7 @@ int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* lo
   CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_text: H=%d must be a positive multiple of 8", H);
   if ((long)B * T <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_fwd_kernel<NCH>), dim3(row_grid((long)B * T, 2048)), dim3(256), 0, s, ids,
+  DISPATCH_NCH(H, crct_launch((embed_text_fwd_kernel<NCH>), dim3(row_grid((long)B * T, 2048)), dim3(256), 0, s, ids,
                                      segs, loc, word, pos, type, w_loc, b_loc, gamma, beta, (bf16_t*)sum_out, (bf16_t*)y,
                                      mean, rstd, B, T, H, n_pos, eps, drop_thr, drop_scale, drop_site, seed));
   CRCT_CHECK_HIP(hipGetLastError());
@@ -1534,7 +1471,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_types <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = embed_bwd_blocks(M);
   const int type_partials = rows_scratch && n_types >= 2 && d_type;     // partials then hold 9 row sets
-  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
+  DISPATCH_NCH(H, crct_launch((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
                                      partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch,
                                      rows_scratch ? idx_scratch : nullptr, type_partials));
@@ -1545,7 +1482,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
     CRCT_REQUIRE(word_lds <= 152 * 1024, "embed_text_bwd: B*T=%ld rows need %zu bytes of LDS for the word-gradient scan", M, word_lds);
     const int n_gather = used_pos + n_types;
     if (g_embed_scatter_split) {      // test hook: the two launches the merged kernel replaces (same bits)
-      hipLaunchKernelGGL(gather_sum_kernel, dim3(n_gather), dim3(256), (size_t)M * sizeof(int), s,
+      crct_launch(gather_sum_kernel, dim3(n_gather), dim3(256), (size_t)M * sizeof(int), s,
                          rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type);
       CRCT_CHECK_HIP(hipGetLastError());
       DISPATCH_NCH(H, {
@@ -1555,7 +1492,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
           big_lds_w = true;
         }
-        hipLaunchKernelGGL((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
+        crct_launch((word_scatter_kernel<NCH>), dim3((int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
                            (const float*)rows_scratch, ids, (int)M, H, d_word);
       });
       CRCT_CHECK_HIP(hipGetLastError());
@@ -1567,7 +1504,7 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         big_lds = true;
       }
-      hipLaunchKernelGGL((embed_scatter_kernel<NCH>), dim3(n_gather + (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
+      crct_launch((embed_scatter_kernel<NCH>), dim3(n_gather + (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
                          (const float*)rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type, n_gather, ids, d_word);
     });
     CRCT_CHECK_HIP(hipGetLastError());
@@ -1593,7 +1530,7 @@ extern "C" int crct_embed_image_fwd(const void* img_lin, const float* loc, const
   CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_image: H=%d must be a positive multiple of 8", H);
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
+  DISPATCH_NCH(H, crct_launch((embed_image_fwd_kernel<NCH>), dim3(row_grid(M, 2048)), dim3(256), 0, s,
                                      (const bf16_t*)img_lin, loc, target, w_loc, b_loc, color, gamma, beta,
                                      (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed));
   CRCT_CHECK_HIP(hipGetLastError());
@@ -1611,13 +1548,13 @@ extern "C" int crct_embed_image_bwd(const void* dy, const void* sum_saved, const
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_color <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = embed_bwd_blocks(M);
-  DISPATCH_NCH(H, hipLaunchKernelGGL((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
+  DISPATCH_NCH(H, crct_launch((embed_image_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, loc, target, gamma, (bf16_t*)d_sum, d_color,
                                      partials, M, H, drop_thr, drop_scale, drop_site, seed, rows_scratch,
                                      rows_scratch ? idx_scratch : nullptr));
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(n_color), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, M, H, d_color,
+    crct_launch(gather_sum_kernel, dim3(n_color), dim3(256), (size_t)M * sizeof(int), s, rows_scratch, idx_scratch, M, H, d_color,
                        n_color, (const int*)nullptr, (float*)nullptr);
     CRCT_CHECK_HIP(hipGetLastError());
   }

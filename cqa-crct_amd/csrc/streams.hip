@@ -36,36 +36,56 @@ int conflict(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, bool* o
   return 0;
 }
 
-// touch `bytes` bytes: every lane loads 16 bytes per step, 8 loads in flight; the value is kept alive by an asm sink (nothing is
-// written).  The lines land in the Infinity Cache (and in the touching XCD's L2).
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, long n16) {
-  const long stride = (long)gridDim.x * 256;
-  uint4 acc = make_uint4(0, 0, 0, 0);
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 7 * stride < n16; i += 8 * stride) {
-    uint4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
-  }
-  for (; i < n16; i += stride) { const uint4 v = p[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
-  asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));
-}
-
 }  // namespace
 
-// Weights are read once per pass (476 MB of bf16 weights against 256 MB of Infinity Cache): a GEMM of the step finds its
-// weight operand in HBM, and with one or two K tiles in flight per workgroup every K step then waits for an HBM round trip
-// (tools/coldstart_lab.py: the text attention-output GEMM takes 7.6 us with hot operands, 9.8 us from the Infinity Cache,
-// 13.5 us from HBM).  crct_prefetch touches a buffer from a few workgroups on a stream that has nothing better to do, a layer
-// ahead of its use.
-extern "C" int crct_prefetch(const void* ptr, int64_t bytes, int workgroups, crct_stream_t stream) {
-  if (!ptr || bytes <= 0) return 0;
-  const long n16 = bytes / 16;
-  if (workgroups < 1) workgroups = 1;
-  hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const uint4*)ptr, n16);
-  CRCT_CHECK_HIP(hipGetLastError());
+// ---------------------------------------------------------------------------------------------------------------- kernel stamps
+namespace {
+struct Stamp { hipEvent_t a, b; hipStream_t s; bool own; };
+std::vector<Stamp> g_stamps;          // slots [0, g_used) belong to the running collection; events of `own` slots are reused after a reset
+size_t g_used = 0;
+bool g_stamp_on = false;
+}  // namespace
+void crct_stamp_enable(int on) { g_stamp_on = on != 0; }
+void crct_stamp_reset(void) {
+  // adopted pairs belong to the GEMM profile (gemm.hip): drop their slots, keep our own events for reuse
+  std::vector<Stamp> keep;
+  for (const Stamp& st : g_stamps) if (st.own) keep.push_back(st);
+  g_stamps.swap(keep);
+  g_used = 0;
+}
+bool crct_stamp_begin(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_stamp_on) return false;
+  while (g_used < g_stamps.size() && !g_stamps[g_used].own) ++g_used;          // (adopted slots sit where they were appended)
+  if (g_used == g_stamps.size()) {
+    Stamp st; st.own = true; st.s = s;
+    if (hipEventCreate(&st.a) != hipSuccess || hipEventCreate(&st.b) != hipSuccess) return false;
+    g_stamps.push_back(st);
+  }
+  Stamp& st = g_stamps[g_used++];
+  st.s = s;
+  *start = st.a; *stop = st.b;
+  return true;
+}
+void crct_stamp_adopt(hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+  if (!g_stamp_on) return;
+  Stamp st; st.a = start; st.b = stop; st.s = s; st.own = false;
+  g_stamps.insert(g_stamps.begin() + (long)g_used, st);
+  ++g_used;
+}
+// Number of stamped launches since the last reset / the i-th one: its stream and its begin / end in milliseconds after the FIRST stamped
+// launch began (synchronises on the events).
+extern "C" int crct_prof_stamp_count(void) { return (int)g_used; }
+extern "C" int crct_prof_stamp_read(int i, void** stream, double* t0_ms, double* t1_ms) {
+  if (i < 0 || (size_t)i >= g_used || !stream || !t0_ms || !t1_ms) return 1;
+  const Stamp& st = g_stamps[(size_t)i];
+  CRCT_CHECK_HIP(hipEventSynchronize(st.b));
+  float a = 0.f, d = 0.f;
+  if (i > 0) {
+    CRCT_CHECK_HIP(hipEventSynchronize(g_stamps[0].a));
+    CRCT_CHECK_HIP(hipEventElapsedTime(&a, g_stamps[0].a, st.a));
+  }
+  CRCT_CHECK_HIP(hipEventElapsedTime(&d, st.a, st.b));
+  *stream = (void*)st.s; *t0_ms = (double)a; *t1_ms = (double)a + (double)d;
   return 0;
 }
 

@@ -117,14 +117,9 @@ int crct_gemm_group_concat(int on);
  * the other instead of one merged launch (identical results; tests/test_kernels_gpu.py, bench.py --embed-scatter-split). */
 void crct_embed_scatter_split(int on);
 /* Kernel configuration of the grouped weight-gradient launches of the step (all 128 x 128 tiles; see gemm.hip): 4 = plain loop,
- * 39 = two-phase loop, 48 / 53 = loader waves (8 + 4 / 4 + 4 waves), 58 / 59 = loader waves + two fragment register sets.  Returns
+ * 48 / 53 = loader waves (8 + 4 / 4 + 4 waves), 58 / 59 = loader waves + two fragment register sets.  Returns
  * the previous value; other values are ignored. */
 int crct_gemm_group_wgrad_config(int cfg);
-
-/* Lab hook (tools/lab/band_lab.py): rows per XCD band, 0 = off (the product).  With a band the GEMM tile maps
- * give XCD x (= block % 8) the row tiles of band x and every column tile, and crct_layernorm_fwd serves band b % 8 from workgroup
- * b, so that a LayerNorm -> GEMM -> GEMM chain produces and consumes an activation row on ONE XCD.  Results do not change. */
-int crct_lab_xcd_band(int rows_per_band);
 
 /* Kernel configuration of one shape class of the forward / data-gradient GEMMs: cls = 3 * rows_bucket + column_class with
  * rows_bucket 0: M <= 2000, 1: M <= 4000, 2: M > 4000 and column_class 0: N >= 2304 (wide), 1: N <= 1024 with K <= 1024, 2: N <= 1024
@@ -150,8 +145,14 @@ int crct_gemm_force_generic(int on);
  * kernel configurations (tile / waves / stages, see gemm.hip), 16..19 = register-staged kernel tiles 0..3.  crct_prof_read
  * synchronises on the recorded events and returns launches, summed algorithmic FLOPs (2MNK) and
  * summed elapsed milliseconds of that variant since the last reset. */
-int crct_prof_enable(int on);
+int crct_prof_enable(int on);      /* 0 off; 1: the GEMM kernels; 2: also every other kernel the library launches (crct_prof_stamp_*) */
 int crct_prof_reset(void);
+/* With crct_prof_enable(2): begin / end stamps of EVERY kernel launch of the library since the last crct_prof_reset, in launch order
+ * over all streams.  crct_prof_stamp_read(i): the stream (hipStream_t) launch i ran on and its begin / end in milliseconds after the
+ * first stamped launch began (synchronises).  bench.py derives config.critical_path from them: launches per step, kernels and busy
+ * time per hardware queue, time with k kernels in flight. */
+int crct_prof_stamp_count(void);
+int crct_prof_stamp_read(int i, void** stream, double* t0_ms, double* t1_ms);
 int crct_prof_read(int variant, long* count, double* flops, double* ms);
 /* The same stamps keyed by model site (CRCT_SITE_*) and kind (CRCT_KIND_*).  A grouped launch (the weight gradients of a layer
  * in one grid) is ONE kernel: its duration is apportioned to its member problems by their share of the launch's FLOPs
@@ -185,14 +186,12 @@ int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, v
                          uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                          void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream);
 
-/* Two independent LayerNorms in ONE launch (the text and the visual side of a co-attention layer, or of two layers the schedule
- * runs side by side): same arithmetic per row as two crct_layernorm_fwd[_q] calls.  q_out == NULL: no e4m3 copy. */
+/* crct_layernorm_fwd / _q with the arguments in a struct (q_out == NULL: no e4m3 copy). */
 typedef struct CrctLnFwdArgs {
   const void* x; const float* gamma; const float* beta; void* y; float* mean; float* rstd;
   int32_t M, H; float eps; uint32_t drop_thr; float drop_scale; uint32_t drop_site; uint64_t seed;
   void* q_out; const float* q_scale; float* q_amax;
 } CrctLnFwdArgs;
-int crct_layernorm_fwd_pair(const CrctLnFwdArgs* a, const CrctLnFwdArgs* b, crct_stream_t stream);
 
 /* Every amax "value" below and in CrctGemmArgs / CrctStepCfg / CrctFp8Shadow is CRCT_FP8_AMAX_LANES consecutive fp32 words
  * (the kernels spread their atomic maxima over them; crct_fp8_update_scales takes the maximum of the words): an amax array
@@ -249,8 +248,7 @@ int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, co
                             uint32_t post_thr, float post_scale, uint32_t post_site,
                             uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
                             crct_stream_t stream);
-/* The rows passes of two independent LayerNorm backwards in ONE launch; arguments as crct_layernorm_bwd_rows, partial rows in
- * each problem's own buffer and geometry (crct_layernorm_bwd_finalize per problem afterwards). */
+/* crct_layernorm_bwd_rows with the arguments in a struct (+ the optional fp8 copy). */
 typedef struct CrctLnBwdArgs {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* gamma; void* dx; void* dx_lin; float* partials;
   int32_t M, H; uint32_t post_thr; float post_scale; uint32_t post_site; uint32_t lin_thr; float lin_scale; uint32_t lin_site;
@@ -261,7 +259,6 @@ typedef struct CrctLnBwdArgs {
   void* q_out; const float* q_scale; float* q_amax;
 } CrctLnBwdArgs;
 int crct_layernorm_bwd_rows_args(const CrctLnBwdArgs* a, crct_stream_t stream);      /* crct_layernorm_bwd_rows from the struct (incl. q_out) */
-int crct_layernorm_bwd_rows_pair(const CrctLnBwdArgs* a, const CrctLnBwdArgs* b, crct_stream_t stream);
 int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin,
                                 int M, int H, int accumulate, crct_stream_t stream);
 
@@ -280,9 +277,6 @@ int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_strea
 int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_stream_t stream);
 
 /* fp32 -> bf16 copy (weight shadow refresh). */
-/* Touch `bytes` bytes at ptr (16-byte aligned) with `workgroups` workgroups: the lines land in the Infinity Cache.  The engine
- * runs it a layer ahead over the weights the next GEMMs read (they are HBM-cold otherwise: every weight is read once per pass). */
-int crct_prefetch(const void* ptr, int64_t bytes, int workgroups, crct_stream_t stream);
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
 /* bf16 -> fp32 copy (a gradient bucket exchanged as bf16 put back into the fp32 gradient buffer for callers that read .grad). */
 int crct_cast_bf16_f32(const void* x, float* y, int64_t n, crct_stream_t stream);
@@ -614,14 +608,9 @@ int crct_engine_set_streams(crct_engine_t*, int use_visual_stream, int use_wgrad
  * glue runs the overlapped optimizer update (during the next forward) and the data-parallel exchange (during backward) on
  * it -- nothing else should.  queue_classes (may be NULL): hardware-queue classes the probe saw, 4 when every stream has its own. */
 crct_stream_t crct_engine_aux_stream(crct_engine_t*, crct_stream_t main_stream, int* queue_classes);
-/* Paired mode (default OFF: measured slower in the step; CRCT_PAIR=1 turns it on for A/B runs): from the first co-attention layer
- * on, the text and the visual side of the schedule share ONE stream and leave as grouped GEMM / pair LayerNorm launches
- * (crct_gemm_bf16_grouped with n = 2, crct_layernorm_*_pair) instead of running on two concurrent streams.  Results are
- * bit-identical in both modes.  The fp8 forward always uses the two-stream schedule. */
-int crct_engine_set_pairing(crct_engine_t*, int on);
-/* TIMING EXPERIMENT ONLY (wrong gradients; bench.py --wgrad-defer-sim): the grouped weight-gradient launches of the layers that
- * run beside the visual stream are dropped and those of the text-only tail of backward are launched 1 + extra_reps times -- the
- * side-stream work of a deferral policy without its buffers, to price it before building it.  0 = off. */
+/* The engine's internal streams, for labelling the stamps of crct_prof_stamp_read: out[0] = visual data stream, out[1] / out[2] = text /
+ * visual weight-gradient streams, out[3] = auxiliary stream (NULL where a stream does not exist yet).  The text data stream is the caller's. */
+int crct_engine_streams(crct_engine_t*, crct_stream_t out[4]);
 // Where a layer's queued weight-gradient GEMMs leave for the side stream (default 1).  0: one grouped launch at the end of the layer.  Bit 0: the
 // FFN block's two (with its LayerNorm column pass) right behind the FFN-up data gradient, the rest at the end of the layer.  Bit 1:
 // the attention-output projection's right behind its data gradient.
@@ -631,14 +620,6 @@ int crct_engine_set_wgrad_flush(crct_engine_t* e, int mode);
 // groups of a data stream with at most max_rows token rows, and only while every data stream has a side stream of its own (a
 // shared side stream -- the mode a gradient exchange uses -- would become the critical path).  Defaults 96 / 3000.
 int crct_engine_set_wgrad_workgroups(crct_engine_t* e, int target_wgs, int max_rows);
-// ... the target while both data streams' groups share one side stream (crct_engine_set_streams(.., 2): the mode a gradient exchange uses)
-int crct_engine_set_wgrad_workgroups_shared(crct_engine_t* e, int target_wgs);
-int crct_engine_set_wgrad_defer_sim(crct_engine_t* e, int extra_reps);
-
-/* Weight prefetch: while a schedule step runs, the bf16 weights of the NEXT step (forward) / the previous one (backward) are
- * touched by `workgroups` workgroups on a weight-gradient side stream, so that the GEMMs find them in the Infinity Cache instead
- * of in HBM (crct_prefetch).  0 = off.  Only with side streams; reads only -- results are identical. */
-int crct_engine_set_prefetch(crct_engine_t*, int workgroups);
 /* Per-site launch policy of the forward / data-gradient GEMMs (A/B switch of the developer tools and the tests; the defaults
  * are the measured choices).  phase 0 = the text-only part of the schedule (layers t0 .. before the first
  * co-attention layer: nothing else on the chip's data path), phase 1 = beside the visual stream; phase < 0 sets both.

@@ -93,6 +93,13 @@ def test_bench_starts_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], cwd=ROOT,
                          env=dict(env, CRCT_LAUNCH_CHECK_FAIL_RANK="2"), capture_output=True, text=True, timeout=300)
     assert res.returncode == 7
+    assert "rank 2 (exit 7)" in res.stderr                                      # ... and the launcher says which rank it was
+    # a rank that never comes back (a peer stuck in the RCCL bootstrap): after --rank-timeout-s the launcher ends every rank it started
+    # and exits 124 with each rank's last stderr lines
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--rank-timeout-s", "3"], cwd=ROOT,
+                         env=dict(env, CRCT_LAUNCH_CHECK_HANG_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 124, (res.returncode, res.stderr[-1500:])
+    assert "--rank-timeout-s 3" in res.stderr and "waiting for a peer that never comes" in res.stderr
     # under a launcher that has set the rendezvous already (torch.distributed.run) no further processes are started
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT,
                          env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),

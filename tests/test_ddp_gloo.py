@@ -124,3 +124,37 @@ def test_two_rank_gradient_exchange_over_gloo():
         p.join(60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] >= 2
+
+
+def test_what_grad_holds_follows_the_optimizer_that_is_alive():
+    """`materialize_grads=None` writes the reduced gradients back into the fp32 views UNLESS a live FusedAdamW that covers
+    every gradient is attached -- an optimizer that was built and discarded, or one over a parameter subset, must not switch the
+    write-back off; and a pass without an exchange (no_sync / one rank) forgets that the owned views were NaN-filled."""
+    import weakref
+    from crct.ddp import FlatGradDDP
+
+    class Core(object):
+        pass
+
+    class Opt(object):
+        def __init__(self, full):
+            self.full = full
+
+        def covers_every_gradient(self):
+            return self.full
+    ddp = object.__new__(FlatGradDDP)
+    ddp.core, ddp.materialize_grads = Core(), None
+    assert ddp.materializes() is True                       # nothing attached: DistributedDataParallel's contract
+    full = Opt(True)
+    ddp.core._fused_optimizer = weakref.ref(full)
+    assert ddp.materializes() is False                      # the fused optimizer reads the bf16 bucket itself
+    part = Opt(False)
+    ddp.core._fused_optimizer = weakref.ref(part)
+    assert ddp.materializes() is True                       # a subset optimizer: somebody else reads .grad of the rest
+    ddp.core._fused_optimizer = weakref.ref(full)
+    del full
+    import gc
+    gc.collect()
+    assert ddp.materializes() is True                       # built, then discarded
+    ddp.materialize_grads = False
+    assert ddp.materializes() is False                      # an explicit choice stands
