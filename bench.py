@@ -117,6 +117,10 @@ def parse():
                     "GEMMs do not write the bf16 communication buffer themselves)")
     ap.add_argument("--adamw-wide-first", type=int, default=-1, help="developer A/B: how many of the first overlapped AdamW launches run unthrottled")
     ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
+    ap.add_argument("--ln-fold", action="store_true", help="developer A/B: the LayerNorm forward folded into the neighbouring GEMMs (params['ln_fold'] = "
+                    "True: 34 launches fewer per step; measured slower, EXPERIMENTS.md round 5) instead of a launch of its own")
+    ap.add_argument("--no-fused-heads", action="store_true", help="developer A/B: the pooler / regressor head chain as 13 + 13 GEMM launches "
+                    "(params['fused_heads'] = False) instead of one kernel per pass")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
     ap.add_argument("--fp8-plain-mfma", action="store_true", help="developer A/B (--dtype fp8): the round-3 fp8 GEMMs (four v_mfma_f32_16x16x32_fp8 per "
                     "128-deep K tile) instead of one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (crct_gemm_fp8_scaled_mfma)")
@@ -191,7 +195,7 @@ def critical_path(run_step, core, n_steps):
     torch.cuda.synchronize()
     lib.crct_prof_enable(0)
     n = lib.crct_prof_stamp_count()
-    names = {torch.cuda.current_stream().cuda_stream: "text (caller's stream)"}
+    names = {torch.cuda.current_stream().cuda_stream or 0: "text (caller's stream)"}
     eng = core._engine
     if eng is not None:
         arr = (C.c_void_p * 4)()
@@ -204,7 +208,7 @@ def critical_path(run_step, core, n_steps):
     for i in range(n):
         if lib.crct_prof_stamp_read(i, C.byref(st), C.byref(t0), C.byref(t1)) != 0:
             continue
-        q = per.setdefault(names.get(st.value, "stream %#x" % (st.value or 0)), dict(kernels=0, busy_ms=0.0, first=t0.value, last=t1.value))
+        q = per.setdefault(names.get(st.value or 0, "stream %#x" % (st.value or 0)), dict(kernels=0, busy_ms=0.0, first=t0.value, last=t1.value))
         q["kernels"] += 1
         q["busy_ms"] += t1.value - t0.value
         q["first"], q["last"] = min(q["first"], t0.value), max(q["last"], t1.value)
@@ -474,6 +478,10 @@ def main():
         cfg = CFG.vilbert_config(v_feature_size=a.feat, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
                                  v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
     params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0, fp8=a.dtype == "fp8")
+    if a.ln_fold:
+        params["ln_fold"] = True
+    if a.no_fused_heads:
+        params["fused_heads"] = False
     if a.fp8_forward_only:
         params["fp8_backward"] = False
     if a.fp8_bf16_wgrad:

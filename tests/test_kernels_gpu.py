@@ -788,3 +788,87 @@ def test_attention_gives_the_same_bits_for_every_wave_count(gemm_path):
         assert torch.equal(res[0][key], res[1][key]), key
         assert torch.equal(res[0][key], res[2][key]), key
         assert float(res[0][key].float().abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ folded LayerNorm (round 5)
+@pytest.mark.parametrize("M,H,N,tile", [(1600, 768, 2304, -1), (1600, 768, 3072, 12), (2880, 1024, 1024, -1), (21, 64, 192, -1), (200, 128, 256, 15)],
+                         ids=["t.qkv", "t.ffn_up-2stage", "v.ffn_up", "tiny", "ragged"])
+def test_folded_layernorm_matches_layernorm_then_linear(M, H, N, tile, gemm_path):
+    """BertLayerNorm (vilbert.py:281-294) between two Linears without a launch of its own: the PRODUCER GEMM (dense + residual,
+    :424-428) writes per (row, column tile) partial statistics of the bf16 pre-norm sum; the CONSUMER GEMM (:455 / :388-390) reads
+    the RAW sum against the gamma-folded weight, finishes the statistics, applies rstd * (acc - mean * c) + b' in its epilogue and
+    writes LN(s), mean and rstd.  Checked against fp32 LayerNorm -> Linear of the same bf16 inputs; the written LN(s) / statistics
+    against the stand-alone LayerNorm kernel."""
+    if gemm_path == "generic":
+        pytest.skip("the folded LayerNorm lives in the LDS-DMA kernels (the engine falls back to the LayerNorm launch elsewhere)")
+    torch.manual_seed(M + N)
+    dev = "cuda"
+    K0 = 128
+    x0 = (torch.randn(M, K0, device=dev) * 0.5).bfloat16()
+    w0 = (torch.randn(H, K0, device=dev) * 0.3).bfloat16()
+    b0 = torch.randn(H, device=dev) * 0.1
+    res = (torch.randn(M, H, device=dev) * 2.0 + 1.5).bfloat16()         # a residual stream with a DC offset: mean / std ~ 1
+    # ---- producer: s = x0 w0^T + b0 + res, with partial statistics
+    stats = torch.full((M, 16, 2), float("nan"), device=dev)
+    s_sum = ops.gemm(x0, w0, M, H, K0, bias=b0, addend=res, ln_stats_out=stats)
+    g = L.GemmArgs()
+    ops._gemm_args(g, x0, w0, M, H, K0, bias=b0, addend=res, out=s_sum)
+    bn = L.load().crct_gemm_tile_cols(C.byref(g))
+    assert bn in (64, 128) and H % bn == 0
+    tiles = H // bn
+    torch.cuda.synchronize()
+    sf = s_sum.float()
+    st = stats.view(-1)[:M * tiles * 2].view(M, tiles, 2)
+    blk = sf.view(M, tiles, bn)
+    assert torch.allclose(st[:, :, 0], blk.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[:, :, 1], ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-3)
+    # ---- fold: W o gamma, c, b'
+    gamma = 1.0 + 0.2 * torch.randn(H, device=dev)
+    beta = 0.1 * torch.randn(H, device=dev)
+    W = torch.randn(N, H, device=dev) * 0.05
+    b = torch.randn(N, device=dev) * 0.1
+    flat = torch.cat([W.flatten(), b, gamma, beta]).contiguous()
+    o_b, o_g, o_be = N * H, N * H + N, N * H + N + H
+    wfold, cvec, bvec, c_off = ops.ln_fold_weights(flat, [(0, o_b, o_g, o_be, H, N)])
+    wf = wfold[:N * H].view(N, H)
+    assert torch.equal(wf, (W * gamma).bfloat16())
+    assert torch.allclose(cvec[:N], wf.float().sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(bvec[:N], b + W @ beta, rtol=1e-5, atol=1e-5)
+    # ---- consumer
+    y = torch.full((M, H), float("nan"), device=dev, dtype=torch.bfloat16)
+    mean = torch.full((M,), float("nan"), device=dev)
+    rstd = torch.full((M,), float("nan"), device=dev)
+    pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    lnf = dict(stats=stats, tiles=tiles, c=cvec, gamma=gamma, beta=beta, y=y, mean=mean, rstd=rstd)
+    gq = L.GemmArgs()
+    ops._gemm_args(gq, s_sum, wf, M, N, H, bias=bvec, lnf=lnf, tile=tile)
+    assert L.load().crct_gemm_lnf_ok(C.byref(gq)) == 1
+    out = ops.gemm(s_sum, wf.contiguous(), M, N, H, bias=bvec, lnf=lnf, act="gelu", preact_out=pre, tile=tile)
+    torch.cuda.synchronize()
+    ln_ref = torch.nn.functional.layer_norm(sf, (H,), gamma, beta, 1e-12)
+    ref_pre = ln_ref @ W.t() + b
+    scale = float(ref_pre.abs().max())
+    # bf16 operands (s and W o gamma are what they are; LN(s) itself is never rounded): 1e-2 of max like every bf16 GEMM test here
+    assert float((pre.float() - ref_pre).abs().max()) <= 1e-2 * scale
+    assert float((out.float() - torch.nn.functional.gelu(ref_pre)).abs().max()) <= 1e-2 * scale
+    # what the kernel leaves for backward / the residual add == the LayerNorm kernel's outputs (same formula, statistics from partials)
+    y2, mean2, rstd2 = ops.layernorm_fwd(s_sum, gamma, beta)
+    assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-5) and torch.allclose(rstd, rstd2, rtol=2e-5, atol=1e-6)
+    assert not torch.isnan(y.float()).any()
+    assert float((y.float() - y2.float()).abs().max()) <= 2 ** -7 * float(y2.float().abs().max())      # a last-bit statistic may flip a bf16 rounding
+
+
+def test_folded_layernorm_requests_are_refused_where_no_kernel_has_them(gemm_path):
+    """The launcher must not compute something else: a consumer request on a configuration without the folded epilogue, or a
+    statistics request on an fp32 output, is an error (the engine asks crct_gemm_lnf_ok / crct_gemm_tile_cols first)."""
+    dev = "cuda"
+    M, H, N = 256, 128, 256
+    s_sum = torch.randn(M, H, device=dev).bfloat16()
+    w = torch.randn(N, H, device=dev).bfloat16()
+    z = torch.zeros(max(M, N), device=dev)
+    stats = torch.zeros(M, 2, 2, device=dev)
+    lnf = dict(stats=stats, tiles=2, c=z, gamma=z, beta=z, y=torch.empty(M, H, device=dev, dtype=torch.bfloat16), mean=z.clone(), rstd=z.clone())
+    with pytest.raises(RuntimeError):
+        ops.gemm(s_sum, w, M, N, H, bias=z, lnf=lnf, tile=4)            # 128 x 128 tiles: no consumer
+    with pytest.raises(RuntimeError):
+        ops.gemm(s_sum, w, M, N, H, bias=z, out_f32=True, ln_stats_out=stats)

@@ -1,0 +1,63 @@
+"""Time the training step (configs[1]) under lab switches that bench.py does not offer (timing only where noted):
+    python tools/lab/step_time.py [--no-fold] [--static-fold] [--steps N]
+--static-fold: the gamma-folded weight shadow is NOT refreshed behind AdamW (stale after the first update: wrong numerics) -- prices the
+fold kernels' share of the step."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (os.path.join(ROOT, "cqa-crct_amd"), ROOT):
+    sys.path.insert(0, p)
+import torch                                             # noqa: E402
+from crct import config as CFG, synthetic as S           # noqa: E402
+from crct.model import VisualDialogEncoder               # noqa: E402
+from crct.optim import get_optimizer, WarmupLinearScheduleNonZero, FusedAdamW   # noqa: E402
+from crct.step_adapter import forward as step_forward    # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fold", action="store_true")
+    ap.add_argument("--static-fold", action="store_true")
+    ap.add_argument("--no-fused-heads", action="store_true")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfg = CFG.vilbert_config(v_feature_size=2048)
+    params = CFG.default_params(device=dev, batch_size=80, seed=0, ln_fold=a.fold, fused_heads=not a.no_fused_heads)
+    model = VisualDialogEncoder(params, config=cfg)
+    core = model.bert_pretrained
+    core.sync_stats = False
+    core.stream_mode = (1, 1)
+    model.train()
+    opt = get_optimizer(params, model)
+    opt.overlap = True
+    if a.static_fold:
+        FusedAdamW._refold = lambda self, seg, stream, wgs: setattr(self, "_folds_kept", True)
+    sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
+    pool = [{k: v.to(dev) for k, v in S.make_batch(80, 20, 36, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
+
+    def step(i):
+        loss = step_forward(model, pool[i % 8], params)[0]
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+    for i in range(8):
+        step(i)
+    out = []
+    for _ in range(a.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / a.steps * 1e3)
+    print("step_time fold=%s static=%s fused_heads=%s: %s ms" % (a.fold, a.static_fold, not a.no_fused_heads, ", ".join("%.3f" % x for x in out)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
