@@ -98,6 +98,13 @@ def parse():
                     "parameter, consumed by the fused AdamW as it lies; fp32: the reference's payload)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1 only: run the bucketed exchange (per-segment callback, pack, all_reduce on a "
                     "single-rank RCCL communicator, AdamW from the bf16 buffer) inside the timed step -- the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--ghost-ranks", type=int, default=0, help="with --force-exchange on ONE GPU: predict the N-rank step -- behind every bucket's "
+                    "single-rank all-reduce a stand-in kernel with RCCL's footprint (--ghost-channels workgroups streaming the bucket 2 (N - 1) / N "
+                    "times through HBM, held for bytes x 2 (N - 1) / N / --ghost-bus-gbps) runs on the exchange's stream; reported as "
+                    "config.gradient_allreduce.ghost.  Nothing is reduced: the losses are the 1-rank run's")
+    ap.add_argument("--ghost-channels", type=int, default=128, help="workgroups of the stand-in (RCCL logs its channel count at init: 128 on this stack)")
+    ap.add_argument("--ghost-bus-gbps", type=float, default=350.0, help="bus bandwidth the stand-in assumes (7 xGMI links x ~153 GB/s per GPU, ~350 GB/s "
+                    "reached by ring all-reduces on 8 x MI300-class nodes)")
     ap.add_argument("--emulate-ranks", type=int, default=1, help="test hook (N = 1): every step's batch is the CONCATENATION of the batches R "
                     "ranks would draw (batch R x --batch): the run a data-parallel R-rank run must agree with (config.global_loss)")
     ap.add_argument("--no-dropout", action="store_true", help="test hook: dropout probabilities 0 (run-to-run and rank-count independent losses)")
@@ -541,6 +548,10 @@ def main():
         if a.exchange_pack_all:
             ddp.direct_bf16_wgrad = False
         ddp.debug_skip = tuple(filter(None, a.exchange_skip.split(",")))
+        if a.ghost_ranks > 1:
+            if world != 1 or not a.force_exchange:
+                raise SystemExit("--ghost-ranks needs --force-exchange on one GPU")
+            ddp.ghost = dict(ranks=a.ghost_ranks, channels=a.ghost_channels, bus_GBps=a.ghost_bus_gbps)
     stats_red = AsyncStats(world, device=dev, ddp=ddp) if (exchange and "stats" not in a.exchange_skip) else None
     host_pool = [S.make_batch(a.batch, a.tokens, a.vis, a.feat, seed=1234 + rank + 97 * i) for i in range(8)]
     if a.emulate_ranks > 1:                          # what `emulate_ranks` data-parallel ranks see in one step, as ONE batch
@@ -683,6 +694,10 @@ def main():
                          "collectives_issued": getattr(rc, "collectives", None), "world": world,
                          "channels_logged_at_init": RC.channels_from_debug_log(rccl_log) if rccl_log else None,
                          "init_log_enabled_by_bench": bool(rccl_log)},      # NCCL_DEBUG=INFO / SUBSYS=INIT / DEBUG_FILE in env are then bench.py's
+                "ghost": (dict(ddp.ghost, stand_in_ms_per_step=ddp.ghost_us / 1e3,
+                               note="one-GPU prediction of the %d-rank step: per bucket a kernel of %d workgroups streams the payload twice through HBM and holds "
+                                    "its stream for payload x 2 (N - 1) / N / bus bandwidth (crct_ghost_collective); nothing is reduced"
+                                    % (ddp.ghost["ranks"], ddp.ghost["channels"])) if ddp.ghost else None),
                 "allreduce_bytes": used * 4, "allreduce_ms": ar * 1e3,
                 "bus_GBps": 2.0 * (world - 1) / world * used * 4 / ar / 1e9,
                 "step_payload": {"dtype": a.grad_dtype, "bytes_per_step": used * (2 if a.grad_dtype == "bf16" else 4),

@@ -158,6 +158,11 @@ class FlatGradDDP(object):
         self.event_mode = True       # False: segment-by-segment engine calls with the collectives launched in between
         self.require_sync = True
         self.force_exchange = False  # run the bucketed exchange even on a single rank (single-rank RCCL communicator: tests, probes)
+        # one-GPU prediction of an N-rank run (bench.py --ghost-ranks N): behind every bucket's (single-rank) all-reduce a stand-in kernel
+        # with RCCL's footprint -- `channels` workgroups streaming the bucket 2 (N - 1) / N times through HBM for as long as the ring
+        # would need at `bus_GBps` -- runs on the exchange's stream (crct_ghost_collective).  dict(ranks, channels, bus_GBps) or None.
+        self.ghost = None
+        self.ghost_us = 0.0          # stand-in time issued in the last pass (sum over the buckets)
         self.last_exchange = None    # BucketExchange of the last synchronised backward pass
         self.issued_inside_engine_call = 0      # collectives launched from the engine's callback during the last pass
         self._grad_source_valid = False
@@ -373,6 +378,18 @@ class FlatGradDDP(object):
         self.packed_runs_only = plans is not None and direct
         rccl = self.communicator()
         collective = (lambda t: rccl.all_reduce_(t, comm)) if rccl is not None else None        # on the auxiliary stream itself: no hidden stream
+        if self.ghost and self.world == 1:
+            real, gh = collective, self.ghost
+            self.ghost_us = 0.0
+
+            def collective(t, real=real, gh=gh):
+                if real is not None:
+                    real(t)
+                n = int(gh["ranks"])
+                nbytes = t.numel() * t.element_size()
+                us = nbytes * 2.0 * (n - 1) / n / (float(gh["bus_GBps"]) * 1e3)          # ring all-reduce: 2 (N - 1) / N of the payload per link direction
+                self.ghost_us += us
+                L.check(lib.crct_ghost_collective(t.data_ptr(), nbytes // 16 * 16, int(gh["channels"]), 2, us, comm.cuda_stream), "ghost_collective")
         ex = BucketExchange(core.flat_grads, self._buckets, self.group,
                             comm_buf=self._comm_buf if self.grad_dtype == torch.bfloat16 else None,
                             materialize=materialize, stream_ctx=lambda: torch.cuda.stream(comm), wait_events=wait_events,

@@ -153,6 +153,7 @@ PROTOTYPES = {
     "crct_engine_set_wgrad_workgroups": (C.c_int, [vp, C.c_int, C.c_int]),
     "crct_gemm_class_config": (C.c_int, [C.c_int, C.c_int]),
     "crct_gemm_fp8_scaled_mfma": (C.c_int, [C.c_int]),
+    "crct_ghost_collective": (C.c_int, [vp, c_i64, C.c_int, C.c_int, C.c_double, vp]),
     "crct_cast_f32_bf16": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_bf16_f32": (C.c_int, [vp, vp, c_i64, vp]),
     "crct_cast_runs_f32_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, c_i64, vp]),

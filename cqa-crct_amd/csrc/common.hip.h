@@ -120,7 +120,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
   const float e = __expf(-z * z);                      // = exp(-x^2 / 2)
   const float er = copysignf(erf_as7126_pos(z, e), x);
+#ifdef CRCT_GELU_GRAD_PERTURB      // tools/lab/libcrct_gelu_perturbed.so only: the build tests/test_kernels_gpu.py must be able to tell from this one
+  return CRCT_GELU_GRAD_PERTURB * fmaf(x * kInvSqrt2Pi, e, 0.5f * (1.0f + er));
+#else
   return fmaf(x * kInvSqrt2Pi, e, 0.5f * (1.0f + er));
+#endif
 }
 #endif
 __device__ __forceinline__ float act_apply(int act, float x) {

@@ -21,6 +21,28 @@ __global__ void spin_kernel(long long ticks) {          // s_memrealtime: 100 MH
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// Footprint of a ring all-reduce on THIS GPU without peers (crct_ghost_collective): `channels` workgroups -- RCCL runs one per channel --
+// stream the payload through HBM (read + write back the same bytes: every element belongs to one thread, nothing changes), `passes` times
+// (a ring all-reduce over N ranks reads and writes ~2 (N - 1) / N of the buffer), and pace themselves so that the whole kernel takes
+// `ticks` of the 100 MHz wall clock -- the time the real collective would hold its channels while the bytes cross xGMI.
+typedef unsigned ghost_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ghost_collective_kernel(ghost_u4* __restrict__ buf, long n16, int passes, long long ticks) {
+  const long long t0 = wall_clock64();
+  const long per = (n16 + gridDim.x - 1) / gridDim.x, lo = (long)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+  constexpr int SLICES = 16;
+  const long span = hi > lo ? hi - lo : 0, sl = (span + SLICES - 1) / SLICES;
+  for (int p = 0; p < passes; ++p)
+    for (int s = 0; s < SLICES; ++s) {
+      const long a = lo + (long)s * sl, b = a + sl < hi ? a + sl : hi;
+      for (long i = a + threadIdx.x; i < b; i += 256) {
+        const ghost_u4 v = __builtin_nontemporal_load(buf + i);
+        __builtin_nontemporal_store(v, buf + i);
+      }
+      const long long due = ticks * (long long)(p * SLICES + s + 1) / (long long)(passes * SLICES);
+      while (wall_clock64() - t0 < due) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 // do kernels on streams a and b serialise?  (both streams idle on entry)
 int conflict(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, bool* out) {
   constexpr long long SPIN_US = 120;
@@ -37,6 +59,18 @@ int conflict(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, bool* o
 }
 
 }  // namespace
+
+// Stand-in for a collective that cannot run on a one-GPU box (bench.py --ghost-ranks N): occupies `channels` workgroups on `stream` for
+// `microseconds`, streaming `bytes` at `ptr` (16-byte aligned; left unchanged) through HBM `passes` times.  The data-parallel exchange
+// launches it per bucket where ncclAllReduce would run, so that what RCCL will take from the step -- CUs, HBM bandwidth, a hardware
+// queue, for as long as xGMI needs -- is in the measured step today.  Not a collective: nothing is reduced.
+extern "C" int crct_ghost_collective(void* ptr, int64_t bytes, int channels, int passes, double microseconds, crct_stream_t stream) {
+  CRCT_REQUIRE(ptr && bytes >= 16 && channels >= 1 && passes >= 1 && microseconds >= 0, "ghost_collective: bad arguments");
+  crct_launch(ghost_collective_kernel, dim3((unsigned)channels), dim3(256), 0, (hipStream_t)stream, (ghost_u4*)ptr, (long)(bytes / 16), passes,
+              (long long)(microseconds * 100.0));
+  CRCT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------- kernel stamps
 namespace {

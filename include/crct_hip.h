@@ -313,6 +313,11 @@ int crct_softmax_rows_f32_bf16(const float* x, void* y, int M, int F, crct_strea
 /* The same from bf16 features (a data loader / input pipeline that ships bf16 halves the step's host -> device bytes). */
 int crct_softmax_rows_bf16_bf16(const void* x, void* y, int M, int F, crct_stream_t stream);
 
+/* Stand-in for a gradient all-reduce on a box with ONE GPU (bench.py --ghost-ranks N; CRCT/train.py:138-143 is what it stands in for):
+ * `channels` workgroups on `stream` (RCCL runs one per channel) stream `bytes` at ptr (16-byte aligned, left unchanged) through HBM
+ * `passes` times and pace themselves so that the kernel lasts `microseconds` -- the CUs, the HBM bandwidth and the hardware queue a real
+ * ring all-reduce would hold while the bytes cross xGMI.  Nothing is reduced: a measuring device, not a collective. */
+int crct_ghost_collective(void* ptr, int64_t bytes, int channels, int passes, double microseconds, crct_stream_t stream);
 /* fp32 -> bf16 copy (weight shadow refresh). */
 int crct_cast_f32_bf16(const float* x, void* y, int64_t n, crct_stream_t stream);
 /* bf16 -> fp32 copy (a gradient bucket exchanged as bf16 put back into the fp32 gradient buffer for callers that read .grad). */
