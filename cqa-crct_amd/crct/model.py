@@ -135,12 +135,10 @@ class CrctModel(nn.Module):
         self._grad_waits = None
         self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
-        # launch-count levers of round 5: LayerNorm forward folded into the neighbouring GEMMs, the 13-Linear head
-        # chain as one kernel per pass.  params['ln_fold'] / params['fused_heads'] = False restore one launch per operator (A/B, tests).
+        # launch-count lever of round 5: the LayerNorm forward folded into the neighbouring GEMMs (params['ln_fold']).
         # ln_fold is OFF by default: built, parity-tested and measured in the step -- 615 instead of 649 launches and no gain (7.52 against
         # 7.35 ms; 7.45 even with the fold kernels' 0.77 GB per step taken out): EXPERIMENTS.md round 5
         self.ln_fold = bool(params.get("ln_fold", False)) if params else False
-        self.fused_heads = False
         self._fold, self._fold_ver = None, None
         self.init_weights(int(params.get("seed", 0)))
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate_shadow())

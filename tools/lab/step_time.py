@@ -21,13 +21,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fold", action="store_true")
     ap.add_argument("--static-fold", action="store_true")
-    ap.add_argument("--no-fused-heads", action="store_true")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = CFG.vilbert_config(v_feature_size=2048)
-    params = CFG.default_params(device=dev, batch_size=80, seed=0, ln_fold=a.fold, fused_heads=not a.no_fused_heads)
+    params = CFG.default_params(device=dev, batch_size=80, seed=0, ln_fold=a.fold)
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False
@@ -56,7 +55,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time fold=%s static=%s fused_heads=%s: %s ms" % (a.fold, a.static_fold, not a.no_fused_heads, ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time fold=%s static=%s : %s ms" % (a.fold, a.static_fold, ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":
