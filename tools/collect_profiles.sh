@@ -1,7 +1,7 @@
 # End-of-round evidence, collected on the GPU box in one call:  bash tools/collect_profiles.sh <tag>
 # writes gpurun_out/<tag>_*; the PMC tables are also put under profiles/ of the box's copy so that the bench lines that
 # follow read their roofline.traffic from the same build.
-tag=${1:-r4}
+tag=${1:-r5}
 # optional second argument: space-separated stages (pmc pmcfp8 pmclc stats labs bench); default: all
 stages=${2:-"pmc pmcfp8 pmclc stats labs bench"}
 want() { case " $stages " in *" $1 "*) return 0;; esac; return 1; }
@@ -71,6 +71,8 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --excha
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --dtype fp8 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp8.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange 2> $O/${tag}_bench_n1_forced_exchange.err | grep '^{' > $O/${tag}_bench_n1_forced_exchange.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --grad-dtype fp32 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp32.json
-for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --ghost-ranks 8 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_ghost8.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --ln-fold 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_ln_fold.json
+for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32 bench_n1_ghost8 bench_n1_ln_fold; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
 fi
 head -45 $O/${tag}_pmc_sites.txt

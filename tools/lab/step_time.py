@@ -21,9 +21,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fold", action="store_true")
     ap.add_argument("--static-fold", action="store_true")
+    ap.add_argument("--lib", default="", help="another build of libcrct_hip.so (A/B builds under tools/lab/)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
+    if a.lib:
+        from crct import lib as L
+        L.LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda", 0)
     cfg = CFG.vilbert_config(v_feature_size=2048)
     params = CFG.default_params(device=dev, batch_size=80, seed=0, ln_fold=a.fold)
@@ -55,7 +59,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time fold=%s static=%s : %s ms" % (a.fold, a.static_fold, ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time fold=%s static=%s lib=%s: %s ms" % (a.fold, a.static_fold, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":
