@@ -39,8 +39,17 @@ bool crct_stamp_begin(hipStream_t s, hipEvent_t* start, hipEvent_t* stop);      
 void crct_stamp_adopt(hipStream_t s, hipEvent_t start, hipEvent_t stop);        // a GEMM launch that carries its own event pair (gemm.hip)
 void crct_stamp_enable(int on);
 void crct_stamp_reset(void);
+#ifdef CRCT_GEMM_LAB
+// LAB build only (make lab -> tools/lab/libcrct_lab.so, never the package's library): launches whose kernel name contains one of the
+// comma-separated entries of $CRCT_LAB_SKIP ("name" or "name@k", k = ordinal of the stream in order of first use) are LEFT OUT --
+// wrong results, timing only: what the step gains when a class of kernels costs nothing (tools/lab/step_sensitivity.sh).
+bool crct_lab_skip(const void* kern, hipStream_t s);
+#endif
 template <class K, class... A>
 inline void crct_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... a) {
+#ifdef CRCT_GEMM_LAB
+  if (crct_lab_skip((const void*)kern, s)) return;
+#endif
   hipEvent_t e0, e1;
   if (crct_stamp_begin(s, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, e0, e1, 0u, a...);
   else hipLaunchKernelGGL(kern, grid, block, lds, s, a...);

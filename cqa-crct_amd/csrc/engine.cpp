@@ -1354,6 +1354,10 @@ static int engine_forward_impl(crct_engine_t* e, const float* params_f32, const 
   const int nseg = (int)e->seg_range.size();
   auto wait_params = [&](Run& R, int seg) {
     if (!cfg->seg_ready_events || R.rc) return;
+#ifdef CRCT_GEMM_LAB   // timing only: the forward does not wait for the overlapped optimizer update (reads parameters mid-update)
+    static const bool lab_no_wait = getenv("CRCT_LAB_NO_PARAM_WAIT") != nullptr;
+    if (lab_no_wait) return;
+#endif
     hipEvent_t ev = (hipEvent_t)cfg->seg_ready_events[seg];
     if (ev && hipStreamWaitEvent(R.s, ev, 0) != hipSuccess) { crct_set_error("engine: wait on a parameter-ready event failed"); R.rc = 1; }
   };

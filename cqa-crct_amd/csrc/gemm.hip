@@ -1817,6 +1817,9 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
     ga.p[i] = g;
   }
   ga.tile_begin[n] = total;
+#ifdef CRCT_GEMM_LAB   // ablation bits for the grouped launches alone (CRCT_GEMM_DBG covers every GEMM)
+  { static const int gd = getenv("CRCT_GEMM_DBG_GROUP") ? atoi(getenv("CRCT_GEMM_DBG_GROUP")) : -1; if (gd >= 0) for (int i = 0; i < n; ++i) ga.map[i].dbg = gd; }
+#endif
   if (gs[0].ta && g_group_concat) group_concat(ga, &total);      // the weight gradients of a layer
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   hipError_t e = hipSuccess;

@@ -17,6 +17,12 @@
 #endif
 namespace {
 constexpr int ADAMW_CHUNK = 4096;
+#ifdef CRCT_GEMM_LAB
+__global__ __launch_bounds__(1024) void lab_spin_kernel(long long ticks) {      // ticks of 10 ns; no clock reads, no memory instruction at all
+  const long long n = ticks * 24 / (127 * 64);                                  // s_sleep 127 = 127 x 64 cycles at ~2.4 GHz
+  for (long long i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#endif
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb,
@@ -205,6 +211,16 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   // forward on its own stream is throttled this way (256 = one workgroup per CU): at full width it saturates HBM for
   // 1.4 ms and the first layers of the forward crawl (measured: 10.25-10.36 -> 10.03 ms per step).
   const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
+#ifdef CRCT_GEMM_LAB   // timing only: the update as a kernel of the same grid and duration that touches no memory (what its TRAFFIC costs the forward beside it)
+  static const double lab_spin_tbps = getenv("CRCT_LAB_ADAMW_SPIN") ? atof(getenv("CRCT_LAB_ADAMW_SPIN")) : 0.0;
+  if (lab_spin_tbps > 0.0) {
+    const long long ticks = (long long)((double)n_blk * ADAMW_CHUNK * 30.0 / (lab_spin_tbps * 1e12) * 1e8);
+    static const int spin_threads = getenv("CRCT_LAB_ADAMW_SPIN_THREADS") ? atoi(getenv("CRCT_LAB_ADAMW_SPIN_THREADS")) : 256;
+    static const int spin_grid = getenv("CRCT_LAB_ADAMW_SPIN_GRID") ? atoi(getenv("CRCT_LAB_ADAMW_SPIN_GRID")) : 0;
+    crct_launch(lab_spin_kernel, dim3((unsigned)(spin_grid > 0 ? spin_grid : grid)), dim3(spin_threads), 0, (hipStream_t)stream, ticks);
+    return 0;
+  }
+#endif
   crct_launch(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      seg_off, seg_len, seg_lr, seg_wd, blk_seg, blk_off, beta1, beta2, eps, (float)(1.0 / bc1),
                      (float)(1.0 / sqrt(bc2)), inv_scale_dev, amp, f8, (int)n_blk, zero_grads, (const bf16_t*)g_bf16);

@@ -174,3 +174,60 @@ int crct_streams_place(hipStream_t main, hipStream_t out[4], int* n_classes) {
     if (!out[k] && hipStreamCreateWithFlags(&out[k], hipStreamNonBlocking) != hipSuccess) { crct_set_error("streams: cannot create a HIP stream"); rc = 1; }
   return rc;
 }
+
+#ifdef CRCT_GEMM_LAB
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+namespace {
+struct LabSkip {
+  std::mutex mu;
+  std::vector<std::pair<std::string, int>> rules;       // (substring, stream ordinal or -1)
+  std::vector<hipStream_t> order;
+  std::map<std::pair<int, std::string>, std::pair<long, long>> seen;   // (ordinal, name) -> (launched, skipped)
+  bool report = false;
+  LabSkip() {
+    const char* e = getenv("CRCT_LAB_SKIP");
+    report = getenv("CRCT_LAB_REPORT") != nullptr;
+    if (!e) return;
+    std::string all(e);
+    size_t i = 0;
+    while (i <= all.size()) {
+      size_t j = all.find(',', i);
+      if (j == std::string::npos) j = all.size();
+      std::string r = all.substr(i, j - i);
+      if (!r.empty()) {
+        int ord = -1;
+        const size_t at = r.find('@');
+        if (at != std::string::npos) { ord = atoi(r.c_str() + at + 1); r = r.substr(0, at); }
+        rules.emplace_back(r, ord);
+      }
+      i = j + 1;
+    }
+  }
+  ~LabSkip() {
+    if (!report) return;
+    for (const auto& kv : seen)
+      fprintf(stderr, "[crct lab] stream %d %-60.60s launched %ld skipped %ld\n", kv.first.first, kv.first.second.c_str(), kv.second.first, kv.second.second);
+  }
+};
+LabSkip g_lab_skip;
+}  // namespace
+bool crct_lab_skip(const void* kern, hipStream_t s) {
+  LabSkip& L = g_lab_skip;
+  if (L.rules.empty() && !L.report) return false;
+  std::lock_guard<std::mutex> lk(L.mu);
+  int ord = -1;
+  for (size_t i = 0; i < L.order.size(); ++i) if (L.order[i] == s) ord = (int)i;
+  if (ord < 0) { ord = (int)L.order.size(); L.order.push_back(s); }
+  const char* nm = hipKernelNameRefByPtr(kern, s);
+  const std::string name(nm ? nm : "?");
+  bool skip = false;
+  for (const auto& r : L.rules)
+    if ((r.second < 0 || r.second == ord) && (r.first == "*" || name.find(r.first) != std::string::npos)) skip = true;
+  if (L.report) { auto& c = L.seen[{ord, name}]; (skip ? c.second : c.first) += 1; }
+  return skip;
+}
+#endif
