@@ -103,6 +103,17 @@ def main():
         for g, t in ((256, 256), (256, 64), (256, 128), (64, 256), (128, 256), (1024, 64), (512, 64), (128, 512), (64, 1024), (32, 1024), (512, 256)):
             cases.append(("sleeping stand-in: %d workgroups x %d threads" % (g, t), "", sp(g, t)))
         cases.append(("nothing left out (again)", ""))
+    if a.set == "small":
+        cases = [
+            ("nothing left out", ""),
+            ("the head chain's 64 x 64-tile GEMMs (forward, data gradients)", "gemm_pipe_kernelILi2ELi2ELi2ELi2E"),
+            ("head chain GEMMs + weight gradients + bias sums", "gemm_pipe_kernelILi2ELi2ELi2ELi2E,gemm_kernelILi2ELi2E,colsum_kernel"),
+            ("head row kernels (loss, pooling)", "head_"),
+            ("embedding kernels (forward + backward)", "embed_"),
+            ("image-feature softmax + gather", "softmax_rows,gather_sum"),
+            ("128 x 128-tile GEMMs of the data streams (visual QKV, image embedding)", "gemm_pipe_kernelILi4ELi4ELi2ELi4E"),
+            ("nothing left out (again)", ""),
+        ]
     base = None
     for case in cases:
         name, skip = case[0], case[1]

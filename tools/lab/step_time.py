@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--fold", action="store_true")
     ap.add_argument("--static-fold", action="store_true")
     ap.add_argument("--lib", default="", help="another build of libcrct_hip.so (A/B builds under tools/lab/)")
+    ap.add_argument("--bf16-grads", action="store_true", help="timing only: Linear weight gradients written as bf16 (CrctStepCfg.grads_bf16) and AdamW "
+                    "reading the bf16 buffer for EVERY element (the small fp32-accumulated gradients are not in it: wrong numerics)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
@@ -40,6 +42,22 @@ def main():
     opt.overlap = True
     if a.static_fold:
         FusedAdamW._refold = lambda self, seg, stream, wgs: setattr(self, "_folds_kept", True)
+    if a.bf16_grads:
+        buf = torch.zeros(core.flat_grads.numel(), dtype=torch.bfloat16, device=dev)
+        from crct.engine import StepEngine
+        eng_backward = StepEngine.backward
+
+        def backward(self, p32, p16, g32, tensors, step, seg):
+            if step.get("wgrad_overwrite"):
+                step = dict(step, grads_bf16=buf)
+            return eng_backward(self, p32, p16, g32, tensors, step, seg)
+        StepEngine.backward = backward
+        launch = FusedAdamW._launch
+
+        def _launch(self, b0, b1, inv_scale, stream, max_workgroups=0):
+            self._g16 = buf
+            return launch(self, b0, b1, inv_scale, stream, max_workgroups)
+        FusedAdamW._launch = _launch
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
     pool = [{k: v.to(dev) for k, v in S.make_batch(80, 20, 36, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
 
@@ -59,7 +77,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time fold=%s static=%s lib=%s: %s ms" % (a.fold, a.static_fold, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time bf16_grads=%s fold=%s static=%s lib=%s: %s ms" % (a.bf16_grads, a.fold, a.static_fold, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":
