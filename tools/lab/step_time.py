@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--lib", default="", help="another build of libcrct_hip.so (A/B builds under tools/lab/)")
     ap.add_argument("--bf16-grads", action="store_true", help="timing only: Linear weight gradients written as bf16 (CrctStepCfg.grads_bf16) and AdamW "
                     "reading the bf16 buffer for EVERY element (the small fp32-accumulated gradients are not in it: wrong numerics)")
+    ap.add_argument("--emb-late", type=int, default=0, help="timing only: all but the last N blocks of the embedding segment's AdamW launch run at the "
+                    "END of the update sequence (the forward then waits for N blocks only and may read rows that are not updated yet)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
@@ -58,6 +60,21 @@ def main():
             self._g16 = buf
             return launch(self, b0, b1, inv_scale, stream, max_workgroups)
         FusedAdamW._launch = _launch
+    if a.emb_late:
+        launch0 = FusedAdamW._launch
+        stash = {}
+
+        def _launch2(self, b0, b1, inv_scale, stream, max_workgroups=0):
+            n = len(self._seg_blocks)
+            if (b0, b1) == tuple(self._seg_blocks[n - 1]) and b1 - b0 > a.emb_late:
+                stash["r"] = (b0, b1 - a.emb_late)
+                return launch0(self, b1 - a.emb_late, b1, inv_scale, stream, max_workgroups)
+            r = launch0(self, b0, b1, inv_scale, stream, max_workgroups)
+            if (b0, b1) == tuple(self._seg_blocks[0]) and "r" in stash:
+                c0, c1 = stash.pop("r")
+                launch0(self, c0, c1, inv_scale, stream, self.overlap_workgroups)
+            return r
+        FusedAdamW._launch = _launch2
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
     pool = [{k: v.to(dev) for k, v in S.make_batch(80, 20, 36, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
 
@@ -77,7 +94,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time bf16_grads=%s fold=%s static=%s lib=%s: %s ms" % (a.bf16_grads, a.fold, a.static_fold, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time emb_late=%d bf16_grads=%s fold=%s static=%s lib=%s: %s ms" % (a.emb_late, a.bf16_grads, a.fold, a.static_fold, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":
