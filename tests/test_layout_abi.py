@@ -84,6 +84,16 @@ def test_library_exports_every_declared_symbol():
     assert handle.crct_abi_version() == 4
 
 
+def test_shipped_library_carries_no_lab_hook():
+    """The timing ablations (leave-one-out launches, GEMM kernels without DMA / epilogue, the sleeping AdamW stand-in) exist only in the
+    -DCRCT_GEMM_LAB build under tools/lab/ (`make -C cqa-crct_amd/csrc lab`): the package's library must not be able to skip work, and it
+    reads no CRCT_* environment variable."""
+    with open(L.LIB_PATH, "rb") as f:
+        blob = f.read()
+    for needle in (b"crct_lab_skip", b"CRCT_LAB_", b"CRCT_GEMM_DBG", b"lab_spin_kernel"):
+        assert needle not in blob, needle
+
+
 def test_struct_mirrors_and_error_path():
     # sizes from the header's field lists (LP64)
     assert C.sizeof(L.GemmArgs) == (7 * 8 + 5 * 8 + 10 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 5 * 8 + 8 + 4 + 4 + 8 + 8     # ... seed, rowsum_out, fp8 (+pad), 5 pointers, ld_q, site, split_k, 2 pointers
