@@ -9,6 +9,8 @@
 // candidate streams, sorts them into queue classes against the caller's stream by that probe, and hands back one stream per
 // foreign class (+ a second one of the last class): the engine's visual / weight-gradient streams and the auxiliary stream the
 // host-side glue (optimizer overlap, gradient exchange) runs on.  One-time cost: a few milliseconds per engine.
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.hip.h"
@@ -77,10 +79,12 @@ namespace {
 struct Stamp { hipEvent_t a, b; hipStream_t s; bool own; };
 std::vector<Stamp> g_stamps;          // slots [0, g_used) belong to the running collection; events of `own` slots are reused after a reset
 size_t g_used = 0;
-bool g_stamp_on = false;
+std::atomic<bool> g_stamp_on{false};
+std::mutex g_stamp_mu;                // forward and backward are enqueued by different host threads (autograd's worker): one store, one lock
 }  // namespace
-void crct_stamp_enable(int on) { g_stamp_on = on != 0; }
+void crct_stamp_enable(int on) { g_stamp_on.store(on != 0); }
 void crct_stamp_reset(void) {
+  std::lock_guard<std::mutex> lk(g_stamp_mu);
   // adopted pairs belong to the GEMM profile (gemm.hip): drop their slots, keep our own events for reuse
   std::vector<Stamp> keep;
   for (const Stamp& st : g_stamps) if (st.own) keep.push_back(st);
@@ -88,7 +92,8 @@ void crct_stamp_reset(void) {
   g_used = 0;
 }
 bool crct_stamp_begin(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
-  if (!g_stamp_on) return false;
+  if (!g_stamp_on.load(std::memory_order_relaxed)) return false;
+  std::lock_guard<std::mutex> lk(g_stamp_mu);
   while (g_used < g_stamps.size() && !g_stamps[g_used].own) ++g_used;          // (adopted slots sit where they were appended)
   if (g_used == g_stamps.size()) {
     Stamp st; st.own = true; st.s = s;
@@ -101,17 +106,19 @@ bool crct_stamp_begin(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
   return true;
 }
 void crct_stamp_adopt(hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-  if (!g_stamp_on) return;
+  if (!g_stamp_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_stamp_mu);
   Stamp st; st.a = start; st.b = stop; st.s = s; st.own = false;
   g_stamps.insert(g_stamps.begin() + (long)g_used, st);
   ++g_used;
 }
 // Number of stamped launches since the last reset / the i-th one: its stream and its begin / end in milliseconds after the FIRST stamped
 // launch began (synchronises on the events).
-extern "C" int crct_prof_stamp_count(void) { return (int)g_used; }
+extern "C" int crct_prof_stamp_count(void) { std::lock_guard<std::mutex> lk(g_stamp_mu); return (int)g_used; }
 extern "C" int crct_prof_stamp_read(int i, void** stream, double* t0_ms, double* t1_ms) {
+  std::lock_guard<std::mutex> lk(g_stamp_mu);
   if (i < 0 || (size_t)i >= g_used || !stream || !t0_ms || !t1_ms) return 1;
-  const Stamp& st = g_stamps[(size_t)i];
+  const Stamp st = g_stamps[(size_t)i];
   CRCT_CHECK_HIP(hipEventSynchronize(st.b));
   float a = 0.f, d = 0.f;
   if (i > 0) {

@@ -26,6 +26,9 @@ def main():
                     "reading the bf16 buffer for EVERY element (the small fp32-accumulated gradients are not in it: wrong numerics)")
     ap.add_argument("--emb-late", type=int, default=0, help="timing only: all but the last N blocks of the embedding segment's AdamW launch run at the "
                     "END of the update sequence (the forward then waits for N blocks only and may read rows that are not updated yet)")
+    ap.add_argument("--batch", type=int, default=80)
+    ap.add_argument("--vis", type=int, default=36)
+    ap.add_argument("--tokens", type=int, default=20)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
@@ -34,7 +37,7 @@ def main():
         L.LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda", 0)
     cfg = CFG.vilbert_config(v_feature_size=2048)
-    params = CFG.default_params(device=dev, batch_size=80, seed=0, ln_fold=a.fold)
+    params = CFG.default_params(device=dev, batch_size=a.batch, seed=0, ln_fold=a.fold)
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False
@@ -76,7 +79,7 @@ def main():
             return r
         FusedAdamW._launch = _launch2
     sched = WarmupLinearScheduleNonZero(opt, warmup_steps=params["warmup"], t_total=60000, min_lr=params["min_lr"])
-    pool = [{k: v.to(dev) for k, v in S.make_batch(80, 20, 36, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
+    pool = [{k: v.to(dev) for k, v in S.make_batch(a.batch, a.tokens, a.vis, 2048, seed=1234 + 97 * i).items()} for i in range(8)]
 
     def step(i):
         loss = step_forward(model, pool[i % 8], params)[0]
