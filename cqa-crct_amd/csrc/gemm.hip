@@ -405,7 +405,7 @@ constexpr int epilogue_passes() {
 
 // NTH: threads that walk the staged tile (default: the WM x WN compute waves; the loader-wave kernels pass their whole workgroup --
 // waves beyond WM x WN hold no accumulators, their wm is >= WM and they never park anything)
-template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING, int NTH = 0, bool LNFE = false>
+template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING, int NTH = 0, bool LNFE = false, bool STATS = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
                                                      int wm, int wn, int lane, int tid, int dbg = 0) {
 #ifdef CRCT_GEMM_LAB   // lab ablations (tools/lab/step_ablate.sh): 64 = no activation / derivative / dropout arithmetic, 128 = no side inputs or outputs
@@ -543,7 +543,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
         }
         const uint4 pk = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
         *dst = pk;
-        if constexpr (CPR == 8 || CPR == 16) {
+        // STATS: compiled into the producers of the folded LayerNorm only (launch_pipe<..., PM = 4>): carried as a run-time branch by
+        // every kernel it cost the plain 128 x 64 kernels registers and 0.05 - 0.07 ms per step (round 5, same-box A/B against round 4)
+        if constexpr (STATS && (CPR == 8 || CPR == 16)) {
           if (g.ln_stats_out) {
             // LayerNorm partial statistics of this row's BN columns (folded LayerNorm, producer side): the values AS STORED (bf16),
             // summed over the CPR lanes that hold the row's chunks -- consecutive lanes of one wave (DPP, no LDS) -- first the sum,
@@ -698,6 +700,7 @@ template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, bool SK = fa
 __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg,
                                                const int slice = 0, const int tile_lin = 0, const int tiles_n = 1) {
   static_assert(!LNF || (!TA && !TB && !SK && PM == 0), "folded LayerNorm: forward GEMM, plain loop");
+  static_assert(PM == 0 || PM == 1 || PM == 4, "PM: 0 plain loop, 1 register-pipelined loop, 4 plain loop + LayerNorm partial statistics in the epilogue");
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave per K tile
@@ -990,7 +993,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
       }
     }
   }
-  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE, 0, LNF>(g, acc, smem, m0, n0, wm, wn, lane, tid, lab_bits(dbg));
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE, 0, LNF, (PM & 4) != 0>(g, acc, smem, m0, n0, wm, wn, lane, tid, lab_bits(dbg));
   if constexpr (LNF) {
     if (lnf_kt >= 0) {      // LN(s) of K step lnf_kt (computed in the loop), written last: nothing of this workgroup waits for these stores
 #pragma unroll
@@ -2266,12 +2269,14 @@ static int resolve_config(const CrctGemmArgs& g, bool& pipe) {
   if (!pipe && t == 0) t = 1;
   return t;
 }
+// the kernels that exist with the producer's statistics epilogue (launch_pipe<..., PM = 4>)
+static bool stats_cfg_ok(int t) { return t == 15 || t == 12 || t == 3 || t == 4 || t == 9; }
 extern "C" int crct_gemm_tile_cols(const CrctGemmArgs* a) {
-  if (!a || (a->fp8 & 1) || a->ta || a->c_is_f32 || a->M <= 0 || a->N <= 0) return 0;
+  if (!a || (a->fp8 & 1) || a->ta || a->c_is_f32 || a->M <= 0 || a->N <= 0 || a->split_k > 1) return 0;
   bool pipe = false;
   const int t = resolve_config(*a, pipe);
   int bm = 0, bn = 0;
-  if (!pipe || !cfg_tile(t, bm, bn) || (bn != 64 && bn != 128) || a->N % bn != 0) return 0;
+  if (!pipe || !stats_cfg_ok(t) || !cfg_tile(t, bm, bn) || (bn != 64 && bn != 128) || a->N % bn != 0) return 0;
   return bn;
 }
 // the folded-LayerNorm consumer exists for the 64-column configurations 15 (128 x 64, 3 stages), 12 (2 stages) and 3 (64 x 64: tiny row
@@ -2318,7 +2323,8 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g.lnf_c && (is_f8 || !lnf_cfg_ok(g, t, pipe))) return hipErrorInvalidValue;
   if (g.ln_stats_out) {
     int bm = 0, bn = 0;
-    if (is_f8 || !pipe || g.ta || g.c_is_f32 || !cfg_tile(t, bm, bn) || (bn != 64 && bn != 128) || g.N % bn != 0 || g.ln_stats_ld != g.N / bn) return hipErrorInvalidValue;
+    if (is_f8 || !pipe || g.ta || g.c_is_f32 || g.split_k || g.lnf_c || !stats_cfg_ok(t) || !cfg_tile(t, bm, bn) || (bn != 64 && bn != 128) || g.N % bn != 0 ||
+        g.ln_stats_ld != g.N / bn) return hipErrorInvalidValue;
   }
   prof_begin((pipe ? t : 16 + (t & 3)) * 3 + kind_of(g), &g, 1);
   hipError_t e;
@@ -2331,6 +2337,14 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 9: e = launch_splitk<4, 4, 2, 4, 2>(g, s); break;
       case 15: e = launch_splitk<4, 2, 4, 2, 3>(g, s); break;
       default: e = launch_splitk<4, 2, 4, 2, 2>(g, s); break;
+    }
+  } else if (pipe && g.ln_stats_out) {      // producer of a folded LayerNorm: the plain loop with the statistics epilogue
+    switch (t) {
+      case 3: e = launch_pipe<2, 2, 2, 2, 4, 4>(g, s); break;
+      case 4: e = launch_pipe<4, 4, 2, 4, 3, 4>(g, s); break;
+      case 9: e = launch_pipe<4, 4, 2, 4, 2, 4>(g, s); break;
+      case 12: e = launch_pipe<4, 2, 4, 2, 2, 4>(g, s); break;
+      default: e = launch_pipe<4, 2, 4, 2, 3, 4>(g, s); break;     // 15
     }
   } else if (pipe && g.lnf_c) {
     switch (t) {
