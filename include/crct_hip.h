@@ -85,7 +85,9 @@ typedef struct CrctGemmArgs {
    *   producer  ln_stats_out != NULL: besides C = s (bf16) the epilogue writes, per output row and column tile, the partial
    *             statistics of the bf16-rounded s: float2 (sum, sum of squared deviations from the tile's own mean) at
    *             ln_stats_out[(row * ln_stats_ld + column_tile) * 2] -- fixed slots, no atomics.  ln_stats_ld = N / tile columns
-   *             (crct_gemm_tile_cols); needs a bf16 C and N % tile columns == 0.
+   *             (crct_gemm_tile_cols); needs a bf16 C and N % tile columns == 0.  A kernel variant of its own (compiled for the
+   *             configurations 15 / 12 / 3 / 4 / 9 only; not with split_k, lnf_c, fp8): launches without ln_stats_out run the
+   *             plain kernels, whose code does not contain the statistics at all.
    *   consumer  lnf_c != NULL: A is the RAW pre-norm sum s [M][K] (lda = K), B the gamma-folded weight bf16(W[n][k] * gamma[k])
    *             (crct_ln_fold_weights), bias the folded bias b'[n] = b[n] + sum_k W[n][k] beta[k], lnf_c[n] = sum_k B[n][k].  Every
    *             workgroup combines the lnf_tiles partials of its rows (Chan's parallel variance: mean, rstd with eps inside the
@@ -101,7 +103,8 @@ typedef struct CrctGemmArgs {
   void* lnf_y; float* lnf_mean; float* lnf_rstd; float lnf_eps;
 } CrctGemmArgs;
 /* Columns of the output tile the launcher would give this GEMM if it can write LayerNorm partial statistics (CrctGemmArgs.ln_stats_out):
- * 64 or 128; 0 = this launch cannot (register-staged kernel, fp32 output, N not a multiple of the tile, other tile widths). */
+ * 64 or 128; 0 = this launch cannot (a configuration without the statistics variant, register-staged kernel, fp32 output, split_k,
+ * N not a multiple of the tile). */
 int crct_gemm_tile_cols(const CrctGemmArgs* args);
 /* != 0: this GEMM (with lnf_* set) would run on a kernel that implements the folded LayerNorm consumer. */
 int crct_gemm_lnf_ok(const CrctGemmArgs* args);
