@@ -232,8 +232,14 @@ template <int NQ, int NK, int ND> struct BwdLds {
 
 // W independent (batch, head) pairs per workgroup, SP cooperating waves per pair (query tiles it = part, part + SP, ...):
 // the arithmetic per tile is the same for every SP, so are the results bit for bit.
+// Kernel-argument preload (gemm.hip, GEMM_HOT_PARAMS): what the first instructions need (operand pointers, sizes, leading dimensions) as 15
+// leading scalar arguments -- gfx950 hands the first argument dwords to the wave in SGPRs; a struct passed by value is fetched by scalar loads.
+#define ATTN_HOT_PARAMS const bf16_t* hq, const bf16_t* hk, const bf16_t* hv, const uint8_t* hkm, int hB, int hheads, int hTq, int hTk, int hldq, int hldk, int hldv, const AttnArgs a_in
+#define ATTN_HOT_UNPACK AttnArgs a = a_in; a.q = hq; a.k = hk; a.v = hv; a.keymask = hkm; a.B = hB; a.heads = hheads; a.Tq = hTq; a.Tk = hTk; a.ldq = hldq; a.ldk = hldk; a.ldv = hldv;
+#define ATTN_HOT_ARGS(a) (a).q, (a).k, (a).v, (a).keymask, (a).B, (a).heads, (a).Tq, (a).Tk, (int)(a).ldq, (int)(a).ldk, (int)(a).ldv,
 template <int NQ, int NK, int ND, int W, int SP>
-__global__ __launch_bounds__(64 * W * SP) void attn_fwd_mfma(const AttnArgs a) {
+__global__ __launch_bounds__(64 * W * SP) void attn_fwd_mfma(ATTN_HOT_PARAMS) {
+  ATTN_HOT_UNPACK
   constexpr int STB = FwdLds<NQ, NK, ND>::STB;
   constexpr int NQL = (NQ + SP - 1) / SP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -313,7 +319,8 @@ __global__ __launch_bounds__(64 * W * SP) void attn_fwd_mfma(const AttnArgs a) {
 // products that contract over the queries (dv, dk) by KEY tiles jt = part, part + SP, ... from the P / dS image all waves
 // have filled.  Every tile is computed exactly as with one wave, in the same summation order: bit-identical results.
 template <int NQ, int NK, int ND, int W, int SP>
-__global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(const AttnArgs a) {
+__global__ __launch_bounds__(64 * W * SP) void attn_bwd_mfma(ATTN_HOT_PARAMS) {
+  ATTN_HOT_UNPACK
   typedef BwdLds<NQ, NK, ND> G;
   constexpr int STB = G::STB, PSB = G::PSB;
   constexpr int NQL = (NQ + SP - 1) / SP, NKL = (NK + SP - 1) / SP;
@@ -557,7 +564,7 @@ hipError_t launch_sp(const AttnArgs& a, hipStream_t s) {
     raised = true;
   }
   const int total = a.B * a.heads;
-  crct_launch(kern, dim3((total + W - 1) / W), dim3(64 * W * SP), BYTES * W, s, a);
+  crct_launch(kern, dim3((total + W - 1) / W), dim3(64 * W * SP), BYTES * W, s, ATTN_HOT_ARGS(a) a);
   return hipGetLastError();
 }
 // Waves per (batch, head): 4 when both sides have at least four tiles, 2 with at least two (each wave then owns whole query

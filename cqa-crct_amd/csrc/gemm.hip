@@ -205,6 +205,22 @@ struct Stage {
 // the A' and B' panels one XCD touches (rm*BM + rn*BN rows of K) are as few as possible and stay
 // L2-resident; block j of XCD x takes the j-th tile of rectangle x.  Placement only affects speed.
 struct TileMap { int tiles_m, tiles_n, gn, rm, rn, dbg; };   // dbg: ablation bits of the -DCRCT_GEMM_LAB build (tools/gemm_lab); the shipped library ignores them
+
+// Kernel-argument PRELOAD (round 5).  gfx950 hands the first <= 16 argument dwords to every wave in SGPRs when they are scalars or pointers
+// (-mllvm -amdgpu-kernarg-preload-count=16 in the Makefile); a struct passed by value is fetched by scalar loads after the wave has
+// started -- from an argument segment the host wrote microseconds ago.  Every GEMM entry kernel therefore takes what its FIRST instructions
+// need -- operand pointers and leading dimensions, the problem size, the tile map -- as 14 leading scalars, and the full CrctGemmArgs /
+// TileMap behind them for everything the epilogue reads later.  Dependent chain of small kernels: 10.05 -> 9.77 us per launch
+// (tools/lab/kernarg_probe.hip); the step: -0.05 ms (profiles/r5_kernarg_preload_ab.txt).
+#define GEMM_HOT_PARAMS                                                                                                                    \
+  const void* hA, const void* hB, int hlda, int hldb, int hM, int hN, int hK, int t_m, int t_n, int t_gn, int t_rm, int t_rn,             \
+      const CrctGemmArgs g_in, const TileMap tmap_in
+#define GEMM_HOT_UNPACK                                                                                                                    \
+  CrctGemmArgs g = g_in;                                                                                                                   \
+  g.A = hA; g.B = hB; g.lda = hlda; g.ldb = hldb; g.M = hM; g.N = hN; g.K = hK;                                                            \
+  TileMap tmap = tmap_in;                                                                                                                  \
+  tmap.tiles_m = t_m; tmap.tiles_n = t_n; tmap.gn = t_gn; tmap.rm = t_rm; tmap.rn = t_rn;
+#define GEMM_HOT_ARGS(g, tmap) (g).A, (g).B, (int)(g).lda, (int)(g).ldb, (g).M, (g).N, (g).K, (tmap).tiles_m, (tmap).tiles_n, (tmap).gn, (tmap).rm, (tmap).rn,
 #ifdef CRCT_GEMM_LAB
 __device__ __forceinline__ int lab_bits(int dbg) { return dbg; }
 #else
@@ -318,7 +334,8 @@ __device__ __forceinline__ void gemm_epilogue(const CrctGemmArgs& g, f4_t (&acc)
 }
 
 template <int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__(256) void gemm_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   constexpr int BM = 32 * TM, BN = 32 * TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;
@@ -1007,14 +1024,16 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
 }
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int PM = 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tile_m, tile_n, tmap.dbg);
 }
 // the folded-LayerNorm consumer (forward only): BM * 8 more bytes of LDS behind the ring for the row statistics
 template <int TM, int TN, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_lnf_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_lnf_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   gemm_pipe_body<TM, TN, WM, WN, false, false, NS, false, 0, true>(g, tile_m, tile_n, 0, 0, 0, tmap.tiles_n);
@@ -1023,7 +1042,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_lnf_kernel(const CrctGemmAr
 // K-partitioned launch: block j of XCD x is slice j % S of the (j / S)-th tile of that XCD's rectangle -- a tile's slices share
 // an L2 (speed only).  Grid = 8 * rm * rn * S.
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   const int S = g.split_k;
   const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
   int tile_m, tile_n;
@@ -1301,7 +1321,8 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
 }
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, int PIPE = 0>
-__global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ldr_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ldr_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   gemm_ldr_body<TM, TN, WM, WN, TA, TB, NS, NL, PIPE>(g, tile_m, tile_n, tmap.dbg);
@@ -1338,7 +1359,8 @@ __device__ __forceinline__ v8i_t f8_pair(const bf8_t& lo, const bf8_t& hi) {
 constexpr int MX_ONE = 0x7F7F7F7F;       // four e8m0 block scales of 2^0
 
 template <int TM, int TN, int WM, int WN, int NS, bool A_BF8 = false, bool MX = false>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
@@ -1478,7 +1500,7 @@ hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                                 \
+    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);                                                 \
   } while (0)
   if (g_f8_mx) { if (g.fp8 & 2) CRCT_LAUNCH_F8(true, true); else CRCT_LAUNCH_F8(false, true); }
   else { if (g.fp8 & 2) CRCT_LAUNCH_F8(true, false); else CRCT_LAUNCH_F8(false, false); }
@@ -1663,7 +1685,8 @@ __device__ __forceinline__ void gemm_f8t_body(const CrctGemmArgs& g, int tile_m,
 }
 
 template <int TM, int TN, int WM, int WN, int NS, bool MX = false>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_kernel(const CrctGemmArgs g, const TileMap tmap) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f8t_kernel(GEMM_HOT_PARAMS) {
+  GEMM_HOT_UNPACK
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   gemm_f8t_body<TM, TN, WM, WN, NS, MX>(g, tile_m, tile_n);
@@ -1685,7 +1708,7 @@ hipError_t launch_f8t(const CrctGemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                                 \
+    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);                                                 \
   } while (0)
   if (g_f8_mx) CRCT_LAUNCH_F8T(true);
   else CRCT_LAUNCH_F8T(false);
@@ -1944,7 +1967,7 @@ hipError_t launch_splitk(const CrctGemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(tiles * g.split_k), dim3(WM * WN * 64), lds, s, g, tmap);                                     \
+    launch_kernel(kern, dim3(tiles * g.split_k), dim3(WM * WN * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);                                     \
   } while (0)
   if (g.ta) return hipErrorInvalidValue;
   if (g.tb) CRCT_LAUNCH_SK(true);
@@ -1969,7 +1992,7 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);                                            \
+    launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);                      \
   } while (0)
   if (!g.ta && !g.tb) CRCT_LAUNCH_PIPE(false, false);
   else if (!g.ta && g.tb) CRCT_LAUNCH_PIPE(false, true);
@@ -1992,7 +2015,7 @@ hipError_t launch_lnf(const CrctGemmArgs& g, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, g, tmap);
+  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);
   return hipGetLastError();
 }
 
@@ -2012,7 +2035,7 @@ hipError_t launch_ldr(const CrctGemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;                                                                                       \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    launch_kernel(kern, dim3(tiles), dim3((WM * WN + NL) * 64), lds, s, g, tmap);                                          \
+    launch_kernel(kern, dim3(tiles), dim3((WM * WN + NL) * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);                                          \
   } while (0)
   if (!g.ta && !g.tb) CRCT_LAUNCH_LDR(false, false);
   else if (!g.ta && g.tb) CRCT_LAUNCH_LDR(false, true);
@@ -2039,9 +2062,9 @@ hipError_t launch_cfg(const CrctGemmArgs& g, hipStream_t s) {
   int tiles = 0;
   const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)(BM + BN) * BK * 2;
-  if (!g.ta && !g.tb) launch_kernel(gemm_kernel<TM, TN, false, false>, dim3(tiles), dim3(256), lds, s, g, tmap);
-  else if (!g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, false, true>, dim3(tiles), dim3(256), lds, s, g, tmap);
-  else if (g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, true, true>, dim3(tiles), dim3(256), lds, s, g, tmap);
+  if (!g.ta && !g.tb) launch_kernel(gemm_kernel<TM, TN, false, false>, dim3(tiles), dim3(256), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);
+  else if (!g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, false, true>, dim3(tiles), dim3(256), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);
+  else if (g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, true, true>, dim3(tiles), dim3(256), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -572,8 +572,17 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, cons
     if (lane == 0) amax_update(a.q_amax, amax);
   }
 }
+// Kernel-argument preload (gemm.hip, GEMM_HOT_PARAMS): the LayerNorm kernels of the data streams' chains take what their first instructions
+// need as leading scalar arguments (gfx950 preloads the first argument dwords into SGPRs; a struct passed by value is fetched by scalar
+// loads after the wave has started).
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdP a) { ln_fwd_body<NCH>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean_o, float* rstd_o, int M, int H,
+                                                       float eps, uint32_t thr, const LnFwdP a_in) {
+  LnFwdP a = a_in;
+  a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean_o = mean_o; a.rstd_o = rstd_o; a.M = M; a.H = H; a.eps = eps; a.thr = thr;
+  ln_fwd_body<NCH>(a, blockIdx.x, gridDim.x);
+}
+#define LN_FWD_HOT(p) (p).x, (p).gamma, (p).beta, (p).y, (p).mean_o, (p).rstd_o, (p).M, (p).H, (p).eps, (p).thr,
 
 // ------------------------------------------------------------------------------ LayerNorm bwd
 // COMBINE: the four waves of a workgroup add their column partials through LDS and store ONE partial row set per
@@ -658,7 +667,13 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, cons
 }
 
 template <int NCH, bool COMBINE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP a) { ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd, const float* gamma, int M, int H,
+                                                       bf16_t* dx, bf16_t* dxl, const LnBwdP a_in) {
+  LnBwdP a = a_in;
+  a.dy = dy; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.M = M; a.H = H; a.dx = dx; a.dxl = dxl;
+  ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, gridDim.x);
+}
+#define LN_BWD_HOT(p) (p).dy, (p).x, (p).mean, (p).rstd, (p).gamma, (p).M, (p).H, (p).dx, (p).dxl,
 
 // out_q[c] (+)= sum_blk partials[q][blk][c]  for q < Q (NULL outputs skipped); out_q may have a leading
 // dimension (ldo) > 1 column group: out index = c*stride_q
@@ -1085,7 +1100,7 @@ static int ln_fwd_launch(const CrctLnFwdArgs& a, hipStream_t s) {
   if (int r = ln_fwd_check(a)) return r;
   if (a.M <= 0) return 0;
   const LnFwdP p = ln_fwd_problem(a);
-  DISPATCH_NCH(a.H, crct_launch((ln_fwd_kernel<NCH>), dim3(row_grid(a.M, 2048)), dim3(256), 0, s, p));
+  DISPATCH_NCH(a.H, crct_launch((ln_fwd_kernel<NCH>), dim3(row_grid(a.M, 2048)), dim3(256), 0, s, LN_FWD_HOT(p) p));
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1129,9 +1144,9 @@ static int ln_bwd_launch(const CrctLnBwdArgs& a, hipStream_t s) {
   const int nb = crct_layernorm_bwd_blocks(a.M);
   const LnBwdP p = ln_bwd_problem(a);
   if (ln_bwd_combines(a.H)) {
-    DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, p));
+    DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, LN_BWD_HOT(p) p));
   } else {
-    DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, p));
+    DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, LN_BWD_HOT(p) p));
   }
   CRCT_CHECK_HIP(hipGetLastError());
   return 0;
