@@ -564,6 +564,7 @@ hipError_t launch_sp(const AttnArgs& a, hipStream_t s) {
     raised = true;
   }
   const int total = a.B * a.heads;
+  if (a.ldq > 0x7fffffffL || a.ldk > 0x7fffffffL || a.ldv > 0x7fffffffL) return hipErrorInvalidValue;      // preloaded as 32-bit scalars (ATTN_HOT_ARGS)
   crct_launch(kern, dim3((total + W - 1) / W), dim3(64 * W * SP), BYTES * W, s, ATTN_HOT_ARGS(a) a);
   return hipGetLastError();
 }

@@ -2317,6 +2317,8 @@ extern "C" int crct_gemm_lnf_ok(const CrctGemmArgs* a) {
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
+  // the leading dimensions of the operands travel to the kernel as preloaded 32-bit scalars (GEMM_HOT_ARGS)
+  if (g_in.lda < 0 || g_in.ldb < 0 || g_in.lda > 0x7fffffffLL || g_in.ldb > 0x7fffffffLL) return hipErrorInvalidValue;
   CrctGemmArgs g = g_in;
   const bool is_f8 = (g.fp8 & 1) != 0;                         // bit 0: fp8 operands; bits 1 / 2 qualify the A operand / the q_out copy
   if (is_f8 && g.ta) {                                         // fp8 weight gradient (token-major operands): ids 36 (3 stages) / 37 (2 stages)

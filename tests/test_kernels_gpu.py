@@ -874,6 +874,23 @@ def test_folded_layernorm_requests_are_refused_where_no_kernel_has_them(gemm_pat
         ops.gemm(s_sum, w, M, N, H, bias=z, out_f32=True, ln_stats_out=stats)
 
 
+def test_gemm_refuses_a_leading_dimension_beyond_32_bits():
+    """The operands' leading dimensions reach the kernel as preloaded 32-bit scalars (gemm.hip GEMM_HOT_ARGS): a larger one is an error, not
+    a truncation."""
+    M, N, K = 64, 64, 64
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = torch.randn(N, K, device="cuda").bfloat16()
+    g = L.GemmArgs()
+    ops._gemm_args(g, a, w, M, N, K)
+    g.lda = 1 << 31
+    assert L.load().crct_gemm_bf16(C.byref(g), L.current_stream()) != 0
+    g.lda, g.ldb = K, 1 << 33
+    assert L.load().crct_gemm_bf16(C.byref(g), L.current_stream()) != 0
+    g.ldb = K
+    assert L.load().crct_gemm_bf16(C.byref(g), L.current_stream()) == 0
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ GELU / GELU' epilogues (round 5)
 def _gelu_points():
     """2^20 pre-activations, bf16-representable: a dense grid over [-9, 9] (beyond +-4 the Abramowitz-Stegun erf is in its tail), a
