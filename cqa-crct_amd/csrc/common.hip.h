@@ -160,3 +160,8 @@ __device__ __forceinline__ void amax_update(float* dst, float v) {
   float* w = dst + (blockIdx.x & (CRCT_FP8_AMAX_LANES - 1));
   if (v > __builtin_nontemporal_load(w)) atomicMax(reinterpret_cast<int*>(w), __float_as_int(v));
 }
+
+// Kernels of the two data streams' dependent chains raise their waves' issue priority (s_setprio 3): on a SIMD they share with waves of the
+// work that is off the path by dependency -- the grouped weight gradients, AdamW, the column-sum passes, all at the default 0 -- they issue
+// first.  Round 5: 7.29 - 7.34 -> 7.24 - 7.26 ms per step for the GEMMs alone (profiles/r5_setprio_ab.txt).  Results are unaffected.
+__device__ __forceinline__ void crct_chain_priority() { __builtin_amdgcn_s_setprio(3); }

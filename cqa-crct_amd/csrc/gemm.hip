@@ -1026,6 +1026,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int PM = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GEMM_HOT_PARAMS) {
   GEMM_HOT_UNPACK
+  if constexpr (!TA) crct_chain_priority();      // forward / data-gradient GEMMs: the data streams (weight gradients stay at 0)
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tile_m, tile_n, tmap.dbg);
@@ -1034,6 +1035,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GEMM_HOT_PARAMS
 template <int TM, int TN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_lnf_kernel(GEMM_HOT_PARAMS) {
   GEMM_HOT_UNPACK
+  crct_chain_priority();
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   gemm_pipe_body<TM, TN, WM, WN, false, false, NS, false, 0, true>(g, tile_m, tile_n, 0, 0, 0, tmap.tiles_n);
@@ -1044,6 +1046,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_lnf_kernel(GEMM_HOT_PARAMS)
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_splitk_kernel(GEMM_HOT_PARAMS) {
   GEMM_HOT_UNPACK
+  crct_chain_priority();
   const int S = g.split_k;
   const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
   int tile_m, tile_n;
@@ -1323,6 +1326,7 @@ __device__ __forceinline__ void gemm_ldr_body(const CrctGemmArgs& g, const int t
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int NL, int PIPE = 0>
 __global__ __launch_bounds__((WM * WN + NL) * 64) void gemm_ldr_kernel(GEMM_HOT_PARAMS) {
   GEMM_HOT_UNPACK
+  if constexpr (!TA) crct_chain_priority();
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   gemm_ldr_body<TM, TN, WM, WN, TA, TB, NS, NL, PIPE>(g, tile_m, tile_n, tmap.dbg);
@@ -1361,6 +1365,7 @@ constexpr int MX_ONE = 0x7F7F7F7F;       // four e8m0 block scales of 2^0
 template <int TM, int TN, int WM, int WN, int NS, bool A_BF8 = false, bool MX = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f8_kernel(GEMM_HOT_PARAMS) {
   GEMM_HOT_UNPACK
+  crct_chain_priority();
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
