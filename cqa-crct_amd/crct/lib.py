@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrct_hip.so")
 
 c_i32, c_i64, c_u32, c_u64, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+ATTN_MAX_LEN = 256           # CRCT_ATTN_MAX_LEN of include/crct_hip.h: longest query / key sequence of the attention kernels
 FP8_AMAX_LANES = 64          # CRCT_FP8_AMAX_LANES of include/crct_hip.h: fp32 words per amax value
 vp = C.c_void_p
 
@@ -164,6 +165,7 @@ PROTOTYPES = {
     "crct_attention_bwd_q": (C.c_int, [vp] * 8 + [C.c_int] * 5 + [c_i64] * 7 + _u8 + [vp, vp]),
     "crct_attention_quant_ok": (C.c_int, [C.c_int] * 3),
     "crct_attention_force_valu": (None, [C.c_int]),
+    "crct_attention_force_long": (None, [C.c_int]),
     "crct_attention_force_split": (None, [C.c_int]),
     "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),
     "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp, vp, C.c_int, vp]),

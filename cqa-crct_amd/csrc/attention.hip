@@ -1,5 +1,6 @@
-// Scaled-dot-product attention for the short CRCT sequences (<= 112 visual elements, <= 112 text
-// tokens, head size 32 / 48 / 64): one 256-thread workgroup per (batch, head); q, k, v, the score
+// Scaled-dot-product attention: the entry points of all three implementations (see pick_path below) and the fp32 VALU kernels
+// for the short CRCT sequences (<= 112 visual elements, <= 112 text tokens, any head size that is a multiple of 8 up to 64):
+// one 256-thread workgroup per (batch, head); q, k, v, the score
 // matrix and the probabilities live in LDS in fp32, all arithmetic is fp32 VALU (the score / PV
 // products are < 1 % of the step's FLOPs -- SURVEY.md 8a -- so they do not go to MFMA).
 //   P = softmax(q k^T / sqrt(d) + (1 - keymask) * -10000) ; ctx = dropout(P) v
@@ -387,20 +388,35 @@ hipError_t dispatch(const AttnArgs& a, size_t lds, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+// Three implementations behind one pair of entry points:
+//   attention_mfma.hip  register-resident MFMA kernels: Tq, Tk <= 112, d in {32, 48, 64}            (the default where it applies)
+//   attention_long.hip  key-tile loop, online softmax:  Tq, Tk <= CRCT_ATTN_MAX_LEN, d in {32, 48, 64} (beyond 112; everywhere it
+//                       applies after crct_attention_force_long(1))
+//   this file           fp32 VALU, everything in LDS:   Tq, Tk <= 112, any d % 8 == 0 up to 64        (other head sizes; everything
+//                       it can take after crct_attention_force_valu(1))
+int g_force_valu = 0, g_force_long = 0;
+enum { PATH_NONE = 0, PATH_MFMA, PATH_LONG, PATH_VALU };
+int pick_path(int Tq, int Tk, int d) {
+  const bool valu_ok = Tq <= 112 && Tk <= 112;
+  if (g_force_valu && valu_ok) return PATH_VALU;
+  if (g_force_long && crct_attention_long_ok(Tq, Tk, d)) return PATH_LONG;
+  if (crct_attention_mfma_ok(Tq, Tk, d)) return PATH_MFMA;
+  if (crct_attention_long_ok(Tq, Tk, d)) return PATH_LONG;
+  return valu_ok ? PATH_VALU : PATH_NONE;
+}
 int check_args(int Tq, int Tk, int d) {
-  CRCT_REQUIRE(Tq >= 1 && Tk >= 1 && Tq <= 112 && Tk <= 112, "attention: Tq=%d Tk=%d must be in [1,112]", Tq, Tk);
+  CRCT_REQUIRE(Tq >= 1 && Tk >= 1 && Tq <= CRCT_ATTN_MAX_LEN && Tk <= CRCT_ATTN_MAX_LEN, "attention: Tq=%d Tk=%d must be in [1,%d]", Tq, Tk,
+               CRCT_ATTN_MAX_LEN);
   CRCT_REQUIRE(d % 8 == 0 && d >= 8 && d <= 64, "attention: head size %d must be a multiple of 8 in [8,64]", d);
+  CRCT_REQUIRE(pick_path(Tq, Tk, d) != PATH_NONE, "attention: Tq=%d Tk=%d beyond 112 needs a head size of 32, 48 or 64 (got %d)", Tq, Tk, d);
   return 0;
 }
-
-// MFMA path (attention_mfma.hip) for the lengths / head sizes it covers; crct_attention_force_valu(1) (test hook) keeps
-// everything on the fp32 kernels of this file
-int g_force_valu = 0;
-bool use_mfma(int Tq, int Tk, int d) { return !g_force_valu && crct_attention_mfma_ok(Tq, Tk, d); }
+bool use_mfma(int Tq, int Tk, int d) { const int p = pick_path(Tq, Tk, d); return p == PATH_MFMA || p == PATH_LONG; }
 
 }  // namespace
 
 extern "C" void crct_attention_force_valu(int on) { g_force_valu = on ? 1 : 0; }
+extern "C" void crct_attention_force_long(int on) { g_force_long = on ? 1 : 0; }
 
 extern "C" int crct_attention_quant_ok(int Tq, int Tk, int d) { return use_mfma(Tq, Tk, d) ? 1 : 0; }
 
@@ -425,8 +441,13 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
   static const int dbg = getenv("CRCT_ATTN_DBG") ? atoi(getenv("CRCT_ATTN_DBG")) : 0;
   a.dbg = dbg;
 #endif
-  if (use_mfma(Tq, Tk, d)) {
+  const int path = pick_path(Tq, Tk, d);
+  if (path == PATH_MFMA) {
     CRCT_CHECK_HIP(crct_attention_mfma_fwd(a, (hipStream_t)stream));
+    return 0;
+  }
+  if (path == PATH_LONG) {
+    CRCT_CHECK_HIP(crct_attention_long_fwd(a, (hipStream_t)stream));
     return 0;
   }
   const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3;
@@ -469,8 +490,13 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
-  if (use_mfma(Tq, Tk, d)) {
+  const int path = pick_path(Tq, Tk, d);
+  if (path == PATH_MFMA) {
     CRCT_CHECK_HIP(crct_attention_mfma_bwd(a, (hipStream_t)stream));
+    return 0;
+  }
+  if (path == PATH_LONG) {
+    CRCT_CHECK_HIP(crct_attention_long_bwd(a, (hipStream_t)stream));
     return 0;
   }
   const int Tq4 = (Tq + 3) & ~3, Tk4 = (Tk + 3) & ~3, Tmax4 = Tq4 > Tk4 ? Tq4 : Tk4;

@@ -1,5 +1,6 @@
-// Arguments shared by the two attention implementations (attention.hip: fp32 VALU, any length up to 112;
-// attention_mfma.hip: one wave per (batch, head) on MFMA, lengths up to 112, head sizes 32 / 48 / 64).
+// Arguments shared by the three attention implementations (attention.hip: fp32 VALU, any length up to 112;
+// attention_mfma.hip: register-resident MFMA kernels, lengths up to 112, head sizes 32 / 48 / 64; attention_long.hip: key-tile loop
+// with online softmax, lengths up to CRCT_ATTN_MAX_LEN, head sizes 32 / 48 / 64).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,7 +15,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   uint32_t thr; float dscale; uint32_t site; uint64_t seed;
   float scale;
-  // fp8 copies of the results (MFMA kernels only; include/crct_hip.h CrctAttnQuant): ctx as e4m3, dq / dk / dv as e5m2, each with
+  // fp8 copies of the results (MFMA kernels of both files only; include/crct_hip.h CrctAttnQuant): ctx as e4m3, dq / dk / dv as e5m2, each with
   // the leading dimension of its bf16 twin (in bytes), quantised with *scale, max |.| into *amax (CRCT_FP8_AMAX_LANES words)
   uint8_t* ctx_q; const float* ctx_qscale; float* ctx_qamax;
   uint8_t* dq_q; uint8_t* dk_q; uint8_t* dv_q;
@@ -25,3 +26,6 @@ struct AttnArgs {
 bool crct_attention_mfma_ok(int Tq, int Tk, int d);
 hipError_t crct_attention_mfma_fwd(const AttnArgs& a, hipStream_t s);
 hipError_t crct_attention_mfma_bwd(const AttnArgs& a, hipStream_t s);
+bool crct_attention_long_ok(int Tq, int Tk, int d);
+hipError_t crct_attention_long_fwd(const AttnArgs& a, hipStream_t s);
+hipError_t crct_attention_long_bwd(const AttnArgs& a, hipStream_t s);

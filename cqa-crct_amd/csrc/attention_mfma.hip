@@ -22,6 +22,7 @@
 #include "common.hip.h"
 #include "crct_internal.h"
 #include "attention_args.h"
+#include "attention_tiles.hip.h"
 
 //
 // A workgroup holds W = 1, 2 or 4 independent (batch, head) pairs, each with its own slice of the dynamic LDS allocation
@@ -34,13 +35,6 @@ extern "C" void crct_attention_force_split(int n) { g_attn_force_split = (n == 1
 
 namespace {
 
-typedef s4_t __attribute__((address_space(3))) * lds_s4_ptr;
-
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // SP == 1: one wave owns a (batch, head) -- a wave-level fence separates its phases; SP > 1: the SP waves that share
 // the (batch, head)'s LDS images meet at a workgroup barrier (every wave of the workgroup takes the same path)
 template <int SP>
@@ -48,8 +42,6 @@ __device__ __forceinline__ void group_sync() {
   if constexpr (SP == 1) wave_sync();
   else __syncthreads();
 }
-
-__device__ __forceinline__ f4_t mma16(s4_t a, s4_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
 // rows [T][16*ND] bf16 (row stride ld) -> LDS image of 16*NT rows (rows >= T are zero), in two phases so that the global
 // loads of SEVERAL matrices are all in flight before the first one is waited for: fetch() issues every load of the
@@ -121,37 +113,6 @@ __device__ __forceinline__ void store_rows_q(bf16_t* dst, uint8_t* qdst, long ld
   am = fmaxf(am, __shfl_xor(am, 4, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64)); am = fmaxf(am, __shfl_xor(am, 1, 64));
   if (lane == 0) amax_update(amax_dst, am);
 }
-// fragment X[r0 + (lane & 15)][c0 + 4 (lane >> 4) + e]: contraction along the image's columns
-__device__ __forceinline__ s4_t frag_rows(const char* img, int stb, int r0, int c0, int lane) {
-  return *reinterpret_cast<const s4_t*>(img + (r0 + (lane & 15)) * stb + (c0 + 4 * (lane >> 4)) * 2);
-}
-// fragment X[k0 + 4 (lane >> 4) + e][c0 + (lane & 15)]: contraction along the image's rows (transposed read;
-// EXEC must be all ones, every lane supplies an in-bounds address)
-__device__ __forceinline__ s4_t frag_cols(const char* img, int stb, int k0, int c0, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const char* addr = img + (k0 + 4 * g + q) * stb + (c0 + 4 * p) * 2;
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(uint32_t)(uintptr_t)addr);
-}
-// result tile (rows 4g + r, col lane & 15) -> transposed into a row-major image: img[col][row0 + 4g .. + 3]
-__device__ __forceinline__ void put_tile_t(char* img, int stb, int row_of_col0, int col_of_row0, f4_t v, int lane) {
-  uint2 u;
-  u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
-  *reinterpret_cast<uint2*>(img + (row_of_col0 + (lane & 15)) * stb + (col_of_row0 + 4 * (lane >> 4)) * 2) = u;
-}
-__device__ __forceinline__ s4_t pack4(f4_t v) {
-  uint2 u;
-  u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
-  return __builtin_bit_cast(s4_t, u);
-}
-__device__ __forceinline__ float xmax2(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float xsum2(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-}
-
 // bit 4*jt + r of the result: key 16*jt + 4*g + r exists and is attended (keymask != 0); `valid`: it exists.
 // Lane l reads keymask[l] (and [l + 64] for more than 64 keys), two wave ballots give every lane all the keys.
 template <int NK>
@@ -215,15 +176,6 @@ __device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, uint
   }
 }
 
-// fragment X[r0 + (lane & 15)][c0 + 4 (lane >> 4) + e] straight from global memory (rows >= T read as zero)
-__device__ __forceinline__ s4_t frag_rows_global(const bf16_t* src, long ld, int T, int r0, int c0, int lane) {
-  const int r = r0 + (lane & 15);
-  // unconditional load (last row for the padding rows) and a mask: no branch, the loads stay batched
-  const uint2 u = *reinterpret_cast<const uint2*>(src + (long)min(r, T - 1) * ld + c0 + 4 * (lane >> 4));
-  const uint32_t m = r < T ? 0xffffffffu : 0u;
-  return __builtin_bit_cast(s4_t, make_uint2(u.x & m, u.y & m));
-}
-
 template <int NQ, int NK, int ND> struct FwdLds { static constexpr int STB = 32 * ND + 16, BYTES = 16 * (NQ + 2 * NK) * STB; };
 template <int NQ, int NK, int ND> struct BwdLds {
   static constexpr int STB = 32 * ND + 16, PSB = 32 * NK + 16, NX = NQ > NK ? NQ : NK;
@@ -232,11 +184,6 @@ template <int NQ, int NK, int ND> struct BwdLds {
 
 // W independent (batch, head) pairs per workgroup, SP cooperating waves per pair (query tiles it = part, part + SP, ...):
 // the arithmetic per tile is the same for every SP, so are the results bit for bit.
-// Kernel-argument preload (gemm.hip, GEMM_HOT_PARAMS): what the first instructions need (operand pointers, sizes, leading dimensions) as 15
-// leading scalar arguments -- gfx950 hands the first argument dwords to the wave in SGPRs; a struct passed by value is fetched by scalar loads.
-#define ATTN_HOT_PARAMS const bf16_t* hq, const bf16_t* hk, const bf16_t* hv, const uint8_t* hkm, int hB, int hheads, int hTq, int hTk, int hldq, int hldk, int hldv, const AttnArgs a_in
-#define ATTN_HOT_UNPACK AttnArgs a = a_in; a.q = hq; a.k = hk; a.v = hv; a.keymask = hkm; a.B = hB; a.heads = hheads; a.Tq = hTq; a.Tk = hTk; a.ldq = hldq; a.ldk = hldk; a.ldv = hldv;
-#define ATTN_HOT_ARGS(a) (a).q, (a).k, (a).v, (a).keymask, (a).B, (a).heads, (a).Tq, (a).Tk, (int)(a).ldq, (int)(a).ldk, (int)(a).ldv,
 template <int NQ, int NK, int ND, int W, int SP>
 __global__ __launch_bounds__(64 * W * SP) void attn_fwd_mfma(ATTN_HOT_PARAMS) {
   ATTN_HOT_UNPACK

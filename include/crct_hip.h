@@ -337,21 +337,28 @@ int crct_cast_runs_bf16_f32(const void* x, float* y, const int64_t* off, const i
                             int64_t n_blk, crct_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Scaled-dot-product attention over short sequences, one workgroup per (batch, head), everything
- * in LDS: P = softmax(q k^T / sqrt(d) + (1-keymask)*-10000), dropout(P), ctx = P v.
+ * Scaled-dot-product attention, one workgroup per (batch, head), operands in LDS:
+ * P = softmax(q k^T / sqrt(d) + (1-keymask)*-10000), dropout(P), ctx = P v.
  * Replaces vilbert.py:392-412 (text self), :522-543 (visual self), :684-701 / :704-723 (co-attn).
  * q [B][Tq][ldq], k/v [B][Tk][ldk] bf16 with head h at column h*d; keymask fp32/int-free: uint8 [B][Tk]
- * (1 = attend); ctx bf16 [B][Tq][ldo].  Tq, Tk <= 112, d <= 64, d % 8 == 0.
+ * (1 = attend); ctx bf16 [B][Tq][ldo].
+ * Lengths: Tq, Tk <= CRCT_ATTN_MAX_LEN (256: CRCT/options.py:27's default max_seq_len; config/plotqa.json:5-6 trains at 124 text
+ * tokens x 44 visual elements) for head sizes 32 / 48 / 64 -- the three of config/vilbert.json; any other head size (d <= 64,
+ * d % 8 == 0) only up to 112 x 112.  Anything else is refused with an error, never truncated.
  */
+#define CRCT_ATTN_MAX_LEN 256
 int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx,
                        int B, int heads, int Tq, int Tk, int d,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                        uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                        crct_stream_t stream);
-/* Two implementations share these entry points: Tq, Tk <= 112 with d in {32, 48, 64} run one wave per
- * (batch, head) on MFMA (attention_mfma.hip); everything else (and everything after
- * crct_attention_force_valu(1)) the fp32 VALU kernels.  Same dropout stream in both. */
+/* Three implementations share these entry points: Tq, Tk <= 112 with d in {32, 48, 64} run register-resident MFMA kernels
+ * (attention_mfma.hip); longer sequences with those head sizes a key-tile loop with online softmax on MFMA (attention_long.hip);
+ * other head sizes up to 112 x 112 (and everything up to 112 x 112 after crct_attention_force_valu(1)) the fp32 VALU kernels.
+ * Same dropout stream in all three. */
 void crct_attention_force_valu(int on);
+/* Test hook: on != 0 sends every shape the long-sequence kernels can take (d in {32, 48, 64}) through them, short ones included. */
+void crct_attention_force_long(int on);
 /* Test hook of the MFMA kernels: n = 1 / 2 / 4 waves per (batch, head) where the tile counts allow it, 0 = automatic.  Every
  * count computes the same bits (tests/test_kernels_gpu.py). */
 void crct_attention_force_split(int n);

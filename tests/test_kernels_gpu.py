@@ -297,13 +297,16 @@ def _attn_ref(q, k, v, km, heads, d):
     return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, heads * d)
 
 
-@pytest.fixture(params=["mfma", "valu"])
+@pytest.fixture(params=["mfma", "valu", "long"])
 def attn_path(request):
-    """Lengths <= 64 with head size 32 / 48 / 64 run on the MFMA kernels by default; 'valu' forces the fp32 kernels."""
+    """Lengths <= 112 with head size 32 / 48 / 64 run on the register-resident MFMA kernels by default; 'valu' forces the fp32
+    kernels, 'long' the key-tile-loop kernels of attention_long.hip (the path of everything beyond 112) wherever they apply."""
     lib = L.load()
     lib.crct_attention_force_valu(int(request.param == "valu"))
+    lib.crct_attention_force_long(int(request.param == "long"))
     yield request.param
     lib.crct_attention_force_valu(0)
+    lib.crct_attention_force_long(0)
 
 
 @pytest.mark.parametrize("B,heads,Tq,Tk,d", [(80, 16, 20, 20, 48), (80, 16, 36, 36, 64), (80, 32, 20, 36, 32), (80, 32, 36, 20, 32),
@@ -331,7 +334,84 @@ def test_attention_fwd_bwd(B, heads, Tq, Tk, d, attn_path):
     assert rel_err(dv, vr.grad) < 1.5e-2
 
 
-def test_attention_identity_asymmetric():
+# Beyond 112 queries / keys: attention_long.hip.  (124, 44) is the reference's own PlotQA shape (config/plotqa.json:5-6), 256 its
+# default max_seq_len (options.py:27) and this library's limit; ragged lengths around the 16-row tiles; padding keys in every batch row.
+LONG_SHAPES = [(4, 16, 124, 124, 48), (4, 32, 124, 44, 32), (4, 32, 44, 124, 32), (2, 16, 256, 256, 64), (2, 16, 130, 200, 48),
+               (3, 4, 113, 17, 32), (2, 4, 17, 113, 64), (2, 8, 256, 256, 32), (2, 4, 241, 129, 48), (1, 2, 1, 200, 64)]
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", LONG_SHAPES)
+def test_attention_long_sequences_fwd_bwd(B, heads, Tq, Tk, d):
+    Hh = heads * d
+    bufq = bf(rand(B, Tq, 3 * Hh, seed=1))
+    bufk = bf(rand(B, Tk, 3 * Hh, seed=2))
+    q, k, v = bufq[:, :, :Hh], bufk[:, :, Hh:2 * Hh], bufk[:, :, 2 * Hh:]
+    km = torch.ones(B, Tk, dtype=torch.uint8, device=DEV)
+    for b in range(B):
+        km[b, Tk - 1 - 5 * b:] = 0
+    ctx = ops.attention_fwd(q, k, v, km, heads, d)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, km, heads, d)
+    assert rel_err(ctx, ref) < 1e-2
+    dctx = bf(rand(B, Tq, Hh, seed=3))
+    ref.backward(dctx.float())
+    dq, dk, dv = ops.attention_bwd(q, k, v, km, dctx, heads, d)
+    assert rel_err(dq, qr.grad) < 1.5e-2
+    assert rel_err(dk, kr.grad) < 1.5e-2
+    assert rel_err(dv, vr.grad) < 1.5e-2
+
+
+def test_attention_long_and_short_kernels_agree_under_dropout():
+    """Same Philox element numbering in attention_mfma.hip and attention_long.hip: with p = 0.1 the two must give the same
+    context and gradients up to rounding (a different mask moves whole probabilities), at shapes both can take; and at a long
+    shape the mask the backward regenerates is the forward's (sum_j dv = sum_i ctx for v = dctx = 1), results reproducible."""
+    lib = L.load()
+    p = 0.1
+    for B, heads, Tq, Tk, d in ((8, 32, 20, 36, 32), (3, 16, 100, 100, 64), (4, 16, 64, 50, 48)):
+        Hh = heads * d
+        q, k, v = bf(rand(B, Tq, Hh, seed=1)), bf(rand(B, Tk, Hh, seed=2)), bf(rand(B, Tk, Hh, seed=3))
+        km = torch.ones(B, Tk, dtype=torch.uint8, device=DEV)
+        km[:, Tk - 2:] = 0
+        dctx = bf(rand(B, Tq, Hh, seed=4))
+        outs = []
+        try:
+            for long in (0, 1):
+                lib.crct_attention_force_long(long)
+                ctx = ops.attention_fwd(q, k, v, km, heads, d, p_drop=p, site=9, seed=4242)
+                outs.append((ctx,) + tuple(ops.attention_bwd(q, k, v, km, dctx, heads, d, p_drop=p, site=9, seed=4242)))
+        finally:
+            lib.crct_attention_force_long(0)
+        for a, b in zip(*outs):
+            assert rel_err(a, b) < 1.5e-2
+    B, heads, T, d = 4, 16, 124, 48
+    Hh = heads * d
+    q, k = bf(rand(B, T, Hh, seed=1)), bf(rand(B, T, Hh, seed=2))
+    ones = bf(torch.ones(B, T, Hh, device=DEV))
+    km = torch.ones(B, T, dtype=torch.uint8, device=DEV)
+    ctx = ops.attention_fwd(q, k, ones, km, heads, d, p_drop=p, site=5, seed=99)
+    assert abs(float(ctx.float().mean()) - 1.0) < 0.01 and float(ctx.float().std()) > 0.01
+    assert torch.equal(ctx, ops.attention_fwd(q, k, ones, km, heads, d, p_drop=p, site=5, seed=99))
+    g1 = ops.attention_bwd(q, k, ones, km, ones, heads, d, p_drop=p, site=5, seed=99)
+    g2 = ops.attention_bwd(q, k, ones, km, ones, heads, d, p_drop=p, site=5, seed=99)
+    assert all(torch.equal(x, y) for x, y in zip(g1, g2))
+    assert rel_err(g1[2].float().sum(1), ctx.float().sum(1)) < 1e-2
+
+
+def test_attention_length_and_head_size_limits_are_errors():
+    lib = L.load()
+    assert L.ATTN_MAX_LEN == 256
+    for Tq, Tk, d in ((257, 20, 64), (20, 257, 32), (120, 120, 40), (113, 20, 16)):
+        q = bf(rand(1, Tq, 2 * d, seed=1))
+        k = bf(rand(1, Tk, 2 * d, seed=2))
+        km = torch.ones(1, Tk, dtype=torch.uint8, device=DEV)
+        with pytest.raises(RuntimeError, match="attention"):
+            ops.attention_fwd(q, k, k, km, 2, d)
+        with pytest.raises(RuntimeError, match="attention"):
+            ops.attention_bwd(q, k, k, km, q, 2, d)
+    assert lib.crct_attention_quant_ok(124, 124, 48) == 1 and lib.crct_attention_quant_ok(124, 124, 40) == 0
+
+
+def test_attention_identity_asymmetric(attn_path):
     # v = one-hot columns, one key unmasked per query block: ctx must reproduce v's rows exactly -> catches a transposed
     # or permuted operand in the MFMA path (cdna_hip_programming.md section 3)
     B, heads, T, d = 2, 4, 36, 64
@@ -719,7 +799,10 @@ def test_attention_fp8_copies_of_context_and_gradients():
     try:
         for split in (1, 2, 0):
             lib.crct_attention_force_split(split)
-            for B, h, Tq, Tk, d in ((3, 16, 100, 100, 64), (3, 32, 40, 100, 32), (5, 12, 20, 20, 64), (5, 16, 36, 36, 64), (4, 32, 20, 36, 32)):
+            for B, h, Tq, Tk, d in ((3, 16, 100, 100, 64), (3, 32, 40, 100, 32), (5, 12, 20, 20, 64), (5, 16, 36, 36, 64), (4, 32, 20, 36, 32),
+                                    (2, 16, 124, 124, 48), (2, 32, 44, 124, 32), (2, 32, 124, 44, 32)):      # the last three: attention_long.hip
+                if split and max(Tq, Tk) > 112:
+                    continue
                 g = torch.Generator().manual_seed(Tq * 1000 + Tk + d)
                 q, k, v = (torch.randn(B, T, h * d, generator=g).cuda().bfloat16() for T in (Tq, Tk, Tk))
                 do = (torch.randn(B, Tq, h * d, generator=g) * 1e-3).cuda().bfloat16()
