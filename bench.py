@@ -50,7 +50,12 @@ from crct import lib as L                 # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 PEAK_FP8_SCALED_TFLOPS = 5000.0           # ... ~5 PF dense fp8 through the block-scaled MFMA the fp8 GEMMs issue (the plain fp8 MFMA runs at the bf16 rate)
-FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9}   # SURVEY.md 8d, fwd+bwd
+FLOP_PER_QA = {(36, 20, 2048): 32.9e9, (100, 40, 2048): 79.8e9, (44, 124, 1024): 121.2e9}   # SURVEY.md 8a / 8d, fwd+bwd
+# Named workloads (batch, visual elements, text tokens, feature width).  "baseline" = BASELINE.json configs[1], the default and the
+# driver's line; "long-context" = configs[3]; "plotqa-real" = the shape the reference's own PlotQA configuration trains at
+# (CRCT/config/plotqa.json:5-6 max_vis_features 44 / max_seq_len 124, every sample padded to it by CRCT/utils.py:152-160;
+# config/vilbert.json v_feature_size 1024): an EXTRA line, M_t = 9 920 text rows per GEMM, 121.2 GFLOP per QA pair.
+WORKLOADS = {"baseline": (80, 36, 20, 2048), "long-context": (64, 100, 40, 2048), "plotqa-real": (80, 44, 124, 1024)}
 VARIANT_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "dma64x64w4s4", 4: "dma128x128w8s3",
               5: "dma128x256w8s3", 6: "dma256x128w8s3", 7: "dma256x128w8s2", 8: "dma128x128w8s4", 9: "dma128x128w8s2",
@@ -72,6 +77,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="a named shape (sets --batch / --vis / --tokens / --feat): %s"
+                    % ", ".join("%s = B %d, V %d, T %d, F_v %d" % ((k,) + v) for k, v in sorted(WORKLOADS.items())))
     ap.add_argument("--batch", type=int, default=80)
     ap.add_argument("--vis", type=int, default=36)
     ap.add_argument("--tokens", type=int, default=20)
@@ -146,7 +153,10 @@ def parse():
     ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
                     help="bf16: the headline (BASELINE configs[1]).  fp8: BASELINE configs[4] -- the QKV / FFN GEMMs of the forward pass on "
                          "OCP e4m3 operands with per-tensor delayed scaling and fp32 accumulation, backward and everything else bf16")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload:
+        a.batch, a.vis, a.tokens, a.feat = WORKLOADS[a.workload]
+    return a
 
 
 def stage(batch, dev):

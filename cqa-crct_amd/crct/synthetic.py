@@ -18,8 +18,11 @@ CAPTION_SEGMENTS = (4, 7, 8, 9, 10, 11)
 
 
 def make_batch(B, T, V, F_v, categories=228, vocab_size=30522, seed=1234, ragged=True,
-               needs_reg_p=0.5, n_types=12):
-    """One CPU batch dict. ``ragged`` gives up to 4 padded text keys / 6 padded visual keys."""
+               needs_reg_p=0.5, n_types=12, lengths=None, n_vis=None):
+    """One CPU batch dict. ``ragged`` gives up to 4 padded text keys / 6 padded visual keys; ``lengths`` / ``n_vis`` (one
+    int per row) fix the number of real tokens / visual elements instead -- the reference pads every PlotQA sample to
+    max_seq_len = 124 tokens and max_vis_features = 44 elements (CRCT/utils.py:152-160, fig_dataloader.py:365-390), so real
+    batches carry long runs of padding."""
     g = torch.Generator().manual_seed(int(seed))
 
     def randint(lo, hi, shape):
@@ -30,7 +33,11 @@ def make_batch(B, T, V, F_v, categories=228, vocab_size=30522, seed=1234, ragged
     segments = torch.zeros(B, T, dtype=torch.int64)
     loc = torch.zeros(B, T, 4, dtype=torch.float32)
     sep_indices = torch.zeros(B, 50, dtype=torch.int64)
-    lengths = randint(max(T - 4, 4), T + 1, (B,)) if ragged else torch.full((B,), T, dtype=torch.int64)
+    if lengths is not None:
+        lengths = torch.tensor([int(v) for v in lengths], dtype=torch.int64)
+        assert lengths.shape == (B,) and int(lengths.min()) >= 4 and int(lengths.max()) <= T
+    else:
+        lengths = randint(max(T - 4, 4), T + 1, (B,)) if ragged else torch.full((B,), T, dtype=torch.int64)
     cap_choices = torch.tensor([s for s in CAPTION_SEGMENTS if s < n_types] or [2], dtype=torch.int64)
     for b in range(B):
         L = int(lengths[b])
@@ -61,7 +68,11 @@ def make_batch(B, T, V, F_v, categories=228, vocab_size=30522, seed=1234, ragged
     image_loc[:, 0] = 0
     image_target = randint(min(8, categories - 1), categories, (B, V))
     image_target[:, 0] = categories
-    n_vis = randint(max(V - 6, 2), V + 1, (B,)) if ragged else torch.full((B,), V, dtype=torch.int64)
+    if n_vis is not None:
+        n_vis = torch.tensor([int(v) for v in n_vis], dtype=torch.int64)
+        assert n_vis.shape == (B,) and int(n_vis.min()) >= 1 and int(n_vis.max()) <= V
+    else:
+        n_vis = randint(max(V - 6, 2), V + 1, (B,)) if ragged else torch.full((B,), V, dtype=torch.int64)
     image_mask = (torch.arange(V)[None, :] < n_vis[:, None]).to(torch.int64)
     image_label = torch.full((B, V), -1, dtype=torch.int64)
 

@@ -8,6 +8,7 @@ it with name-keyed seeded weights, feeds seeded synthetic batches through the re
 .npz files next to this script.  Reference source never enters the repo; only these vectors do.
 
     python tests/golden/make_golden.py            # regenerates every fixture
+    python tests/golden/make_golden.py long       # only the long-sequence fixtures (T = 124 / 130)
 """
 import json
 import os
@@ -50,7 +51,7 @@ def build_reference_model(vilbert, encoder_decorator, cfg, params):
     return model
 
 
-def run_case(name, cfg, params, batch, vilbert, ed, save_weights, evaluation=False, grad_sample=None):
+def run_case(name, cfg, params, batch, vilbert, ed, save_weights, evaluation=False, grad_sample=None, yardstick=False):
     params = dict(params)
     params["device"] = torch.device("cpu")
     model = build_reference_model(vilbert, ed, cfg, params)
@@ -125,6 +126,21 @@ def run_case(name, cfg, params, batch, vilbert, ed, save_weights, evaluation=Fal
                 idx = (torch.arange(n, dtype=torch.int64) * (flat.numel() - 1)) // max(n - 1, 1)
                 rec["gradidx." + k] = idx.numpy()
                 rec["gradsample." + k] = flat[idx].numpy()
+    if yardstick and not evaluation:
+        # what bf16 itself costs on this draw: the oracle under torch's CPU bf16 autocast (the reference's mixed-precision mode,
+        # train.py:172) against its fp32 self -- per tensor the ratio of the gradient norms (tests add |ratio - 1| to their norm bound)
+        sd16 = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            o16 = O.oracle_step(sd16, cfg, params, batch, training=True, cls_dropout=0.0)
+        o16[0].float().backward()
+        dev = []
+        for k, p in sd.items():
+            if p.grad is None or sd16[k].grad is None or float(p.grad.norm()) < 1e-7:
+                continue
+            r = float(sd16[k].grad.double().norm() / p.grad.double().norm())
+            rec["yardratio." + k] = np.array(r)
+            dev.append(abs(r - 1))
+        print("  [%s] bf16-autocast yardstick: gradient norm off by up to %.1f %% (median %.2f %%)" % (name, 100 * max(dev), 100 * sorted(dev)[len(dev) // 2]))
     if save_weights:
         for k, p in sd.items():
             rec["w." + k] = p.detach().numpy()
@@ -390,6 +406,41 @@ def eval_scoring_case(vilbert, ed):
     print("  wrote %s (%.1f KB); total_correct =\n%s" % (path, os.path.getsize(path) / 1024, total.numpy()))
 
 
+def small_long_config():
+    """A small model with the head sizes the long-sequence attention kernels take
+    (32 / 48 / 32) and a position table that covers 130 tokens."""
+    return C.tiny_config(hidden_size=128, num_attention_heads=4, intermediate_size=256, max_position_embeddings=160,
+                         v_hidden_size=192, v_num_attention_heads=4, v_intermediate_size=192, bi_hidden_size=128,
+                         bi_num_attention_heads=4)
+
+
+def long_sequence_cases(vilbert, ed):
+    """Sequences beyond 112 tokens: the reference's own PlotQA shape (config/plotqa.json:5-6 max_vis_features 44, max_seq_len 124;
+    v_feature_size 1024 of config/vilbert.json) at full depth with the padding real samples carry (utils.py:152-160), and a
+    small model at T = 130 / V = 9 with padding in both streams (name-keyed seeded weights; outputs, activations at the heads,
+    gradient norms and samples of every tensor committed -- the oracle, asserted here to match the reference's full gradients
+    to 1e-3 of each tensor's maximum, supplies full tensors at test time)."""
+    cfg = C.vilbert_config(v_feature_size=1024, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                           v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
+    # seed 1238: a signal-rich draw (coherence of the per-row gradient sum at the CLS rows 0.44; the oracle under bf16 autocast keeps
+    # min / median cosine 0.988 / 0.993 against its fp32 self).  Seed 1234 at this shape is a cancelling draw with 2 + 2 labels on 4 rows:
+    # a 0.003 error of a logit (tolerance 0.03) moves the visual pooler's gradient norm by 20 % (profiles/r6_long_attn_parity.txt) --
+    # a fixture with sample cosines and 5 % norm bounds needs a draw whose gradients are not the residue of a cancellation.
+    batch = S.make_batch(4, 124, 44, 1024, seed=1238, lengths=[124, 71, 96, 110], n_vis=[44, 29, 37, 44])
+    batch["R"][:, 1] = torch.tensor([1.0, 1.0, 0.0, 1.0])      # three regression rows: the regressor's gradients are not one row's outer product
+    batch["needs_reg"] = (batch["R"][:, 1:2] == 1)
+    batch["image_feat"] = batch["image_feat"].half().float()
+    run_case("full_B4_V44_T124_F1024", cfg, C.default_params(), batch, vilbert, ed, save_weights=False, yardstick=True)
+    small = small_long_config()
+    b = S.make_batch(3, 130, 9, small.v_feature_size, categories=9, vocab_size=small.vocab_size, seed=21,
+                     lengths=[130, 97, 113], n_vis=[9, 4, 7])
+    b["R"][0, 1] = 1.0
+    b["R"][1, 1] = 0.0
+    b["R"][2, 1] = 1.0
+    b["needs_reg"] = (b["R"][:, 1:2] == 1)
+    run_case("small_B3_V9_T130", small, C.default_params(categories=9), b, vilbert, ed, save_weights=False, yardstick=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -428,6 +479,7 @@ def main():
         # keep the committed inputs small: features rounded to fp16-representable values
         batch["image_feat"] = batch["image_feat"].half().float()
         run_case(nm, cfg, params, batch, vilbert, ed, save_weights=False)
+    long_sequence_cases(vilbert, ed)
 
 
 if __name__ == "__main__":
@@ -436,5 +488,9 @@ if __name__ == "__main__":
         checkpoint_schema_case(*import_reference())
     elif len(sys.argv) > 1 and sys.argv[1] == "evalscore":      # regenerate only the evaluation-scoring fixture
         eval_scoring_case(*import_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "long":           # regenerate only the long-sequence fixtures (round 6)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        long_sequence_cases(*import_reference())
     else:
         main()
