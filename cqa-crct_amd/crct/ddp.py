@@ -136,13 +136,42 @@ class BucketExchange(object):
             self.launch(b)
 
 
-class FlatGradDDP(object):
-    """Attach to a ``VisualDialogEncoder`` / ``CrctModel``: ``FlatGradDDP(model)`` after
-    ``dist.init_process_group(backend='nccl', ...)`` (RCCL on ROCm)."""
+class FlatGradDDP(torch.nn.Module):
+    """``torch.nn.parallel.DistributedDataParallel``'s place in CRCT/train.py:138-143 and CRCT/evaluation.py:56-61, after
+    ``dist.init_process_group(backend='nccl', ...)`` (RCCL on ROCm)::
 
-    def __init__(self, model, process_group=None, bucket_mb=64, broadcast=True, grad_dtype=torch.bfloat16, materialize_grads=None):
+        crct_model = FlatGradDDP(crct_model, device_ids=[gpu], find_unused_parameters=True)
+
+    The result is an ``nn.Module`` WRAPPER with the surface those loops use: calling it calls the wrapped model (``forward(crct_model,
+    batch, params)`` of the step adapter, train.py:173), ``.module`` is the wrapped model (``crct_model.module.state_dict()``,
+    train.py:289), ``train()`` / ``eval()`` / ``to(device)`` / ``parameters()`` pass through as for any module, its own
+    ``state_dict()`` carries DistributedDataParallel's ``module.`` prefix, ``no_sync()`` skips the exchange of a micro-step.  It also
+    attaches itself to the model's flat-buffer core, so a loop that keeps calling the ORIGINAL model object gets the exchange too
+    (bench.py does).  ``device_ids`` / ``output_device`` must name the device the model is on; ``find_unused_parameters`` is accepted
+    and moot (the 36 never-used tensors sit outside the exchanged range by construction); other DistributedDataParallel keywords
+    (``broadcast_buffers``, ``gradient_as_bucket_view``, ``static_graph``, ``bucket_cap_mb`` = ``bucket_mb`` ...) are accepted."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True, process_group=None, bucket_cap_mb=None,
+                 find_unused_parameters=True, check_reduction=False, gradient_as_bucket_view=False, static_graph=False,
+                 bucket_mb=64, broadcast=True, grad_dtype=torch.bfloat16, materialize_grads=None):
+        super().__init__()
         from .optim import _crct_core
-        self.core = _crct_core(model)
+        self.module = module
+        # NOT a child module: the core already is one of `module` (state_dict / parameters() must list every tensor once)
+        self.__dict__["core"] = _crct_core(module)
+        if not hasattr(self.core, "flat_params"):
+            raise TypeError("FlatGradDDP wraps this package's VisualDialogEncoder / CrctModel (got %s)" % type(module).__name__)
+        dev = self.core.flat_params.device
+        for name, ids in (("device_ids", device_ids), ("output_device", None if output_device is None else [output_device])):
+            if ids is None:
+                continue
+            if len(ids) != 1:
+                raise ValueError("FlatGradDDP: one process per GPU (train.py:356-363): %s must name exactly one device, got %r" % (name, ids))
+            want = torch.device("cuda", ids[0]) if isinstance(ids[0], int) else torch.device(ids[0])
+            if dev.type == "cuda" and (want.type != "cuda" or (want.index if want.index is not None else torch.cuda.current_device()) != dev.index):
+                raise ValueError("FlatGradDDP: %s=%r but the model is on %s" % (name, ids, dev))
+        if bucket_cap_mb is not None:
+            bucket_mb = bucket_cap_mb
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
@@ -174,7 +203,12 @@ class FlatGradDDP(object):
         if broadcast:      # DDP constructor semantics: rank 0's parameters win (train.py:139)
             dist.broadcast(self.core.flat_params, 0, group=process_group)
             self.core._invalidate_shadow()
-        self.core._ddp = self
+        # plain attribute of the core, NOT a registered child: core -> wrapper -> module -> core would be a cycle in the module tree
+        object.__setattr__(self.core, "_ddp", self)
+
+    def forward(self, *args, **kwargs):
+        """The wrapped model's call (encoder_decorator.py:19-54 signature); the exchange itself hangs on the core's backward."""
+        return self.module(*args, **kwargs)
 
     @contextlib.contextmanager
     def no_sync(self):

@@ -676,16 +676,35 @@ class CrctModel(nn.Module):
 
 class VisualDialogEncoder(nn.Module):
     """encoder_decorator.py:9-54.  ``params['model_config']`` must exist (same assertion as :14).
-    The reference then downloads BERT-base; offline we keep the init_bert_weights initialisation
-    (exactly the state of the reference model right before its weight loading, vilbert.py:1205)."""
 
-    def __init__(self, params, config=None):
+    The reference builds its model with ``from_pretrained('bert-base-uncased', ...)`` (encoder_decorator.py:16), i.e. it STARTS FROM
+    BERT-base for the tensors that have a counterpart there (text embeddings, the twelve text layers, the LM head) and downloads the
+    archive when it is not cached.  Here the archive is a local path: ``pretrained=`` (or ``params['bert_pretrained']``) names a
+    directory holding ``pytorch_model.bin``, a ``.bin`` file or a ``.tar.gz`` archive -- or is a state dict -- and is loaded with the
+    reference's rules (crct/pretrained.py: gamma / beta rename, ``bert.`` prefix rule, name-and-shape matching, size mismatch =
+    RuntimeError).  Without it the model keeps the ``init_bert_weights`` initialisation -- exactly the state of the reference model
+    right before its weight loading (vilbert.py:1205) -- and says so once: that is a different starting point from the reference's."""
+
+    _warned_no_pretrained = False
+
+    def __init__(self, params, config=None, pretrained=None):
         super().__init__()
         if config is None:
             config_path = params["model_config"]
             assert os.path.exists(config_path), "model_config file not found"
             config = BertConfig.from_json_file(config_path)
         self.bert_pretrained = CrctModel(config, params=params)
+        if pretrained is None:
+            pretrained = params.get("bert_pretrained")
+        if pretrained is not None:
+            from .pretrained import load_pretrained
+            self.pretrained_missing, self.pretrained_unexpected = load_pretrained(self.bert_pretrained, pretrained)
+        elif not VisualDialogEncoder._warned_no_pretrained and not params.get("quiet_init", False):
+            VisualDialogEncoder._warned_no_pretrained = True
+            import warnings
+            warnings.warn("VisualDialogEncoder: no BERT-base checkpoint given (pretrained=<path> or params['bert_pretrained']); the model starts "
+                          "from init_bert_weights, whereas the reference starts its text stream from bert-base-uncased "
+                          "(encoder_decorator.py:16).  Loading a CRCT checkpoint afterwards (train.py:91-130) makes this moot.")
         self.bert_pretrained.train()
 
     def forward(self, input_ids, txt_loc, image_feat, image_loc, sep_indices=None, sep_len=None, token_type_ids=None,

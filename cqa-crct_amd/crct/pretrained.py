@@ -12,7 +12,7 @@ through ``_load_from_state_dict`` (:1243-1264), every tensor whose name AND shap
 
 There is no network here (and none on a training node should be needed): the archive is a LOCAL path.  What BERT-base supplies to the
 CRCT model (config/vilbert.json): the word and position embeddings and their LayerNorm, all twelve text layers
-(``bert.encoder.layer.N.*``: same names and shapes as BERT's), and the LM head (``cls.predictions.*``, tied decoder included) -- 203 of
+(``bert.encoder.layer.N.*``: same names and shapes as BERT's), and the LM head (``cls.predictions.*``, tied decoder included) -- 202 of
 the 561 state_dict entries; the visual stream, the connection layers, both poolers, the location / type embeddings and the regressor
 have no counterpart and keep ``init_bert_weights``.
 
