@@ -131,8 +131,6 @@ def parse():
                     "GEMMs do not write the bf16 communication buffer themselves)")
     ap.add_argument("--adamw-wide-first", type=int, default=-1, help="developer A/B: how many of the first overlapped AdamW launches run unthrottled")
     ap.add_argument("--adamw-groups", type=int, default=-1, help="developer A/B: the overlapped AdamW in this many launches (0 = one per backward segment)")
-    ap.add_argument("--ln-fold", action="store_true", help="developer A/B: the LayerNorm forward folded into the neighbouring GEMMs (params['ln_fold'] = "
-                    "True: 34 launches fewer per step; measured slower, EXPERIMENTS.md round 5) instead of a launch of its own")
     ap.add_argument("--fp8-bf16-wgrad", action="store_true", help="--dtype fp8 with bf16 weight gradients (fp8 forward and data gradients)")
     ap.add_argument("--fp8-plain-mfma", action="store_true", help="developer A/B (--dtype fp8): the round-3 fp8 GEMMs (four v_mfma_f32_16x16x32_fp8 per "
                     "128-deep K tile) instead of one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (crct_gemm_fp8_scaled_mfma)")
@@ -493,8 +491,6 @@ def main():
         cfg = CFG.vilbert_config(v_feature_size=a.feat, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
                                  v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
     params = CFG.default_params(device=dev, rank=rank, world_size=world, ddp=world > 1, batch_size=a.batch, seed=0, fp8=a.dtype == "fp8")
-    if a.ln_fold:
-        params["ln_fold"] = True
     if a.fp8_forward_only:
         params["fp8_backward"] = False
     if a.fp8_bf16_wgrad:
@@ -751,7 +747,7 @@ def main():
                                        "wgrad_target_workgroups": [a.wgrad_target_wgs, a.wgrad_target_rows] if a.wgrad_target_wgs >= 0 else "default (96, 3000)",
                                        "wgrad_concat": a.wgrad_concat if a.wgrad_concat >= 0 else 0, "optimizer_overlap": not a.no_opt_overlap, "optimizer_early": bool(a.opt_early),
                                        "adamw_workgroups": a.adamw_wgs if a.adamw_wgs >= 0 else "default (256)", "eager_zero_grad": bool(a.eager_zero_grad),
-                                       "fuse_zero_grad": bool(a.fuse_zero_grad), "exchange_skip": a.exchange_skip or None, "ln_fold": core.ln_fold},
+                                       "fuse_zero_grad": bool(a.fuse_zero_grad), "exchange_skip": a.exchange_skip or None},
                           "gemm_sites": sites, "gemm_variants": rows}}
         if h2d is not None:      # the PCIe-inclusive rate next to `value` (SURVEY.md 8d defines the step with its H2D copy; the bench contract's `value` is HBM-resident)
             out["value_h2d_inclusive"] = h2d["qa_pairs_per_s"]

@@ -95,9 +95,6 @@ class StepEngine(object):
         c.grad_scale = step.get("grad_scale", 1.0)
         c.wgrad_overwrite = int(bool(step.get("wgrad_overwrite", False)))
         c.grads_bf16 = L.ptr(step.get("grads_bf16")) if c.wgrad_overwrite else None
-        fold = step.get("ln_fold")      # (gamma-folded bf16 weight shadow, c vectors, b' vectors): the folded LayerNorm forward
-        if fold is not None:
-            c.params_fold, c.fold_c, c.fold_b = (L.ptr(t) for t in fold)
         c.seed = int(step["seed"])
         c.g_nsp_dev, c.g_reg_dev, c.g_loss_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg")), L.ptr(step.get("g_loss"))
         f8 = step.get("fp8")
@@ -152,19 +149,6 @@ class StepEngine(object):
         if n > 0:
             assert self.lib.crct_engine_fp8_weights(self.handle, off, num, n) == n
         return self.lib.crct_engine_fp8_sites(self.handle), list(zip(off[:n], num[:n]))
-
-    def fold_entries(self):
-        """The (consumer Linear, producer LayerNorm) pairs of the folded LayerNorm: dict of equal-length lists (flat offsets w, b, g,
-        be; dims n_in, n_out; compact offset c_off; backward segment seg) + the size of the compact c / b' buffers."""
-        total = c_i64 = C.c_int64(0)
-        n = self.lib.crct_engine_fold_entries(self.handle, None, None, None, None, None, None, None, None, 0, C.byref(total))
-        i64, i32 = (C.c_int64 * max(n, 1)), (C.c_int32 * max(n, 1))
-        w, b, g, be, c_off = i64(), i64(), i64(), i64(), i64()
-        n_in, n_out, seg = i32(), i32(), i32()
-        if n > 0:
-            assert self.lib.crct_engine_fold_entries(self.handle, w, b, g, be, n_in, n_out, c_off, seg, n, C.byref(total)) == n
-        return dict(w=list(w[:n]), b=list(b[:n]), g=list(g[:n]), be=list(be[:n]), n_in=list(n_in[:n]), n_out=list(n_out[:n]),
-                    c_off=list(c_off[:n]), seg=list(seg[:n])), int(total.value)
 
     def wgrad_owned(self):
         """(offsets, numels) of the weight gradients the engine overwrites under CrctStepCfg.wgrad_overwrite: fixed by the

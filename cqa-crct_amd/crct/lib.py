@@ -22,9 +22,7 @@ class GemmArgs(C.Structure):
                 ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
                 ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp),
                 ("fp8", c_i32), ("scale_a", vp), ("scale_b", vp), ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("ld_q", c_i64),
-                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp),
-                ("ln_stats_out", vp), ("ln_stats_ld", c_i32), ("lnf_stats", vp), ("lnf_tiles", c_i32), ("lnf_c", vp), ("lnf_gamma", vp),
-                ("lnf_beta", vp), ("lnf_y", vp), ("lnf_mean", vp), ("lnf_rstd", vp), ("lnf_eps", c_f32)]
+                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp)]
 
 
 class LaunchRec(C.Structure):
@@ -95,8 +93,7 @@ class StepCfg(C.Structure):
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
                 ("fp8_bwd", c_i32), ("fp8_wgrad", c_i32), ("params_fp8_t", vp), ("fp8_grad_scale", vp), ("fp8_grad_amax", vp),
-                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32), ("grads_bf16", vp),
-                ("params_fold", vp), ("fold_c", vp), ("fold_b", vp)]
+                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32), ("grads_bf16", vp)]
 
 
 SEG_ENQUEUED_FN = C.CFUNCTYPE(None, C.c_int, vp)      # void (*seg_enqueued)(int seg, void* user)
@@ -110,11 +107,6 @@ PROTOTYPES = {
     "crct_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "crct_gemm_bf16_grouped": (C.c_int, [C.POINTER(GemmArgs), C.c_int, vp]),
     "crct_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
-    "crct_gemm_tile_cols": (C.c_int, [C.POINTER(GemmArgs)]),
-    "crct_gemm_lnf_ok": (C.c_int, [C.POINTER(GemmArgs)]),
-    "crct_ln_fold_plan": (c_i64, [vp, C.c_int, vp, vp, c_i64]),
-    "crct_ln_fold_weights": (C.c_int, [vp] * 13 + [c_i64, C.c_int, vp]),
-    "crct_engine_fold_entries": (C.c_int, [vp] * 9 + [C.c_int, C.POINTER(c_i64)]),
     "crct_gemm_group_max_workgroups": (C.c_int, [C.c_int]),
     "crct_gemm_group_target_workgroups": (C.c_int, [C.c_int]),
     "crct_gemm_group_concat": (C.c_int, [C.c_int]),

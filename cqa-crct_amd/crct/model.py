@@ -135,11 +135,6 @@ class CrctModel(nn.Module):
         self._grad_waits = None
         self.record_segment_events = False           # set by FusedAdamW's early mode
         self._opt_stream = None
-        # launch-count lever of round 5: the LayerNorm forward folded into the neighbouring GEMMs (params['ln_fold']).
-        # ln_fold is OFF by default: built, parity-tested and measured in the step -- 615 instead of 649 launches and no gain (7.52 against
-        # 7.35 ms; 7.45 even with the fold kernels' 0.77 GB per step taken out): EXPERIMENTS.md round 5
-        self.ln_fold = bool(params.get("ln_fold", False)) if params else False
-        self._fold, self._fold_ver = None, None
         self.init_weights(int(params.get("seed", 0)))
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate_shadow())
 
@@ -204,59 +199,6 @@ class CrctModel(nn.Module):
             self._shadow_ver = v
             if self._fp8 is not None:
                 self._fp8_requantize()
-        if self.ln_fold and self._engine is not None and self._fold_ver != v:      # parameters changed behind the fused optimizer's back
-            self._fold_launch(None, L.current_stream())
-            self._fold_ver = v
-
-    # ------------------------------------------------------------------ folded LayerNorm forward (CrctStepCfg.params_fold)
-    def _fold_state(self):
-        """Device state of the folded LayerNorm: the gamma-folded bf16 weight shadow (element offsets of the flat buffers), the compact c / b'
-        vectors, the pair tables of ``crct_engine_fold_entries`` and the workgroup table of ``crct_ln_fold_weights`` with the block range of
-        every backward segment (the fused optimizer refolds a segment right behind its AdamW launch).  None when the model has no pair."""
-        if self._fold is None:
-            ents, total = self._engine.fold_entries()
-            n = len(ents["w"])
-            if n == 0:
-                self._fold = dict(n=0)
-                return None
-            dev = self._flat_p.device
-            lib = L.load()
-            out_host = torch.tensor(ents["n_out"], dtype=torch.int32)
-            n_blk = int(lib.crct_ln_fold_plan(out_host.data_ptr(), n, None, None, 0))
-            blk_entry, blk_row = torch.empty(n_blk, dtype=torch.int32), torch.empty(n_blk, dtype=torch.int32)
-            lib.crct_ln_fold_plan(out_host.data_ptr(), n, blk_entry.data_ptr(), blk_row.data_ptr(), n_blk)
-            first, seg_blocks = {}, {}
-            for i, e in enumerate(blk_entry.tolist()):
-                first.setdefault(e, i)
-            for e in range(n):
-                b0 = first[e]
-                b1 = first[e + 1] if e + 1 < n else n_blk
-                lo, hi = seg_blocks.get(ents["seg"][e], (b0, b1))
-                if b0 != hi and (lo, hi) != (b0, b1):
-                    raise RuntimeError("folded LayerNorm: the pairs of backward segment %d are not adjacent" % ents["seg"][e])
-                seg_blocks[ents["seg"][e]] = (min(lo, b0), max(hi, b1))
-            i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)      # noqa: E731
-            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
-            self._fold = dict(n=n, n_blk=n_blk, seg_blocks=seg_blocks, entries=ents,
-                              wfold=torch.zeros(self.total, dtype=torch.bfloat16, device=dev),
-                              c=torch.zeros(max(total, 1), device=dev), b=torch.zeros(max(total, 1), device=dev),
-                              w=i64(ents["w"]), bo=i64(ents["b"]), g=i64(ents["g"]), be=i64(ents["be"]), n_in=i32(ents["n_in"]),
-                              n_out=i32(ents["n_out"]), c_off=i64(ents["c_off"]), blk_entry=blk_entry.to(dev), blk_row=blk_row.to(dev))
-        return self._fold if self._fold["n"] else None
-
-    def _fold_launch(self, seg, stream, max_workgroups=0):
-        """(Re)fold the pairs of backward segment ``seg`` (None: all of them) from the CURRENT fp32 parameters, on ``stream``."""
-        st = self._fold_state()
-        if st is None:
-            return
-        b0, b1 = (0, st["n_blk"]) if seg is None else st["seg_blocks"].get(int(seg), (0, 0))
-        if b1 <= b0:
-            return
-        L.check(L.load().crct_ln_fold_weights(self._flat_p.data_ptr(), st["wfold"].data_ptr(), st["c"].data_ptr(), st["b"].data_ptr(),
-                                              st["w"].data_ptr(), st["bo"].data_ptr(), st["g"].data_ptr(), st["be"].data_ptr(),
-                                              st["n_in"].data_ptr(), st["n_out"].data_ptr(), st["c_off"].data_ptr(),
-                                              st["blk_entry"].data_ptr() + 4 * b0, st["blk_row"].data_ptr() + 4 * b0, b1 - b0,
-                                              int(max_workgroups), stream), "ln_fold_weights")
 
     # ------------------------------------------------------------------ fp8 forward state
     def _fp8_state(self, eng):
@@ -363,7 +305,6 @@ class CrctModel(nn.Module):
             # everything bound to the old device goes with the engine: fp8 shadow / scales / chunk tables, segment events, the
             # lazy-clear plan, constants (the fused optimizer drops its own device state when it sees the new buffers)
             self._fp8 = None
-            self._fold, self._fold_ver = None, None
             self._seg_done = None
             self._lazy_plan_key, self._lazy_plan = None, None
             self._const_zeros = None
@@ -398,10 +339,9 @@ class CrctModel(nn.Module):
     def flat_shadow(self):
         return self._flat_b16
 
-    def note_params_updated_natively(self, folded=False):
-        """Called by the fused optimizer, which rewrites the flat buffers and the shadow itself (``folded``: and the gamma-folded shadow)."""
+    def note_params_updated_natively(self):
+        """Called by the fused optimizer, which rewrites the flat buffers and the shadow itself."""
         self._shadow_ver = self._param_version()
-        self._fold_ver = self._shadow_ver if folded else None
 
     def zero_flat_grads(self, lazy=False):
         """Clear the gradients.  ``lazy``: only the gradients that backward ACCUMULATES into (biases, LayerNorm, embeddings,
@@ -629,8 +569,6 @@ class CrctModel(nn.Module):
                     seg_events=self._param_events)
         self._param_events = None
         dev = self._flat_p.device
-        if self.ln_fold and self._fold_state() is not None:      # the engine folds where it can (not in the fp8 forward modes)
-            step["ln_fold"] = (self._fold["wfold"], self._fold["c"], self._fold["b"])
         if self.fp8 and not self.fp8_forward and not self.fp8_wgrad:
             # fp8 DATA GRADIENTS only: nothing of the forward pass is quantised (no e4m3 copies, no activation maxima); the backward
             # pass multiplies e5m2 gradients (copies written by the backward kernels themselves) with the transposed e4m3 weight shadow

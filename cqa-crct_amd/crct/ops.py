@@ -32,8 +32,7 @@ def _drop(p, site):
 
 def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
                preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
-               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0,
-               ln_stats_out=None, lnf=None):
+               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0):
     _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
@@ -50,15 +49,6 @@ def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=Non
     g.seed = seed
     g.rowsum_out = L.ptr(rowsum_out)
     g.site = int(model_site)
-    if lnf is not None:                # folded-LayerNorm consumer: dict(stats, tiles, c, gamma, beta, y, mean, rstd[, eps]); A = raw pre-norm sum, B = W o gamma
-        g.lnf_stats, g.lnf_tiles, g.lnf_c = L.ptr(lnf["stats"]), int(lnf["tiles"]), L.ptr(lnf["c"])
-        g.lnf_gamma, g.lnf_beta, g.lnf_y = L.ptr(lnf["gamma"]), L.ptr(lnf["beta"]), L.ptr(lnf["y"])
-        g.lnf_mean, g.lnf_rstd, g.lnf_eps = L.ptr(lnf["mean"]), L.ptr(lnf["rstd"]), float(lnf.get("eps", 1e-12))
-    if ln_stats_out is not None:       # LayerNorm producer: float32 [M][N / tile columns][2] partial statistics (tile columns from crct_gemm_tile_cols)
-        bn = L.load().crct_gemm_tile_cols(C.byref(g))
-        if bn <= 0:
-            raise RuntimeError("this GEMM launch cannot write LayerNorm partial statistics (crct_gemm_tile_cols = 0)")
-        g.ln_stats_out, g.ln_stats_ld = L.ptr(ln_stats_out), N // bn
     if split_k and split_k > 1:       # K-partitioned launch: slab space + ticket words (zero before the first use) per device
         ws, cnt = _splitk_space(A.device, M, N, split_k)
         g.split_k, g.splitk_ws, g.splitk_cnt = int(split_k), L.ptr(ws), L.ptr(cnt)
@@ -205,32 +195,6 @@ def softmax_rows(x):
     y = torch.empty(M, F, device=x.device, dtype=torch.bfloat16)
     L.check(lib.crct_softmax_rows_f32_bf16(L.ptr(_chk(x, torch.float32)), L.ptr(y), M, F, L.current_stream()), "softmax_rows")
     return y
-
-
-def ln_fold_weights(p32, entries, wfold=None):
-    """crct_ln_fold_weights over ``entries`` = [(w_off, b_off, gamma_off, beta_off, n_in, n_out)] of the flat fp32 buffer ``p32``:
-    returns (wfold bf16 with p32's element offsets, c fp32, b' fp32, [c_off per entry])."""
-    lib = L.load()
-    dev = p32.device
-    n = len(entries)
-    c_off, tot = [], 0
-    for e in entries:
-        c_off.append(tot)
-        tot += (e[5] + 63) // 64 * 64
-    if wfold is None:
-        wfold = torch.zeros(p32.numel(), dtype=torch.bfloat16, device=dev)
-    cvec, bvec = torch.zeros(tot, device=dev), torch.zeros(tot, device=dev)
-    out_host = torch.tensor([e[5] for e in entries], dtype=torch.int32)
-    n_blk = int(lib.crct_ln_fold_plan(out_host.data_ptr(), n, None, None, 0))
-    be, br = torch.empty(n_blk, dtype=torch.int32), torch.empty(n_blk, dtype=torch.int32)
-    lib.crct_ln_fold_plan(out_host.data_ptr(), n, be.data_ptr(), br.data_ptr(), n_blk)
-    t64 = lambda k: torch.tensor([e[k] for e in entries], dtype=torch.int64, device=dev)      # noqa: E731
-    t32 = lambda k: torch.tensor([e[k] for e in entries], dtype=torch.int32, device=dev)      # noqa: E731
-    tabs = (t64(0), t64(1), t64(2), t64(3), t32(4), t32(5), torch.tensor(c_off, dtype=torch.int64, device=dev), be.to(dev), br.to(dev))
-    L.check(lib.crct_ln_fold_weights(p32.data_ptr(), wfold.data_ptr(), cvec.data_ptr(), bvec.data_ptr(), *[t.data_ptr() for t in tabs],
-                                     n_blk, 0, L.current_stream()), "ln_fold_weights")
-    torch.cuda.current_stream().synchronize()       # the tables above die with this frame
-    return wfold, cvec, bvec, c_off
 
 
 def cast_bf16(x, out=None):

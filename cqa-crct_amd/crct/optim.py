@@ -82,7 +82,6 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step_dev, self._amp_arg, self._amp_keep = None, None, None
         self._fp8_keep = None
         self._g16 = None                     # bf16 gradient source of the running update (data-parallel bf16 exchange), else None
-        self._folds_kept = False             # did the last step() also refresh the model's gamma-folded weight shadow (_refold)
         # crct/ddp.py: while THIS optimizer is alive and covers every gradient, a bf16 exchange need not write the weight gradients
         # back to fp32 (a weak reference: an optimizer that was built and discarded must not change what .grad holds)
         import weakref
@@ -317,7 +316,6 @@ class FusedAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         core = self.core
         self._follow_device()
-        self._folds_kept = False
         amp = self._amp_begin()
         if not amp:
             self._step += 1
@@ -355,8 +353,6 @@ class FusedAdamW(torch.optim.Optimizer):
                     b1 = max(self._seg_blocks[i][1] for i in members)
                     if b1 > b0:
                         self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, self.overlap_workgroups)
-                    for i in members:
-                        self._refold(i, self._opt_stream.cuda_stream, self.overlap_workgroups)
                     ev = self._events[members[0]]
                     ev.record(self._opt_stream)
                     for i in members[1:]:
@@ -377,19 +373,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     wide = done is None and launched < int(self.full_width_first)
                     self._launch(b0, b1, inv_scale, self._opt_stream.cuda_stream, 0 if wide else self.overlap_workgroups)
                     launched += 1
-                if done is None:
-                    # the gamma-folded weight shadow of this segment's consumer Linears (folded LayerNorm forward) from the new weights and
-                    # the new gamma / beta of their producer LayerNorms -- this segment's or an earlier one's in first-use order, i.e.
-                    # already updated on this stream
-                    self._refold(sgi, self._opt_stream.cuda_stream, self.overlap_workgroups)
                 self._events[sgi].record(self._opt_stream)
             if done is not None:
-                # early mode walks the segments in BACKWARD order (a consumer before its producer LayerNorm): refold everything behind
-                # the last update and let the next forward wait for that
-                self._refold(None, self._opt_stream.cuda_stream, self.overlap_workgroups)
-                if getattr(core, "ln_fold", False):
-                    for ev in self._events:
-                        ev.record(self._opt_stream)
                 order_streams(cur, self._opt_stream)          # the gradient memset that follows must not pass backward's tail
             if not (done is None and self.launch_groups > 0):
                 core._param_events = self._events            # the next forward waits segment by segment
@@ -398,7 +383,6 @@ class FusedAdamW(torch.optim.Optimizer):
             self._upload_hyper()
             self._fp8_before_update(L.current_stream())
             self._launch(0, self._blk_seg.numel(), inv_scale, L.current_stream())
-            self._refold(None, L.current_stream(), 0)
         if getattr(core, "fp8_backward", False) and self._fp8_arg() is not None:
             # the update rewrote the e4m3 weight shadow: its transposed copy (fp8 data gradients) follows on the same stream
             beside = self.overlap and not amp and self._opt_stream is not None
@@ -406,21 +390,12 @@ class FusedAdamW(torch.optim.Optimizer):
             if not self._fp8_transposes:                # normally the update kernel has written the transposed copy itself
                 core._fp8_transpose(side, self.fp8_transpose_workgroups if beside else 0)
             core._fp8_update_grad_scales(side)          # the scales the NEXT backward pass quantises its gradients with
-        core.note_params_updated_natively(folded=self._folds_kept)
+        core.note_params_updated_natively()
         # under GradScaler the kernel returns at once on a skipped step and zeroes nothing: only without it the clear is certain
         self._grads_cleared = bool(self.fuse_zero_grad) and not amp
         if self._grads_cleared:
             core._grads_dirty = False                         # until the next backward pass
         return loss
-
-    def _refold(self, seg, stream, max_workgroups):
-        """Keep the model's gamma-folded weight shadow current (``CrctModel._fold_launch``) -- only once the model has built it (its first
-        forward pass), and only when this optimizer updates every parameter the shadow is made of."""
-        core = self.core
-        self._folds_kept = False
-        if getattr(core, "ln_fold", False) and getattr(core, "_fold", None) is not None and core._engine is not None and self.covers_every_gradient():
-            core._fold_launch(seg, stream, max_workgroups)
-            self._folds_kept = True
 
     def synchronize(self):
         """Order the current stream after an in-flight overlapped update (before reading weights outside forward)."""

@@ -41,7 +41,7 @@ void crct_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crct_last_error(void) { return g_err; }
-extern "C" int crct_abi_version(void) { return 4; }
+extern "C" int crct_abi_version(void) { return 5; }
 
 extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a != nullptr, "gemm: null args");
@@ -130,14 +130,6 @@ struct crct_engine {
   size_t partials[2], colsum_part[4];   // per internal stream: [text, visual] / [text, visual, text-wgrad, visual-wgrad]
   size_t embed_rows[2], embed_idx[2];   // embedding backward: fp32 row gradients + table indices for the gather-sum pass
   size_t km_t = 0, km_v = 0;
-  // folded LayerNorm (CrctGemmArgs.lnf_*): every (consumer Linear, producer LayerNorm) pair of the schedule -- the QKV projection behind
-  // the previous layer's output LayerNorm of its stream, the FFN-up projection behind the attention-output LayerNorm -- in first-use
-  // order; fold_of: consumer weight offset -> entry.  ln_part: per data stream, the producers' partial statistics [rows][tiles] float2.
-  struct FoldEntry { int64_t w, b, g, be; int in, out; int64_t c_off; int seg; };
-  std::vector<FoldEntry> folds;
-  std::unordered_map<int64_t, int> fold_of;
-  int64_t fold_c_total = 0;
-  size_t ln_part[2] = {0, 0};
   // per-site launch policy of the forward / data-gradient GEMMs (crct_engine_set_site_policy): [site][kind][phase]
   struct SitePolicy { int cfg = -1, split_k = 0; };
   SitePolicy policy[CRCT_SITE_COUNT][3][2];      // kind 2 (weight gradient): cfg only -- the layer's grouped launch takes the first problem's
@@ -298,12 +290,6 @@ struct Run {
     }
     parity ^= 1;
   }
-  // ---- folded LayerNorm forward: a LayerNorm whose producing GEMM has written partial row statistics is not launched; it waits here
-  // for the next Linear of this stream, which applies it in its own epilogue and writes LN(s), mean, rstd (lin_fwd_ln), or is launched
-  // after all when that Linear cannot (flush_ln)
-  struct PendLn { bool on = false; size_t s = 0, y = 0, mean = 0, rstd = 0, yq = 0; LnP ln; int M = 0, H = 0, tiles = 0, site = 0; } pend;
-  size_t ln_part = 0;
-  bool fold_on() const { return c->params_fold && c->fold_c && c->fold_b && !f8(); }
   std::vector<CrctGemmArgs> pending;   // weight-gradient GEMMs of the current layer, launched as ONE grouped grid
   bool defer_wgrad = true;             // false: launch every weight gradient immediately on s (buffers are recycled)
   struct FinJob { const float* part; float* dg; float* db; float* dlb; int M, H; };
@@ -340,8 +326,6 @@ struct Run {
     int site = 0;
     void* q_out = nullptr; const float* q_scale = nullptr; float* q_amax = nullptr; int64_t ld_q = 0;      // fp8 copy of the result (calibration passes):
     bool q_e4m3 = false;                                                                                   // e5m2 (a gradient) unless q_e4m3 (an activation)
-    int* stats_tiles = nullptr;      // producer of a LayerNorm: if the launch can, it writes the partial row statistics into this stream's ln_part
-                                     // and *stats_tiles = column tiles per row (else 0)
   };
   void gemm(const void* Ap, int64_t lda, bool ta, const void* Bp, int64_t ldb, bool tb, void* C, int64_t ldc, int M, int N,
             int K, const Opt& o, hipStream_t st = nullptr) {
@@ -364,56 +348,7 @@ struct Run {
         g.split_k = pol.split_k; g.splitk_ws = F(e->sk_ws[which]); g.splitk_cnt = W<uint32_t>(e->sk_cnt[which]);
       }
     }
-    if (o.stats_tiles) {
-      *o.stats_tiles = 0;
-      const int bn = st == s ? crct_gemm_tile_cols(&g) : 0;
-      if (bn > 0) { g.ln_stats_out = F(ln_part); g.ln_stats_ld = N / bn; *o.stats_tiles = N / bn; }
-    }
     fail(crct_gemm_bf16(&g, st));
-  }
-  // The Linear `l` of this stream reads x.  If x is the output of the LayerNorm that is pending on this stream, the GEMM takes the raw
-  // pre-norm sum and the gamma-folded weight instead and normalises in its epilogue (writing x, mean, rstd for backward on the way);
-  // otherwise -- other input, no folded entry, a kernel configuration without the consumer -- the LayerNorm is launched first.
-  void lin_fwd_ln(size_t x, const LinearP& l, int M, void* y, int64_t ldy, Opt o) {
-    if (rc) return;
-    if (pend.on && pend.y == x && fold_on()) {
-      auto it = e->fold_of.find(l.w);
-      if (it != e->fold_of.end() && pend.H == l.in && pend.M == M) {
-        const crct_engine::FoldEntry& fe = e->folds[(size_t)it->second];
-        CrctGemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.A = A(pend.s); g.B = reinterpret_cast<const bf16_t*>(c->params_fold) + l.w; g.C = y; g.bias = c->fold_b + fe.c_off;
-        g.preact_out = o.preact; g.dact_src = o.dact_src; g.addend = o.addend;
-        g.lda = l.in; g.ldb = l.in; g.ldc = ldy; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
-        g.M = M; g.N = l.out; g.K = l.in; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
-        g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
-        g.site = l.site;
-        if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][0][phase].cfg >= 0) g.tile = e->policy[l.site][0][phase].cfg;
-        g.lnf_stats = F(ln_part); g.lnf_tiles = pend.tiles; g.lnf_c = c->fold_c + fe.c_off;
-        g.lnf_gamma = P(pend.ln.g); g.lnf_beta = P(pend.ln.b);
-        g.lnf_y = A(pend.y); g.lnf_mean = F(pend.mean); g.lnf_rstd = F(pend.rstd); g.lnf_eps = 1e-12f;
-        const bool split = l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][0][phase].split_k > 1;
-        if (!split && crct_gemm_lnf_ok(&g)) {
-          ++tick;
-          pend.on = false;
-          fail(crct_gemm_bf16(&g, s));
-          return;
-        }
-      }
-    }
-    if (pend.on && pend.y == x) flush_ln();
-    lin_fwd(A(x), l.in, l, M, y, ldy, o);
-  }
-  void flush_ln() {
-    if (!pend.on) return;
-    pend.on = false;
-    ln_fwd(pend.s, pend.ln, pend.y, pend.mean, pend.rstd, pend.M, pend.H, pend.yq, pend.site);
-  }
-  // y = LN(s) where s has just been produced by a GEMM that was asked for partial statistics (Opt::stats_tiles): deferred when it got them
-  void ln_fwd_or_defer(int tiles, size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H, size_t yq, int site) {
-    flush_ln();
-    if (tiles > 0 && !rc) { pend.on = true; pend.s = x; pend.y = y; pend.mean = mean; pend.rstd = rstd; pend.yq = yq; pend.ln = ln; pend.M = M; pend.H = H; pend.tiles = tiles; pend.site = site; return; }
-    ln_fwd(x, ln, y, mean, rstd, M, H, yq, site);
   }
   // both sides reach this point before either goes on: the two data streams are ordered against each other
   void cross_sync(Run& V) {
@@ -634,11 +569,9 @@ struct Run {
   // ctxq / site_ctx: the e4m3 copy of ctx the attention kernel wrote (-1: none, the projection runs in bf16)
   void proj_fwd(const ProjP& p, const ProjA& a, size_t ctx, size_t x, int M, const Drop& dr, size_t ctxq = (size_t)-1, int site_ctx = -1) {
     Opt o; o.drop = dr; o.addend = A(x); o.ld_add = p.dense.out;
-    int tiles = 0;
-    if (fold_on()) o.stats_tiles = &tiles;
     if (site_ctx >= 0 && f8_lin(p.dense)) lin_fwd_f8(A(ctx), ctxq, site_ctx, p.dense, M, A(a.s), p.dense.out, o);
     else lin_fwd(A(ctx), p.dense.in, p.dense, M, A(a.s), p.dense.out, o);
-    ln_fwd_or_defer(tiles, a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out, a.aq, a.site_a);
+    ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out, a.aq, a.site_a);
   }
   // in: g = grad of a.  out: dres (residual gradient), dctx.  Parameter gradients accumulated.
   void proj_bwd(const ProjP& p, const ProjA& a, size_t ctx, size_t g, size_t dres, size_t dlin, size_t dctx, size_t part, int M, const Drop& dr,
@@ -657,13 +590,11 @@ struct Run {
     Opt o; o.preact = A(a.u); o.ld_aux = p.up.out; o.act = ACT_GELU;
     const bool q_up = f8_lin(p.up), q_dn = f8_lin(p.down);
     if (q_up) lin_fwd_f8(A(x), xq, site_x, p.up, M, A(a.h), p.up.out, o, a.hq, q_dn ? a.site_h : -1);
-    else lin_fwd_ln(x, p.up, M, A(a.h), p.up.out, o);       // x = the attention-output LayerNorm's result: folded into this GEMM when it is pending
+    else lin_fwd(A(x), p.up.in, p.up, M, A(a.h), p.up.out, o);
     Opt o2; o2.drop = dr; o2.addend = A(x); o2.ld_add = p.down.out;
-    int tiles = 0;
-    if (fold_on()) o2.stats_tiles = &tiles;
     if (q_up && q_dn) lin_fwd_f8(A(a.h), a.hq, a.site_h, p.down, M, A(a.s), p.down.out, o2);
     else lin_fwd(A(a.h), p.down.in, p.down, M, A(a.s), p.down.out, o2);
-    ln_fwd_or_defer(tiles, a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out, a.yq, a.site_y);
+    ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out, a.yq, a.site_y);
   }
   // in: g = grad of a.y.  out: gx = grad of x.
   // xq / site_x: the e4m3 copy of x the forward pass read (fp8 weight gradient of the up projection)
@@ -693,7 +624,7 @@ struct Run {
   void self_fwd(const SelfLayerP& p, const SelfLayerA& a, size_t x, size_t xq, int site_x, const uint8_t* km, int B, int T) {
     const int M = B * T, H = p.H, d = H / p.heads;
     if (f8_lin(p.qkv)) lin_fwd_f8(A(x), xq, site_x, p.qkv, M, A(a.qkv), 3 * H, Opt());
-    else lin_fwd_ln(x, p.qkv, M, A(a.qkv), 3 * H, Opt());      // x = the previous layer's output LayerNorm (folded when pending)
+    else lin_fwd(A(x), p.qkv.in, p.qkv, M, A(a.qkv), 3 * H, Opt());
     const bool cq = f8_lin(p.proj.dense) && attn_q_ok(T, T, d);
     attn_fwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(a.ctx), H, B, p.heads, T, T, d, drop(p.p_attn, p.site),
              cq ? a.ctxq : (size_t)-1, cq ? a.site_ctx : -1);
@@ -728,9 +659,9 @@ struct Run {
     const CrctModelDims& D = e->d;
     const int B = b->B, Mv = B * b->V, Mt = B * b->T, Hb = D.Hb, d = Hb / D.b_heads;
     if (V.f8_lin(p.qkv1)) V.lin_fwd_f8(V.A(xv), xvq, site_v, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());
-    else V.lin_fwd_ln(xv, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());            // query1/key1/value1  :662-664
+    else V.lin_fwd(V.A(xv), p.qkv1.in, p.qkv1, Mv, V.A(a.qkv1), 3 * Hb, Opt());  // query1/key1/value1  :662-664
     if (f8_lin(p.qkv2)) lin_fwd_f8(A(xt), xtq, site_t, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());
-    else lin_fwd_ln(xt, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());                // query2/key2/value2  :673-675
+    else lin_fwd(A(xt), p.qkv2.in, p.qkv2, Mt, A(a.qkv2), 3 * Hb, Opt());      // query2/key2/value2  :673-675
     cross_sync(V);                                    // text needs k1, v1; visual needs k2, v2
     // text queries over visual keys/values -> ctx1 [B,T,Hb]  :684-701 (dropout1 = v_attention prob)
     const bool aq = attn_q_ok(b->T, b->V, d) && attn_q_ok(b->V, b->T, d);
@@ -878,7 +809,6 @@ struct Run {
   // Heads, forward.  The pooler and the regressor pipe of a stream only need that stream's last hidden states, so each data
   // stream runs its own branch (this = text or visual Run) before the two join for the fusion MLP and the loss kernel.
   void heads_branch_fwd(bool visual, size_t seq) {
-    flush_ln();                                 // the last layer's output LayerNorm has no Linear behind it to fold into
     const CrctModelDims& D = e->d;
     const int B = b->B;
     const int64_t ld = visual ? (int64_t)b->V * D.Hv : (int64_t)b->T * D.H;  // CLS / IMG rows: hidden_states[:, 0]
@@ -1171,11 +1101,6 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   }
   e->km_t = ar.take(Mt); e->km_v = ar.take(Mv);      // uint8 key masks built from sep_indices / hist_len / image_mask (CrctBatch)
   {
-    // folded LayerNorm: partial row statistics of the running pre-norm sum, [rows][column tiles of >= 64] float2 per data stream
-    const size_t tmax = ((size_t)std::max(std::max(D.H, D.Hv), D.Hb) + 63) / 64;
-    e->ln_part[0] = ar.take(Mt * tmax * 8 + 16); e->ln_part[1] = ar.take(Mv * tmax * 8 + 16);      // (+ one 16-byte piece: the consumer copies whole pieces)
-  }
-  {
     // split-K slab space per data stream: the narrow outputs (N <= the widest hidden size) with up to 4 slices; wider outputs
     // have enough tiles and are never split.  Ticket words: zeroed at the start of every engine call.
     const int Hmax = std::max(std::max(D.H, D.Hv), D.Hb);
@@ -1202,42 +1127,6 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     e->final_t = xt; e->final_v = xv;
     e->taps.push_back({"seq_t", xt, 't'});
     e->taps.push_back({"seq_v", xv, 'v'});
-  }
-
-  // ---- folded LayerNorm pairs, following the schedule: (consumer Linear, LayerNorm that produced its input on that stream).  The
-  // embedding LayerNorms are followed by a dropout (vilbert.py:356-357, :1494-1495) and cannot fold; everything else can.
-  {
-    bool have_t = false, have_v = false;
-    LnP prev_t, prev_v;
-    auto add = [&](const LinearP& l, const LnP& ln, int seg) {
-      if (l.in % 64 != 0 || l.in > 1024 || l.out < l.in || l.out % 8 != 0 || e->fold_of.count(l.w)) return;      // (crct_ln_fold_weights: rows of <= 1024)
-      crct_engine::FoldEntry fe{l.w, l.b, ln.g, ln.b, l.in, l.out, e->fold_c_total, seg};
-      e->fold_of[l.w] = (int)e->folds.size();
-      e->folds.push_back(fe);
-      e->fold_c_total += (l.out + 63) / 64 * 64;
-    };
-    for (size_t i = 0; i < e->sched.size(); ++i) {
-      const Step& st = e->sched[i];
-      const int seg = (int)e->sched.size() - (int)i;
-      if (st.kind == 't') {
-        const SelfLayerP& l = e->tl[st.idx];
-        if (have_t) add(l.qkv, prev_t, seg);
-        add(l.ffn.up, l.proj.ln, seg);
-        prev_t = l.ffn.ln; have_t = true;
-      } else if (st.kind == 'v') {
-        const SelfLayerP& l = e->vl[st.idx];
-        if (have_v) add(l.qkv, prev_v, seg);
-        add(l.ffn.up, l.proj.ln, seg);
-        prev_v = l.ffn.ln; have_v = true;
-      } else {
-        const ConnLayerP& l = e->cl[st.idx];
-        if (have_v) add(l.qkv1, prev_v, seg);
-        if (have_t) add(l.qkv2, prev_t, seg);
-        add(l.ffn_v.up, l.proj_v.ln, seg);
-        add(l.ffn_t.up, l.proj_t.ln, seg);
-        prev_v = l.ffn_v.ln; prev_t = l.ffn_t.ln; have_v = have_t = true;
-      }
-    }
   }
 
   // ---- gradient segments in backward order: heads, schedule reversed, embeddings
@@ -1312,7 +1201,6 @@ void make_runs(crct_engine* e, const float* p32, const void* p16, float* g32, vo
   Rt.sets[0] = &e->st; Rt.sets[1] = &e->st2;
   Rv.sets[0] = &e->sv; Rv.sets[1] = &e->sv2;
   Rt.which = 0; Rv.which = 1;
-  Rt.ln_part = e->ln_part[0]; Rv.ln_part = e->ln_part[1];
 }
 
 // the split-K ticket words of both data streams start every engine call at zero (an aborted launch must not poison the next)
@@ -1509,22 +1397,6 @@ extern "C" int crct_engine_wgrad_owned(crct_engine_t* e, int64_t* offsets, int64
   for (const auto& kv : v) {
     if (offsets && numels && n < cap) { offsets[n] = kv.first; numels[n] = kv.second; }
     ++n;
-  }
-  return n;
-}
-
-// The folded-LayerNorm pairs of the model in first-use order (entries of one backward segment are adjacent): flat offsets of the
-// consumer's weight / bias and of the producing LayerNorm's gamma / beta, the consumer's dimensions, the offset of its c / b' vectors
-// in the compact fold buffers, and the backward segment (= parameter range) the consumer belongs to.  Returns the count, fills up to
-// `cap`; *c_total = fp32 elements of each of the two compact buffers.
-extern "C" int crct_engine_fold_entries(const crct_engine_t* e, int64_t* w_off, int64_t* b_off, int64_t* g_off, int64_t* be_off, int32_t* n_in,
-                                        int32_t* n_out, int64_t* c_off, int32_t* seg, int cap, int64_t* c_total) {
-  if (!e) return -1;
-  const int n = (int)e->folds.size();
-  if (c_total) *c_total = e->fold_c_total;
-  for (int i = 0; i < n && i < cap && w_off; ++i) {
-    const crct_engine::FoldEntry& f = e->folds[(size_t)i];
-    w_off[i] = f.w; b_off[i] = f.b; g_off[i] = f.g; be_off[i] = f.be; n_in[i] = f.in; n_out[i] = f.out; c_off[i] = f.c_off; seg[i] = f.seg;
   }
   return n;
 }

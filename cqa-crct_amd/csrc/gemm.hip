@@ -403,16 +403,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GEMM_HOT_PARAMS) {
 // OCP e4m3: largest finite value 448; the hardware conversion does not saturate, so clamp first
 __device__ __forceinline__ float f8_clamp(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
 
-// sum over groups of G = 8 / 16 consecutive lanes (G-aligned), in every lane of the group: DPP only (see common.hip.h, wave_sum)
-template <int G>
-__device__ __forceinline__ float lanes_sum(float v) {
-  v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
-  v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
-  v += dpp_f32<0x141>(v);       // row_half_mirror: lane i <- lane 7 - i of its 8-lane half row (the other quad)
-  if constexpr (G == 16) v += dpp_f32<0x140>(v);      // row_mirror: the other half row
-  return v;
-}
-
 template <int BM, int BN, int WM, int RING>
 constexpr int epilogue_passes() {
   for (int p = 1; p <= WM; p *= 2)
@@ -422,7 +412,7 @@ constexpr int epilogue_passes() {
 
 // NTH: threads that walk the staged tile (default: the WM x WN compute waves; the loader-wave kernels pass their whole workgroup --
 // waves beyond WM x WN hold no accumulators, their wm is >= WM and they never park anything)
-template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING, int NTH = 0, bool LNFE = false, bool STATS = false>
+template <int BM, int BN, int WM, int WN, int WTM, int WTN, int RING, int NTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f4_t (&acc)[WTN][WTM], char* smem, int m0, int n0,
                                                      int wm, int wn, int lane, int tid, int dbg = 0) {
 #ifdef CRCT_GEMM_LAB   // lab ablations (tools/lab/step_ablate.sh): 64 = no activation / derivative / dropout arithmetic, 128 = no side inputs or outputs
@@ -470,14 +460,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
       if (alpha != 1.0f) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= alpha;
-      }
-      if constexpr (LNFE) {       // folded LayerNorm (consumer): acc = s (W o gamma)^T  ->  rstd * (acc - mean * c[n]); the bias below is the folded b'
-        const float2 ms = reinterpret_cast<const float2*>(smem + RING)[pass * R + r];      // (mean, rstd) of this row: gemm_pipe_body<LNF>
-        const float* cst = reinterpret_cast<const float*>(smem + RING + BM * 8) + ch * 8;    // c of this tile's columns (staged there too)
-        const float4 c0 = *reinterpret_cast<const float4*>(cst), c1 = *reinterpret_cast<const float4*>(cst + 4);
-        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ms.y * (v[j] - ms.x * cc[j]);
       }
       if (bias) {
         const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
@@ -560,29 +542,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
         }
         const uint4 pk = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
         *dst = pk;
-        // STATS: compiled into the producers of the folded LayerNorm only (launch_pipe<..., PM = 4>): carried as a run-time branch by
-        // every kernel it cost the plain 128 x 64 kernels registers and 0.05 - 0.07 ms per step (round 5, same-box A/B against round 4)
-        if constexpr (STATS && (CPR == 8 || CPR == 16)) {
-          if (g.ln_stats_out) {
-            // LayerNorm partial statistics of this row's BN columns (folded LayerNorm, producer side): the values AS STORED (bf16),
-            // summed over the CPR lanes that hold the row's chunks -- consecutive lanes of one wave (DPP, no LDS) -- first the sum,
-            // then the squared deviations from the tile's own mean (the consumer combines the tiles with Chan's formula: no
-            // cancellation of large means).  One fixed slot per (row, column tile): deterministic.  The launcher guarantees
-            // N % BN == 0, so the CPR lanes of a row are active together.
-            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-            float rv[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { rv[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); rv[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
-            float s1 = ((rv[0] + rv[1]) + (rv[2] + rv[3])) + ((rv[4] + rv[5]) + (rv[6] + rv[7]));
-            s1 = lanes_sum<CPR>(s1);
-            const float mt = s1 * (1.0f / (float)BN);
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = rv[j] - mt; q += d * d; }
-            q = lanes_sum<CPR>(q);
-            if (ch == 0) reinterpret_cast<float2*>(g.ln_stats_out)[(long)m * g.ln_stats_ld + n0 / BN] = make_float2(s1, q);
-          }
-        }
       }
     }
     if (pass + 1 < P) __syncthreads();       // the staging tile is rewritten by the next group of wave rows
@@ -604,7 +563,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
 // (cdna_hip_programming.md section 5 "Projection GEMM at M = 256" item 2, Guideline 16 R1); the block -> (tile, slice) map only
 // keeps a tile's slices on one XCD for speed.  The ticket is put back to 0 by the last arriver (all S adds have happened).
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-typedef float f2v_t __attribute__((ext_vector_type(2)));
 template <int BM, int BN, int NW, int WTM, int WTN>
 __device__ __forceinline__ bool splitk_reduce(const CrctGemmArgs& g, f4_t (&acc)[WTN][WTM], char* smem, int slice, int tile_lin, int tid) {
   const int S = g.split_k;
@@ -711,13 +669,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // PM = 1: register-pipelined main loop (the fragments of K tile k + 1 are read from LDS while the MFMAs of tile k run): what the
 // 128 x 64 tiles cannot use -- they sit on the ~70 GB/s per CU L2 -> LDS fill rate either way -- but the larger tiles need: with
 // half the fill bytes per FLOP their time is the serial "read fragments, then multiply" of the plain loop.
-// LNF: the folded-LayerNorm consumer (CrctGemmArgs.lnf_*; forward GEMMs, plain loop): row statistics from the producer's partials into
-// LDS behind the ring, LN(s) written back from the A tile of K step (tile_n), (mean, rstd) applied in the epilogue.
-template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, bool SK = false, int PM = 0, bool LNF = false>
+template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, bool SK = false, int PM = 0>
 __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int tile_m, const int tile_n, const int dbg,
-                                               const int slice = 0, const int tile_lin = 0, const int tiles_n = 1) {
-  static_assert(!LNF || (!TA && !TB && !SK && PM == 0), "folded LayerNorm: forward GEMM, plain loop");
-  static_assert(PM == 0 || PM == 1 || PM == 4, "PM: 0 plain loop, 1 register-pipelined loop, 4 plain loop + LayerNorm partial statistics in the epilogue");
+                                               const int slice = 0, const int tile_lin = 0) {
+  static_assert(PM == 0 || PM == 1, "PM: 0 plain loop, 1 register-pipelined loop");
   constexpr int BM = 32 * TM, BN = 32 * TN, NW = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave per K tile
@@ -777,45 +732,6 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(base + A_BYTES + i * NW * 1024), 16, (int)offB[i], (kt0 + kt) * stepB, 0, 0);
   };
 
-  // folded LayerNorm: which K step's 64 columns of LN(s) this workgroup writes back (-1: none): K step kt belongs to column tile
-  // kt * (tiles_n / nk) -- spread over the whole tile row (the first nk column tiles sit in ONE XCD rectangle); lnf_y: the normalised
-  // chunks, stored at the very end of the kernel (a store inside the loop sits in the counted vmcnt of the DMA ring, one in front of
-  // the epilogue in its first barrier's fence).
-  // Everything the fold needs from global memory -- the producer's partial row statistics (FOUR threads per row, thread q of a row
-  // taking tiles q, q + 4, q + 8, q + 12), gamma / beta of the 8 columns this thread normalises in its K step, c[n0 .. n0 + BN) --
-  // is requested HERE, in front of the first operand DMA, by loads the compiler does not see (inline asm): they are older than every
-  // DMA piece, so the counted vmcnt that says "tile 0 has landed" also says they have, and no wave ever waits for them alone.
-  // (Measured on the way here, per GEMM: one thread per row walking the tiles serially +15 us; all its loads in flight +5 us; an
-  // LDS staging copy +3 - 8 us of bank conflicts; compiler-visible loads behind the DMA issue, i.e. a vmcnt(0) in the prologue,
-  // +2 - 3 us stand-alone and +5 - 10 us in the step.)
-  constexpr int LNF_CH = (BM * 8 + NW * 64 - 1) / (NW * 64);
-  int lnf_kt = -1;
-  f4_t lnf_g0 = {0.f, 0.f, 0.f, 0.f}, lnf_g1 = lnf_g0, lnf_b0 = lnf_g0, lnf_b1 = lnf_g0, lnf_cv = lnf_g0;
-  f2v_t lnf_pv[4];
-  uint4 lnf_y[LNF_CH];
-  if constexpr (LNF) {
-    static_assert(NW * 64 == 4 * BM, "four threads per row of the tile");
-    const int nt = g.lnf_tiles;
-    const int stride = tiles_n / nk;                          // >= 1: the launcher checks N >= K
-    if (tile_n % stride == 0 && tile_n / stride < nk) lnf_kt = tile_n / stride;
-    const int r = tid >> 2, q = tid & 3, m = m0 + r;
-    const float2* p = reinterpret_cast<const float2*>(g.lnf_stats) + (long)(m < g.M ? m : 0) * nt;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                             // unconditional loads; tiles past nt are masked when they are summed
-      const float2* pj = p + (q + 4 * j < nt ? q + 4 * j : 0);
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lnf_pv[j]) : "v"(pj));
-    }
-    const int k = (lnf_kt >= 0 ? lnf_kt : 0) * BK + (tid & 7) * 8;
-    const float* gp = g.lnf_gamma + k;
-    const float* bp = g.lnf_beta + k;
-    const float* cp = g.lnf_c + (n0 + (tid & (BN / 4 - 1)) * 4 < g.N ? n0 + (tid & (BN / 4 - 1)) * 4 : 0);
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnf_g0) : "v"(gp));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(lnf_g1) : "v"(gp));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnf_b0) : "v"(bp));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(lnf_b1) : "v"(bp));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnf_cv) : "v"(cp));
-  }
-
   const int npre = nk < NS - 1 ? nk : NS - 1;
   for (int t = 0; t < npre; ++t) issue(t, t);
 
@@ -866,37 +782,6 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
         }
     }
   };
-  if constexpr (LNF) {
-    // tile 0 has landed => the older statistics / gamma / beta / c loads have: combine the partials within the quad by DPP in a fixed
-    // order (deterministic): mean = sum / K; M2 = sum_t M2_t + cnt * (mean_t - mean)^2; rstd = 1 / sqrt(M2 / K + eps); (mean, rstd) and
-    // c go to LDS behind the ring -- the barrier of the first K step publishes them to the LN(s) write-back and the epilogue.
-    wait_tile(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(lnf_pv[j]));
-    asm volatile("" : "+v"(lnf_g0), "+v"(lnf_g1), "+v"(lnf_b0), "+v"(lnf_b1), "+v"(lnf_cv));
-    const int nt = g.lnf_tiles;
-    const int r = tid >> 2, q = tid & 3, m = m0 + r;
-    const float cnt = (float)g.K / (float)nt, inv_k = 1.0f / (float)g.K, inv_cnt = 1.0f / cnt;
-    float S = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S += q + 4 * j < nt ? lnf_pv[j][0] : 0.f;
-    S += dpp_f32<0xB1>(S);        // quad_perm [1,0,3,2]
-    S += dpp_f32<0x4E>(S);        // quad_perm [2,3,0,1]
-    const float mean = S * inv_k;
-    float M2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const float d = lnf_pv[j][0] * inv_cnt - mean; M2 += q + 4 * j < nt ? lnf_pv[j][1] + cnt * d * d : 0.f; }
-    M2 += dpp_f32<0xB1>(M2);
-    M2 += dpp_f32<0x4E>(M2);
-    const float rstd = 1.0f / sqrtf(M2 * inv_k + g.lnf_eps);
-    // LDS writes as asm too: a store the compiler sees would be fenced against the DMA pieces in flight (s_waitcnt vmcnt(0))
-    const f2v_t ms = m < g.M ? f2v_t{mean, rstd} : f2v_t{0.f, 0.f};
-    const uint32_t lnst_w = smem_base + NS * STAGE + r * 8, cst_w = smem_base + NS * STAGE + BM * 8 + (tid & (BN / 4 - 1)) * 16;
-    if (q == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(lnst_w), "v"(ms));
-    if (tid < BN / 4) asm volatile("ds_write_b128 %0, %1" ::"v"(cst_w), "v"(lnf_cv));
-    frag_async_wait<0>();           // ... and they have landed before this wave reaches the first K-step barrier
-    if (q == 0 && tile_n == 0 && m < g.M) { g.lnf_mean[m] = mean; g.lnf_rstd[m] = rstd; }
-  }
   if constexpr (PM == 1) {
   // register-pipelined: while the MFMAs of tile kt run from one register set, the reads of tile kt+1 fill the other;
   // tile t lives in stage t % NS and its stage goes back to the DMA one barrier after its reads have completed
@@ -945,38 +830,6 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
     frag_async_wait<0>();
     multiply(1, fm, fn);
     rowsums(kt, fm);
-    if constexpr (LNF) {
-      // LN(s) for backward and the residual adds: the 64 columns of K step kt are written by the workgroups of column tile kt
-      // (N >= K: every K step has its column tile), from the raw A tile this stage holds until the next barrier.  LDS reads as
-      // uncounted asm reads (a plain LDS load would make the compiler drain the DMA ring first), gamma / beta from the prologue.
-      if (kt == lnf_kt) {
-        const uint32_t lnst_a = smem_base + NS * STAGE, img_a = smem_base + st * STAGE;
-#pragma unroll
-        for (int i = 0; i < LNF_CH; ++i) {
-          const int c = tid + i * NW * 64, r = c >> 3, ch = c & 7;
-          lnf_y[i] = make_uint4(0u, 0u, 0u, 0u);
-          if (c < BM * 8) {
-            bf8_t raw = lds_read_b128_imm<0>(img_a + off_rowmajor(r, ch));
-            f2v_t ms;
-            asm volatile("ds_read_b64 %0, %1" : "=v"(ms) : "v"(lnst_a + r * 8));
-            frag_async_wait<0>();
-            frag_async_use(raw);
-            asm volatile("" : "+v"(ms));
-            const u4_t w4 = __builtin_bit_cast(u4_t, raw);
-            const uint32_t w[4] = {w4[0], w4[1], w4[2], w4[3]};
-            const float gg[8] = {lnf_g0[0], lnf_g0[1], lnf_g0[2], lnf_g0[3], lnf_g1[0], lnf_g1[1], lnf_g1[2], lnf_g1[3]};
-            const float bb[8] = {lnf_b0[0], lnf_b0[1], lnf_b0[2], lnf_b0[3], lnf_b1[0], lnf_b1[1], lnf_b1[2], lnf_b1[3]};
-            float y[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {      // the arithmetic of row_normalize (rowops.hip): gamma * ((x - mean) * rstd) + beta
-              y[2 * j] = gg[2 * j] * ((bf2f((bf16_t)(w[j] & 0xffff)) - ms[0]) * ms[1]) + bb[2 * j];
-              y[2 * j + 1] = gg[2 * j + 1] * ((bf2f((bf16_t)(w[j] >> 16)) - ms[0]) * ms[1]) + bb[2 * j + 1];
-            }
-            lnf_y[i] = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
-          }
-        }
-      }
-    }
     st_next = st;
     st = st + 1 == NS ? 0 : st + 1;
   }
@@ -1010,17 +863,7 @@ __device__ __forceinline__ void gemm_pipe_body(const CrctGemmArgs& g, const int 
       }
     }
   }
-  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE, 0, LNF, (PM & 4) != 0>(g, acc, smem, m0, n0, wm, wn, lane, tid, lab_bits(dbg));
-  if constexpr (LNF) {
-    if (lnf_kt >= 0) {      // LN(s) of K step lnf_kt (computed in the loop), written last: nothing of this workgroup waits for these stores
-#pragma unroll
-      for (int i = 0; i < LNF_CH; ++i) {
-        const int c = tid + i * NW * 64, r = c >> 3, ch = c & 7;
-        if (c < BM * 8 && m0 + r < g.M)
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.lnf_y) + (long)(m0 + r) * g.K + lnf_kt * BK + ch * 8) = lnf_y[i];
-      }
-    }
-  }
+  gemm_epilogue_staged<BM, BN, WM, WN, WTM, WTN, NS * STAGE>(g, acc, smem, m0, n0, wm, wn, lane, tid, lab_bits(dbg));
 }
 
 template <int TM, int TN, int WM, int WN, bool TA, bool TB, int NS, int PM = 0>
@@ -1030,15 +873,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GEMM_HOT_PARAMS
   int tile_m, tile_n;
   if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;     // padding block of a short edge region
   gemm_pipe_body<TM, TN, WM, WN, TA, TB, NS, false, PM>(g, tile_m, tile_n, tmap.dbg);
-}
-// the folded-LayerNorm consumer (forward only): BM * 8 more bytes of LDS behind the ring for the row statistics
-template <int TM, int TN, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_lnf_kernel(GEMM_HOT_PARAMS) {
-  GEMM_HOT_UNPACK
-  crct_chain_priority();
-  int tile_m, tile_n;
-  if (!map_tile(tmap, blockIdx.x, tile_m, tile_n)) return;
-  gemm_pipe_body<TM, TN, WM, WN, false, false, NS, false, 0, true>(g, tile_m, tile_n, 0, 0, 0, tmap.tiles_n);
 }
 
 // K-partitioned launch: block j of XCD x is slice j % S of the (j / S)-th tile of that XCD's rectangle -- a tile's slices share
@@ -2007,23 +1841,6 @@ hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int TM, int TN, int WM, int WN, int NS>
-hipError_t launch_lnf(const CrctGemmArgs& g, hipStream_t s) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
-  int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
-  const size_t lds = (size_t)NS * (BM + BN) * BK * 2 + (size_t)BM * 8 + (size_t)BN * 4;
-  auto kern = gemm_lnf_kernel<TM, TN, WM, WN, NS>;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  launch_kernel(kern, dim3(tiles), dim3(WM * WN * 64), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);
-  return hipGetLastError();
-}
-
 template <int TM, int TN, int WM, int WN, int NS, int NL, int PIPE = 0>
 hipError_t launch_ldr(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -2297,28 +2114,6 @@ static int resolve_config(const CrctGemmArgs& g, bool& pipe) {
   if (!pipe && t == 0) t = 1;
   return t;
 }
-// the kernels that exist with the producer's statistics epilogue (launch_pipe<..., PM = 4>)
-static bool stats_cfg_ok(int t) { return t == 15 || t == 12 || t == 3 || t == 4 || t == 9; }
-extern "C" int crct_gemm_tile_cols(const CrctGemmArgs* a) {
-  if (!a || (a->fp8 & 1) || a->ta || a->c_is_f32 || a->M <= 0 || a->N <= 0 || a->split_k > 1) return 0;
-  bool pipe = false;
-  const int t = resolve_config(*a, pipe);
-  int bm = 0, bn = 0;
-  if (!pipe || !stats_cfg_ok(t) || !cfg_tile(t, bm, bn) || (bn != 64 && bn != 128) || a->N % bn != 0) return 0;
-  return bn;
-}
-// the folded-LayerNorm consumer exists for the 64-column configurations 15 (128 x 64, 3 stages), 12 (2 stages) and 3 (64 x 64: tiny row
-// counts); every column tile kt < K / 64 writes one 64-column block of LN(s), hence N >= K
-static bool lnf_cfg_ok(const CrctGemmArgs& g, int t, bool pipe) {
-  return pipe && (t == 15 || t == 12 || t == 3) && !g.ta && !g.tb && !(g.fp8 & 1) && g.split_k <= 1 && !g.rowsum_out && !g.q_out && g.N >= g.K &&
-         g.lda == g.K && g.lnf_stats && g.lnf_tiles >= 1 && g.lnf_tiles <= 16 && g.K % g.lnf_tiles == 0 && g.lnf_gamma && g.lnf_beta && g.lnf_y && g.lnf_mean && g.lnf_rstd && g.bias;
-}
-extern "C" int crct_gemm_lnf_ok(const CrctGemmArgs* a) {
-  if (!a || !a->lnf_c || a->M <= 0 || a->N <= 0) return 0;
-  bool pipe = false;
-  const int t = resolve_config(*a, pipe);
-  return lnf_cfg_ok(*a, t, pipe) ? 1 : 0;
-}
 
 hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
@@ -2348,14 +2143,6 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
   // K-partitioned launch: the four configurations it is built for; anything else runs unsplit (same function, other summation order)
   if (g.split_k > 1 && !(pipe && splitk_ok(g) && (t == 4 || t == 9 || t == 12 || t == 15))) g.split_k = 0;
   if (g.split_k <= 1) g.split_k = 0;
-  // folded LayerNorm: both sides need what only some kernels have -- refuse rather than compute something else (the engine asks
-  // crct_gemm_lnf_ok / crct_gemm_tile_cols before it builds such a launch)
-  if (g.lnf_c && (is_f8 || !lnf_cfg_ok(g, t, pipe))) return hipErrorInvalidValue;
-  if (g.ln_stats_out) {
-    int bm = 0, bn = 0;
-    if (is_f8 || !pipe || g.ta || g.c_is_f32 || g.split_k || g.lnf_c || !stats_cfg_ok(t) || !cfg_tile(t, bm, bn) || (bn != 64 && bn != 128) || g.N % bn != 0 ||
-        g.ln_stats_ld != g.N / bn) return hipErrorInvalidValue;
-  }
   prof_begin((pipe ? t : 16 + (t & 3)) * 3 + kind_of(g), &g, 1);
   hipError_t e;
   int grid = 0;
@@ -2367,20 +2154,6 @@ hipError_t crct_gemm_launch(const CrctGemmArgs& g_in, hipStream_t s) {
       case 9: e = launch_splitk<4, 4, 2, 4, 2>(g, s); break;
       case 15: e = launch_splitk<4, 2, 4, 2, 3>(g, s); break;
       default: e = launch_splitk<4, 2, 4, 2, 2>(g, s); break;
-    }
-  } else if (pipe && g.ln_stats_out) {      // producer of a folded LayerNorm: the plain loop with the statistics epilogue
-    switch (t) {
-      case 3: e = launch_pipe<2, 2, 2, 2, 4, 4>(g, s); break;
-      case 4: e = launch_pipe<4, 4, 2, 4, 3, 4>(g, s); break;
-      case 9: e = launch_pipe<4, 4, 2, 4, 2, 4>(g, s); break;
-      case 12: e = launch_pipe<4, 2, 4, 2, 2, 4>(g, s); break;
-      default: e = launch_pipe<4, 2, 4, 2, 3, 4>(g, s); break;     // 15
-    }
-  } else if (pipe && g.lnf_c) {
-    switch (t) {
-      case 3: e = launch_lnf<2, 2, 2, 2, 4>(g, s); break;
-      case 12: e = launch_lnf<4, 2, 4, 2, 2>(g, s); break;
-      default: e = launch_lnf<4, 2, 4, 2, 3>(g, s); break;     // 15
     }
   } else if (pipe) {
     switch (t) {

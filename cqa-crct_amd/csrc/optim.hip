@@ -228,105 +228,6 @@ extern "C" int crct_adamw_step(float* p, float* g, float* m, float* v, void* p_b
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------------ folded-LayerNorm weight shadow
-// (CrctGemmArgs.lnf_*; BertLayerNorm vilbert.py:281-294 followed by a Linear, e.g. :424-428 -> :455).  For every (consumer Linear W, b;
-// producer LayerNorm gamma, beta) pair: wfold = bf16(W o gamma) -- the B operand of the consumer GEMM, which then reads the RAW pre-norm
-// sum --, c[n] = sum_k wfold[n][k] (from the ROUNDED values: it cancels mean * sum_k exactly as the MFMAs see it) and
-// b'[n] = b[n] + sum_k W[n][k] beta[k].  One wave per output row, 16 rows per workgroup; HBM-bound (4 B read + 2 B written per weight).
-namespace {
-constexpr int FOLD_ROWS = 16;
-// NCH = ceil(K / 256) float4 chunks per lane and row.  A wave takes 4 rows at once and requests ALL their chunks before it touches
-// one (up to 16 x 16 bytes in flight per lane: the first version walked row by row, chunk by chunk -- one HBM round trip each -- and
-// took 0.67 ms per step for 0.77 GB).
-template <int NCH>
-__device__ __forceinline__ void ln_fold_rows(const float* __restrict__ W, const float* __restrict__ gam, const float* __restrict__ bet,
-                                             const float* __restrict__ bias, bf16_t* __restrict__ F, float* __restrict__ cv,
-                                             float* __restrict__ bv, int K, int N, int row0, int lane) {
-  float4 gv[NCH], bt[NCH];
-  f4_t w[4][NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int k = min(lane * 4 + 256 * i, K - 4);
-    gv[i] = *reinterpret_cast<const float4*>(gam + k);
-    bt[i] = *reinterpret_cast<const float4*>(bet + k);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = min(row0 + r, N - 1);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      w[r][i] = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(W + (long)n * K + min(lane * 4 + 256 * i, K - 4)));
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = row0 + r;
-    float c = 0.f, bb = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int k = lane * 4 + 256 * i;
-      if (k < K && n < N) {
-        const f4_t x = w[r][i];
-        const uint32_t lo = pack2bf(x[0] * gv[i].x, x[1] * gv[i].y), hi = pack2bf(x[2] * gv[i].z, x[3] * gv[i].w);
-        *reinterpret_cast<uint2*>(F + (long)n * K + k) = make_uint2(lo, hi);
-        c += (bf2f((bf16_t)(lo & 0xffff)) + bf2f((bf16_t)(lo >> 16))) + (bf2f((bf16_t)(hi & 0xffff)) + bf2f((bf16_t)(hi >> 16)));
-        bb += (x[0] * bt[i].x + x[1] * bt[i].y) + (x[2] * bt[i].z + x[3] * bt[i].w);
-      }
-    }
-    c = wave_sum(c);
-    bb = wave_sum(bb);
-    if (lane == 0 && n < N) { cv[n] = c; bv[n] = bias[n] + bb; }
-  }
-}
-__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ p32, bf16_t* __restrict__ wfold, float* __restrict__ cvec,
-                                                      float* __restrict__ bvec, const int64_t* __restrict__ w_off,
-                                                      const int64_t* __restrict__ b_off, const int64_t* __restrict__ g_off,
-                                                      const int64_t* __restrict__ be_off, const int32_t* __restrict__ n_in,
-                                                      const int32_t* __restrict__ n_out, const int64_t* __restrict__ c_off,
-                                                      const int32_t* __restrict__ blk_entry, const int32_t* __restrict__ blk_row, int n_blk) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
-    const int e = blk_entry[blk], row0 = blk_row[blk] + 4 * wave;      // 4 waves x 4 rows = FOLD_ROWS
-    const int K = n_in[e], N = n_out[e];
-    if (row0 >= N) continue;
-    const float* W = p32 + w_off[e];
-    bf16_t* F = wfold + w_off[e];
-    float* cv = cvec + c_off[e];
-    float* bv = bvec + c_off[e];
-    const int nch = (K + 255) / 256;
-    switch (nch) {
-      case 1: ln_fold_rows<1>(W, p32 + g_off[e], p32 + be_off[e], p32 + b_off[e], F, cv, bv, K, N, row0, lane); break;
-      case 2: ln_fold_rows<2>(W, p32 + g_off[e], p32 + be_off[e], p32 + b_off[e], F, cv, bv, K, N, row0, lane); break;
-      case 3: ln_fold_rows<3>(W, p32 + g_off[e], p32 + be_off[e], p32 + b_off[e], F, cv, bv, K, N, row0, lane); break;
-      default: ln_fold_rows<4>(W, p32 + g_off[e], p32 + be_off[e], p32 + b_off[e], F, cv, bv, K, N, row0, lane); break;      // K <= 1024 (checked by the launcher's caller: CRCT hidden sizes)
-    }
-  }
-}
-}  // namespace
-
-extern "C" int64_t crct_ln_fold_plan(const int32_t* out_rows, int n_entries, int32_t* blk_entry, int32_t* blk_row, int64_t cap) {
-  int64_t nb = 0;
-  for (int e = 0; e < n_entries; ++e)
-    for (int r = 0; r < out_rows[e]; r += FOLD_ROWS) {
-      if (blk_entry && blk_row && nb < cap) { blk_entry[nb] = e; blk_row[nb] = r; }
-      ++nb;
-    }
-  return nb;
-}
-
-extern "C" int crct_ln_fold_weights(const float* p32, void* wfold, float* cvec, float* bvec, const int64_t* w_off, const int64_t* b_off,
-                                    const int64_t* g_off, const int64_t* be_off, const int32_t* n_in, const int32_t* n_out,
-                                    const int64_t* c_off, const int32_t* blk_entry, const int32_t* blk_row, int64_t n_blk,
-                                    int max_workgroups, crct_stream_t stream) {
-  CRCT_REQUIRE(p32 && wfold && cvec && bvec && w_off && b_off && g_off && be_off && n_in && n_out && c_off && blk_entry && blk_row,
-               "ln_fold_weights: null argument");
-  if (n_blk <= 0) return 0;
-  const long grid = (max_workgroups > 0 && n_blk > max_workgroups) ? max_workgroups : n_blk;
-  crct_launch(ln_fold_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p32, (bf16_t*)wfold, cvec, bvec, w_off, b_off, g_off,
-              be_off, n_in, n_out, c_off, blk_entry, blk_row, (int)n_blk);
-  CRCT_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 extern "C" int crct_adamw_advance(int32_t* step_dev, const float* found_inf_dev, crct_stream_t stream) {
   CRCT_REQUIRE(step_dev, "adamw_advance: null step counter");
   crct_launch(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, found_inf_dev);

@@ -78,47 +78,7 @@ typedef struct CrctGemmArgs {
    * stream-ordered.  0 / 1 = off.  Not with ta (weight gradients), rowsum_out or fp8. */
   int32_t split_k;
   float* splitk_ws; uint32_t* splitk_cnt;
-  /* ---- LayerNorm forward folded into the neighbouring GEMMs (round 5; BertLayerNorm vilbert.py:281-294 between two Linears,
-   * :424-428 -> :455, :467-471 -> next layer's :388-390).  The LayerNorm between a PRODUCER Linear (attention output / FFN down:
-   * its epilogue writes the pre-norm sum s = dropout(dense(x)) + residual) and a CONSUMER Linear (FFN up / next QKV) is not a
-   * launch of its own any more:
-   *   producer  ln_stats_out != NULL: besides C = s (bf16) the epilogue writes, per output row and column tile, the partial
-   *             statistics of the bf16-rounded s: float2 (sum, sum of squared deviations from the tile's own mean) at
-   *             ln_stats_out[(row * ln_stats_ld + column_tile) * 2] -- fixed slots, no atomics.  ln_stats_ld = N / tile columns
-   *             (crct_gemm_tile_cols); needs a bf16 C and N % tile columns == 0.  A kernel variant of its own (compiled for the
-   *             configurations 15 / 12 / 3 / 4 / 9 only; not with split_k, lnf_c, fp8): launches without ln_stats_out run the
-   *             plain kernels, whose code does not contain the statistics at all.
-   *   consumer  lnf_c != NULL: A is the RAW pre-norm sum s [M][K] (lda = K), B the gamma-folded weight bf16(W[n][k] * gamma[k])
-   *             (crct_ln_fold_weights), bias the folded bias b'[n] = b[n] + sum_k W[n][k] beta[k], lnf_c[n] = sum_k B[n][k].  Every
-   *             workgroup combines the lnf_tiles partials of its rows (Chan's parallel variance: mean, rstd with eps inside the
-   *             square root) and its epilogue computes  rstd[m] * (acc[m][n] - mean[m] * lnf_c[n]) + b'[n]  = LN(s) W^T + b without
-   *             LN(s) ever being rounded to bf16; the rest of the epilogue (saved pre-activation, GELU, ...) follows as usual.
-   *             The kernel also WRITES what backward and the residual add need: lnf_y = bf16(gamma * (s - mean) * rstd + beta)
-   *             [M][K] (column block kt by the workgroups of column tile kt, from the A tile they hold in LDS anyway) and lnf_mean /
-   *             lnf_rstd fp32 [M] (column tile 0).  Forward GEMMs of the LDS-DMA kernel with 64-column tiles and N >= K only
-   *             (crct_gemm_lnf_ok); not with split_k, fp8, ta / tb. */
-  void* ln_stats_out; int32_t ln_stats_ld;
-  const void* lnf_stats; int32_t lnf_tiles;
-  const float* lnf_c; const float* lnf_gamma; const float* lnf_beta;
-  void* lnf_y; float* lnf_mean; float* lnf_rstd; float lnf_eps;
 } CrctGemmArgs;
-/* Columns of the output tile the launcher would give this GEMM if it can write LayerNorm partial statistics (CrctGemmArgs.ln_stats_out):
- * 64 or 128; 0 = this launch cannot (a configuration without the statistics variant, register-staged kernel, fp32 output, split_k,
- * N not a multiple of the tile). */
-int crct_gemm_tile_cols(const CrctGemmArgs* args);
-/* != 0: this GEMM (with lnf_* set) would run on a kernel that implements the folded LayerNorm consumer. */
-int crct_gemm_lnf_ok(const CrctGemmArgs* args);
-/* The gamma-folded weight shadow and its two vectors for every (consumer Linear, producer LayerNorm) pair of a model
- * (crct_engine_fold_entries): entry e has weight p32[w_off .. + out * in) ([out][in], fp32 master), bias p32[b_off .. + out),
- * gamma / beta p32[g_off / be_off .. + in); written are wfold[w_off + n * in + k] = bf16(W[n][k] * gamma[k]) (same element offsets as
- * the bf16 weight shadow), cvec[c_off + n] = sum_k float(wfold[n][k]), bvec[c_off + n] = b[n] + sum_k W[n][k] * beta[k].
- * All tables are DEVICE arrays; blk_entry / blk_row [n_blk]: workgroup -> (entry, first of its 16 output rows), built on the host
- * by crct_ln_fold_plan.  max_workgroups > 0: grid-stride launch of at most that many workgroups (an update beside the next forward). */
-int64_t crct_ln_fold_plan(const int32_t* out_rows, int n_entries, int32_t* blk_entry, int32_t* blk_row, int64_t cap);
-int crct_ln_fold_weights(const float* p32, void* wfold, float* cvec, float* bvec,
-                         const int64_t* w_off, const int64_t* b_off, const int64_t* g_off, const int64_t* be_off,
-                         const int32_t* n_in, const int32_t* n_out, const int64_t* c_off,
-                         const int32_t* blk_entry, const int32_t* blk_row, int64_t n_blk, int max_workgroups, crct_stream_t stream);
 
 /* GEMM sites of the step.  The FFN group of BASELINE.md section 4 ("fraction of the FFN-GEMM roofline") = the four *_FFN_* sites. */
 enum {
@@ -635,14 +595,6 @@ typedef struct CrctStepCfg {
                                 rounded to bf16 by the GEMM epilogue, and NOT into grads_f32 -- the exchange need not pack them (1.4 GB
                                 of traffic per step less) and the weight-gradient GEMMs write half the bytes.  Every other gradient
                                 still goes to grads_f32. */
-  /* Folded LayerNorm forward (round 5; forward only, bf16 mode; all three or none).  params_fold: bf16 buffer with the element offsets of
-   * params_bf16 holding bf16(W o gamma) for every consumer Linear of crct_engine_fold_entries; fold_c / fold_b: the compact fp32
-   * vectors c[n] = sum_k fold[n][k] and b'[n] = b[n] + sum_k W[n][k] beta[k] (crct_ln_fold_weights keeps all three current behind every
-   * parameter update).  When set, the attention-output and FFN-output LayerNorms are not launched: the GEMM that produces the pre-norm
-   * sum writes partial row statistics and the next Linear of the stream normalises in its epilogue (CrctGemmArgs.lnf_*), writing LN(s),
-   * mean and rstd where the LayerNorm kernel would have -- backward is unchanged.  The last LayerNorm of each stream (the heads read
-   * it) and the embedding LayerNorms (a dropout follows them) stay launches. */
-  const void* params_fold; const float* fold_c; const float* fold_b;
 } CrctStepCfg;
 
 int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,
@@ -698,12 +650,6 @@ int crct_zero_runs(float* base, const int64_t* off, const int64_t* len, const in
                    int64_t n_blk, crct_stream_t stream);
 /* fp8 forward: number of activation scale sites, and the (flat offset, element count) of every weight that has an e4m3 shadow
  * (index = its slot in CrctStepCfg.fp8_w_scale).  Both are fixed at crct_engine_create. */
-/* The (consumer Linear, producer LayerNorm) pairs of the folded LayerNorm, in first-use order (the entries of one backward segment are
- * adjacent): flat offsets of the consumer's weight / bias and the LayerNorm's gamma / beta, the consumer's (in, out), the offset of its
- * c / b' vectors in the compact buffers, the backward segment whose parameter range holds the consumer.  Returns the count, fills up to
- * `cap`; *c_total = fp32 elements of each compact buffer.  Fixed at crct_engine_create. */
-int crct_engine_fold_entries(const crct_engine_t*, int64_t* w_off, int64_t* b_off, int64_t* g_off, int64_t* be_off, int32_t* n_in,
-                             int32_t* n_out, int64_t* c_off, int32_t* seg, int cap, int64_t* c_total);
 int crct_engine_fp8_sites(const crct_engine_t*);
 int crct_engine_fp8_grad_sites(const crct_engine_t*);      /* gradient scale sites of the fp8 backward (CrctStepCfg.fp8_grad_scale) */
 int crct_engine_fp8_weights(const crct_engine_t*, int64_t* offsets, int64_t* numels, int cap);

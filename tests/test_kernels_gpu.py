@@ -873,90 +873,6 @@ def test_attention_gives_the_same_bits_for_every_wave_count(gemm_path):
         assert float(res[0][key].float().abs().max()) > 0
 
 
-# ------------------------------------------------------------------------------------------------ folded LayerNorm (round 5)
-@pytest.mark.parametrize("M,H,N,tile", [(1600, 768, 2304, -1), (1600, 768, 3072, 12), (2880, 1024, 1024, -1), (21, 64, 192, -1), (200, 128, 256, 15)],
-                         ids=["t.qkv", "t.ffn_up-2stage", "v.ffn_up", "tiny", "ragged"])
-def test_folded_layernorm_matches_layernorm_then_linear(M, H, N, tile, gemm_path):
-    """BertLayerNorm (vilbert.py:281-294) between two Linears without a launch of its own: the PRODUCER GEMM (dense + residual,
-    :424-428) writes per (row, column tile) partial statistics of the bf16 pre-norm sum; the CONSUMER GEMM (:455 / :388-390) reads
-    the RAW sum against the gamma-folded weight, finishes the statistics, applies rstd * (acc - mean * c) + b' in its epilogue and
-    writes LN(s), mean and rstd.  Checked against fp32 LayerNorm -> Linear of the same bf16 inputs; the written LN(s) / statistics
-    against the stand-alone LayerNorm kernel."""
-    if gemm_path == "generic":
-        pytest.skip("the folded LayerNorm lives in the LDS-DMA kernels (the engine falls back to the LayerNorm launch elsewhere)")
-    torch.manual_seed(M + N)
-    dev = "cuda"
-    K0 = 128
-    x0 = (torch.randn(M, K0, device=dev) * 0.5).bfloat16()
-    w0 = (torch.randn(H, K0, device=dev) * 0.3).bfloat16()
-    b0 = torch.randn(H, device=dev) * 0.1
-    res = (torch.randn(M, H, device=dev) * 2.0 + 1.5).bfloat16()         # a residual stream with a DC offset: mean / std ~ 1
-    # ---- producer: s = x0 w0^T + b0 + res, with partial statistics
-    stats = torch.full((M, 16, 2), float("nan"), device=dev)
-    s_sum = ops.gemm(x0, w0, M, H, K0, bias=b0, addend=res, ln_stats_out=stats)
-    g = L.GemmArgs()
-    ops._gemm_args(g, x0, w0, M, H, K0, bias=b0, addend=res, out=s_sum)
-    bn = L.load().crct_gemm_tile_cols(C.byref(g))
-    assert bn in (64, 128) and H % bn == 0
-    tiles = H // bn
-    torch.cuda.synchronize()
-    sf = s_sum.float()
-    st = stats.view(-1)[:M * tiles * 2].view(M, tiles, 2)
-    blk = sf.view(M, tiles, bn)
-    assert torch.allclose(st[:, :, 0], blk.sum(-1), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(st[:, :, 1], ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-3)
-    # ---- fold: W o gamma, c, b'
-    gamma = 1.0 + 0.2 * torch.randn(H, device=dev)
-    beta = 0.1 * torch.randn(H, device=dev)
-    W = torch.randn(N, H, device=dev) * 0.05
-    b = torch.randn(N, device=dev) * 0.1
-    flat = torch.cat([W.flatten(), b, gamma, beta]).contiguous()
-    o_b, o_g, o_be = N * H, N * H + N, N * H + N + H
-    wfold, cvec, bvec, c_off = ops.ln_fold_weights(flat, [(0, o_b, o_g, o_be, H, N)])
-    wf = wfold[:N * H].view(N, H)
-    assert torch.equal(wf, (W * gamma).bfloat16())
-    assert torch.allclose(cvec[:N], wf.float().sum(1), rtol=1e-5, atol=1e-4)
-    assert torch.allclose(bvec[:N], b + W @ beta, rtol=1e-5, atol=1e-5)
-    # ---- consumer
-    y = torch.full((M, H), float("nan"), device=dev, dtype=torch.bfloat16)
-    mean = torch.full((M,), float("nan"), device=dev)
-    rstd = torch.full((M,), float("nan"), device=dev)
-    pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    lnf = dict(stats=stats, tiles=tiles, c=cvec, gamma=gamma, beta=beta, y=y, mean=mean, rstd=rstd)
-    gq = L.GemmArgs()
-    ops._gemm_args(gq, s_sum, wf, M, N, H, bias=bvec, lnf=lnf, tile=tile)
-    assert L.load().crct_gemm_lnf_ok(C.byref(gq)) == 1
-    out = ops.gemm(s_sum, wf.contiguous(), M, N, H, bias=bvec, lnf=lnf, act="gelu", preact_out=pre, tile=tile)
-    torch.cuda.synchronize()
-    ln_ref = torch.nn.functional.layer_norm(sf, (H,), gamma, beta, 1e-12)
-    ref_pre = ln_ref @ W.t() + b
-    scale = float(ref_pre.abs().max())
-    # bf16 operands (s and W o gamma are what they are; LN(s) itself is never rounded): 1e-2 of max like every bf16 GEMM test here
-    assert float((pre.float() - ref_pre).abs().max()) <= 1e-2 * scale
-    assert float((out.float() - torch.nn.functional.gelu(ref_pre)).abs().max()) <= 1e-2 * scale
-    # what the kernel leaves for backward / the residual add == the LayerNorm kernel's outputs (same formula, statistics from partials)
-    y2, mean2, rstd2 = ops.layernorm_fwd(s_sum, gamma, beta)
-    assert torch.allclose(mean, mean2, rtol=1e-5, atol=1e-5) and torch.allclose(rstd, rstd2, rtol=2e-5, atol=1e-6)
-    assert not torch.isnan(y.float()).any()
-    assert float((y.float() - y2.float()).abs().max()) <= 2 ** -7 * float(y2.float().abs().max())      # a last-bit statistic may flip a bf16 rounding
-
-
-def test_folded_layernorm_requests_are_refused_where_no_kernel_has_them(gemm_path):
-    """The launcher must not compute something else: a consumer request on a configuration without the folded epilogue, or a
-    statistics request on an fp32 output, is an error (the engine asks crct_gemm_lnf_ok / crct_gemm_tile_cols first)."""
-    dev = "cuda"
-    M, H, N = 256, 128, 256
-    s_sum = torch.randn(M, H, device=dev).bfloat16()
-    w = torch.randn(N, H, device=dev).bfloat16()
-    z = torch.zeros(max(M, N), device=dev)
-    stats = torch.zeros(M, 2, 2, device=dev)
-    lnf = dict(stats=stats, tiles=2, c=z, gamma=z, beta=z, y=torch.empty(M, H, device=dev, dtype=torch.bfloat16), mean=z.clone(), rstd=z.clone())
-    with pytest.raises(RuntimeError):
-        ops.gemm(s_sum, w, M, N, H, bias=z, lnf=lnf, tile=4)            # 128 x 128 tiles: no consumer
-    with pytest.raises(RuntimeError):
-        ops.gemm(s_sum, w, M, N, H, bias=z, out_f32=True, ln_stats_out=stats)
-
-
 def test_gemm_refuses_a_leading_dimension_beyond_32_bits():
     """The operands' leading dimensions reach the kernel as preloaded 32-bit scalars (gemm.hip GEMM_HOT_ARGS): a larger one is an error, not
     a truncation."""
@@ -1027,30 +943,59 @@ def _gelu_check(U, y, dy):
     return out
 
 
-def test_gelu_epilogues_are_within_one_bf16_step_of_libm_and_a_perturbed_build_is_told_apart(gemm_path):
+def test_gelu_epilogues_are_within_one_bf16_step_of_libm(gemm_path):
     """the branch-free erf (Abramowitz & Stegun 7.1.26) behind the GELU / GELU' epilogues (vilbert.py:111-117 and its
     derivative) against float64 erf on 2^20 points including |u| > 4: never more than ONE bf16 step from the correctly rounded value,
     and the correctly rounded value itself on >= 99 % of the points (measured: 99.9+ %).  The second bound is what a wrong derivative
-    cannot pass: the same check on tools/lab/libcrct_gelu_perturbed.so (this library built with gelu' x 1.001: make -C cqa-crct_amd/csrc
-    perturbed) must FAIL -- a 1e-3 relative error moves a quarter of the roundings."""
+    cannot pass: test_a_build_with_a_perturbed_gelu_derivative_is_told_apart."""
     U, y, dy = _gelu_epilogue_outputs(lambda *a, **k: ops.gemm(*a, **k))
     (d0, f0, a0), (d1, f1, a1) = _gelu_check(U, y, dy)
     print("gelu: worst %d bf16 steps, %.4f %% not correctly rounded; gelu': worst %d, %.4f %%" % (d0, 100 * f0, d1, 100 * f1))
     assert d0 <= 1 and d1 <= 1 and a0 and a1, (d0, d1, a0, a1)
     assert f0 <= 0.01 and f1 <= 0.01, (f0, f1)
-    alt = __import__("os").path.join(__import__("os").path.dirname(L.LIB_PATH), "..", "..", "tools", "lab", "libcrct_gelu_perturbed.so")
-    if gemm_path == "pipelined" and __import__("os").path.exists(alt):
-        lib2 = C.CDLL(alt)
-        lib2.crct_gemm_bf16.restype = C.c_int
-        lib2.crct_gemm_bf16.argtypes = [C.POINTER(L.GemmArgs), C.c_void_p]
 
-        def call2(A, B, M, N, K, **kw):
-            g = L.GemmArgs()
-            out = ops._gemm_args(g, A, B, M, N, K, **kw)
-            assert lib2.crct_gemm_bf16(C.byref(g), L.current_stream()) == 0
-            return out
-        U2, y2, dy2 = _gelu_epilogue_outputs(call2)
-        (_, f0p, _), (d1p, f1p, _) = _gelu_check(U2, y2, dy2)
-        print("perturbed build: gelu %.4f %% not correctly rounded (unchanged code), gelu' worst %d steps, %.2f %% not correctly rounded" % (100 * f0p, d1p, 100 * f1p))
-        assert f0p <= 0.01                       # its GELU is this build's
-        assert f1p > 0.05                        # ... its GELU' is caught: the bound above (1 %) fails on it
+
+def _perturbed_library():
+    """tools/lab/libcrct_gelu_perturbed.so: this library with gelu' x 1.001 (make -C cqa-crct_amd/csrc perturbed).  A test fixture, not a
+    build product (__graft_entry__.build() does not make it): built HERE when it is missing or older than the library under test --
+    the same structs must be on both sides of the call -- with the box's own hipcc; no hipcc, no sensitivity check (skipped, visibly)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(L.LIB_PATH), "..", ".."))
+    alt = os.path.join(root, "tools", "lab", "libcrct_gelu_perturbed.so")
+    if os.path.exists(alt) and os.path.getmtime(alt) >= os.path.getmtime(L.LIB_PATH):
+        return alt
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) and shutil.which("make")):
+        pytest.skip("no hipcc / make on this box: the perturbed-GELU build cannot be made")
+    env = dict(os.environ, HIPCC=hipcc)
+    r = subprocess.run(["make", "-C", os.path.join(root, "cqa-crct_amd", "csrc"), "perturbed"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=1500)
+    if r.returncode != 0 or not os.path.exists(alt):
+        pytest.skip("make perturbed failed: " + r.stdout[-400:])
+    return alt
+
+
+def test_a_build_with_a_perturbed_gelu_derivative_is_told_apart(gemm_path):
+    """The sensitivity of test_gelu_epilogues_are_within_one_bf16_step_of_libm: the same check on a build whose GELU' is off by 1e-3
+    relative must FAIL its correct-rounding bound (a quarter of the roundings move), while its unchanged GELU still passes."""
+    if gemm_path != "pipelined":
+        pytest.skip("the second library has its own (default) GEMM path: one run")
+    alt = _perturbed_library()
+    lib2 = C.CDLL(alt)
+    lib2.crct_gemm_bf16.restype = C.c_int
+    lib2.crct_gemm_bf16.argtypes = [C.POINTER(L.GemmArgs), C.c_void_p]
+    lib2.crct_abi_version.restype = C.c_int
+    assert lib2.crct_abi_version() == L.load().crct_abi_version()
+
+    def call2(A, B, M, N, K, **kw):
+        g = L.GemmArgs()
+        out = ops._gemm_args(g, A, B, M, N, K, **kw)
+        assert lib2.crct_gemm_bf16(C.byref(g), L.current_stream()) == 0
+        return out
+    U2, y2, dy2 = _gelu_epilogue_outputs(call2)
+    (_, f0p, _), (d1p, f1p, _) = _gelu_check(U2, y2, dy2)
+    print("perturbed build: gelu %.4f %% not correctly rounded (unchanged code), gelu' worst %d steps, %.2f %% not correctly rounded" % (100 * f0p, d1p, 100 * f1p))
+    assert f0p <= 0.01                       # its GELU is this build's
+    assert f1p > 0.05                        # ... its GELU' is caught: the 1 % bound fails on it

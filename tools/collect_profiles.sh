@@ -1,9 +1,9 @@
 # End-of-round evidence, collected on the GPU box in one call:  bash tools/collect_profiles.sh <tag>
 # writes gpurun_out/<tag>_*; the PMC tables are also put under profiles/ of the box's copy so that the bench lines that
 # follow read their roofline.traffic from the same build.
-tag=${1:-r5}
-# optional second argument: space-separated stages (pmc pmcfp8 pmclc stats labs bench); default: all
-stages=${2:-"pmc pmcfp8 pmclc stats labs bench"}
+tag=${1:-r6}
+# optional second argument: space-separated stages (pmc pmcfp8 pmclc pmcpq stats labs bench); default: all
+stages=${2:-"pmc pmcfp8 pmclc pmcpq stats labs bench"}
 want() { case " $stages " in *" $1 "*) return 0;; esac; return 1; }
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -39,6 +39,16 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p7 -- $PB 
 python3 $R/tools/pmc_sites.py /tmp/log6.json $O/${tag}_pmc_sites_longctx.json $(cc /tmp/p6) $(cc /tmp/p7) > $O/${tag}_pmc_sites_longctx.txt 2>&1
 cp $O/${tag}_pmc_sites_longctx.json $R/profiles/${tag}_pmc_sites_longctx.json
 fi
+if want pmcpq; then
+# the reference's own PlotQA shape (bench.py --workload plotqa-real: B 80, V 44, T 124, F_v 1024): SQ pass + fabric traffic
+PQ="--workload plotqa-real"
+rm -rf /tmp/r1 /tmp/r3 /tmp/r4
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d /tmp/r1 -- $PB $PQ --launch-log /tmp/logr1.json > /tmp/r1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/r3 -- $PB $PQ --launch-log /tmp/logr3.json > /tmp/r3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/r4 -- $PB $PQ --launch-log /tmp/logr4.json > /tmp/r4.log 2>&1
+python3 $R/tools/pmc_sites.py /tmp/logr1.json $O/${tag}_pmc_sites_plotqa_real.json $(cc /tmp/r1) $(cc /tmp/r3) $(cc /tmp/r4) > $O/${tag}_pmc_sites_plotqa_real.txt 2>&1
+cp $O/${tag}_pmc_sites_plotqa_real.json $R/profiles/${tag}_pmc_sites_plotqa_real.json
+fi
 if want stats; then
 # kernel stats + timeline of the bench workload
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- $BENCH --steps 10 --warmup 3 > /tmp/ks.log 2>&1
@@ -46,6 +56,9 @@ cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/${tag}_rocprof_kernel_
 python3 $R/tools/trace_timeline.py $(find /tmp/ks -name "*kernel_trace.csv" | head -1) > $O/${tag}_step_timeline.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kl -- $BENCH --steps 10 --warmup 3 $LC > /tmp/kl.log 2>&1
 cp $(find /tmp/kl -name "*kernel_stats.csv" | head -1) $O/${tag}_longctx_kernel_stats.csv
+rm -rf /tmp/kp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp -- $BENCH --steps 10 --warmup 3 --workload plotqa-real > /tmp/kp.log 2>&1
+cp $(find /tmp/kp -name "*kernel_stats.csv" | head -1) $O/${tag}_plotqa_real_kernel_stats.csv
 fi
 cd $R
 F="RCCL\|HIP ver\|ROCm ver\|Hostname\|Librccl\|amdgpu.ids\|socket.cpp"
@@ -57,7 +70,6 @@ CRCT_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 10 --warmup 3 --batch 40
 python tools/lab/wgrad_fp8_lab.py 2>&1 | grep -v "$F" > $O/${tag}_wgrad_fp8_lab.txt
 python tools/lab/fp8_draws.py 2>&1 | grep -v "$F" > $O/${tag}_fp8_parity_draws.txt
 ./tools/lab/tr8_probe.bin > $O/${tag}_tr8_probe.txt 2>&1
-python tools/coldstart_lab.py 2>&1 | grep -v "$F" > $O/${tag}_coldstart_lab.txt
 fi
 if want bench; then
 python bench.py --steps 20 --warmup 5 2> $O/${tag}_bench_n1.err | grep '^{' > $O/${tag}_bench_n1.json
@@ -72,7 +84,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --dtype
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange 2> $O/${tag}_bench_n1_forced_exchange.err | grep '^{' > $O/${tag}_bench_n1_forced_exchange.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --grad-dtype fp32 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp32.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --ghost-ranks 8 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_ghost8.json
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --ln-fold 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_ln_fold.json
-for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32 bench_n1_ghost8 bench_n1_ln_fold; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
+python bench.py --steps 20 --warmup 5 --workload plotqa-real 2> $O/${tag}_bench_n1_plotqa_real.err | grep '^{' > $O/${tag}_bench_n1_plotqa_real.json
+for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32 bench_n1_ghost8 bench_n1_plotqa_real; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
 fi
 head -45 $O/${tag}_pmc_sites.txt

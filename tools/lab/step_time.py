@@ -1,7 +1,5 @@
 """Time the training step (configs[1]) under lab switches that bench.py does not offer (timing only where noted):
-    python tools/lab/step_time.py [--no-fold] [--static-fold] [--steps N]
---static-fold: the gamma-folded weight shadow is NOT refreshed behind AdamW (stale after the first update: wrong numerics) -- prices the
-fold kernels' share of the step."""
+    python tools/lab/step_time.py [--lib tools/lab/libcrct_lab.so] [--steps N]"""
 import argparse
 import os
 import sys
@@ -19,8 +17,6 @@ from crct.step_adapter import forward as step_forward    # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--fold", action="store_true")
-    ap.add_argument("--static-fold", action="store_true")
     ap.add_argument("--lib", default="", help="another build of libcrct_hip.so (A/B builds under tools/lab/)")
     ap.add_argument("--bf16-grads", action="store_true", help="timing only: Linear weight gradients written as bf16 (CrctStepCfg.grads_bf16) and AdamW "
                     "reading the bf16 buffer for EVERY element (the small fp32-accumulated gradients are not in it: wrong numerics)")
@@ -37,7 +33,7 @@ def main():
         L.LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda", 0)
     cfg = CFG.vilbert_config(v_feature_size=2048)
-    params = CFG.default_params(device=dev, batch_size=a.batch, seed=0, ln_fold=a.fold)
+    params = CFG.default_params(device=dev, batch_size=a.batch, seed=0)
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False
@@ -45,8 +41,6 @@ def main():
     model.train()
     opt = get_optimizer(params, model)
     opt.overlap = True
-    if a.static_fold:
-        FusedAdamW._refold = lambda self, seg, stream, wgs: setattr(self, "_folds_kept", True)
     if a.bf16_grads:
         buf = torch.zeros(core.flat_grads.numel(), dtype=torch.bfloat16, device=dev)
         from crct.engine import StepEngine
@@ -97,7 +91,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time emb_late=%d bf16_grads=%s fold=%s static=%s lib=%s: %s ms" % (a.emb_late, a.bf16_grads, a.fold, a.static_fold, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time emb_late=%d bf16_grads=%s lib=%s: %s ms" % (a.emb_late, a.bf16_grads, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":

@@ -19,15 +19,13 @@ import re
 import sys
 from collections import defaultdict
 
-GEMM = re.compile(r"gemm_(pipe|splitk|group|ldr|group_ldr|f8|f8t|f8t_group|lnf)?_?kernel<")
+GEMM = re.compile(r"gemm_(pipe|splitk|group|ldr|group_ldr|f8|f8t|f8t_group)?_?kernel<")
 
 
 def kind_of_name(name):
     m = re.search(r"gemm_(pipe|splitk|group|ldr|group_ldr)_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
     if m:
         return "wgrad" if m.group(6) == "true" else ("dgrad" if m.group(7) == "true" else "fwd")
-    if "gemm_lnf_kernel" in name:
-        return "fwd"          # folded-LayerNorm consumer: forward GEMMs only
     m = re.search(r"gemm_kernel<(\d+), (\d+), (true|false), (true|false)>", name)
     if m:
         return "wgrad" if m.group(3) == "true" else ("dgrad" if m.group(4) == "true" else "fwd")
