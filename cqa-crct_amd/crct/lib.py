@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
                 ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
                 ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp),
                 ("fp8", c_i32), ("scale_a", vp), ("scale_b", vp), ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("ld_q", c_i64),
-                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp), ("xcd_mask", c_i32)]
+                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp)]
 
 
 class LaunchRec(C.Structure):

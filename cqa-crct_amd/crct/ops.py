@@ -32,7 +32,7 @@ def _drop(p, site):
 
 def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
                preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
-               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0, xcd_mask=0):
+               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0):
     _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
@@ -49,7 +49,6 @@ def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=Non
     g.seed = seed
     g.rowsum_out = L.ptr(rowsum_out)
     g.site = int(model_site)
-    g.xcd_mask = int(xcd_mask)
     if split_k and split_k > 1:       # K-partitioned launch: slab space + ticket words (zero before the first use) per device
         ws, cnt = _splitk_space(A.device, M, N, split_k)
         g.split_k, g.splitk_ws, g.splitk_cnt = int(split_k), L.ptr(ws), L.ptr(cnt)

@@ -227,17 +227,9 @@ __device__ __forceinline__ int lab_bits(int dbg) { return dbg; }
 __device__ __forceinline__ constexpr int lab_bits(int) { return 0; }      // no environment variable can make a production kernel skip work
 #endif
 
-// XCD mask (CrctGemmArgs.xcd_mask, lab: tools/lab/xcd_partition_lab.py): bits 8.. of `gn` hold the set of XCD labels the launch may use
-// (0 = all eight).  The grid still deals blocks over all 8 labels; a block whose label is outside the set returns at once, the others
-// renumber themselves 0 .. k - 1 and share the tile grid as k rectangles.
 __device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int& tn) {
-  int x = bid & 7;
-  const int j = bid >> 3, mask = t.gn >> 8, gn = t.gn & 0xff;
-  if (mask) {
-    if (!((mask >> x) & 1)) return false;
-    x = __builtin_popcount(mask & ((1 << x) - 1));
-  }
-  const int m_lo = (x / gn) * t.rm, n_lo = (x % gn) * t.rn;
+  const int x = bid & 7, j = bid >> 3;
+  const int m_lo = (x / t.gn) * t.rm, n_lo = (x % t.gn) * t.rn;
   const int hm = min(t.rm, t.tiles_m - m_lo), hn = min(t.rn, t.tiles_n - n_lo);
   if (hm <= 0 || hn <= 0 || j >= hm * hn) return false;
   tm = m_lo + j / hn;
@@ -245,25 +237,20 @@ __device__ __forceinline__ bool map_tile(const TileMap& t, int bid, int& tm, int
   return true;
 }
 
-inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid, int xcd_mask = 0) {
+inline TileMap make_tile_map(int M, int N, int BM, int BN, int* grid) {
   TileMap t;
   t.tiles_m = (M + BM - 1) / BM; t.tiles_n = (N + BN - 1) / BN;
-  xcd_mask &= 0xff;
-  if (xcd_mask == 0xff) xcd_mask = 0;
-  const int nx = xcd_mask ? __builtin_popcount((unsigned)xcd_mask) : 8;      // XCDs the launch may use
   long best = -1;
   int bgm = 1;
-  for (int gm = 1; gm <= nx; ++gm) {
-    if (nx % gm) continue;
-    const int gn = nx / gm;
+  for (int gm = 1; gm <= 8; gm *= 2) {
+    const int gn = 8 / gm;
     const int rm = (t.tiles_m + gm - 1) / gm, rn = (t.tiles_n + gn - 1) / gn;
     // panel rows held per XCD, plus a penalty for padded (idle) blocks
-    const long cost = (long)rm * BM + (long)rn * BN + 4L * ((long)rm * rn * nx - (long)t.tiles_m * t.tiles_n) * 16;
+    const long cost = (long)rm * BM + (long)rn * BN + 4L * ((long)rm * rn * 8 - (long)t.tiles_m * t.tiles_n) * 16;
     if (best < 0 || cost < best) { best = cost; bgm = gm; }
   }
-  const int gn = nx / bgm;
-  t.rm = (t.tiles_m + bgm - 1) / bgm; t.rn = (t.tiles_n + gn - 1) / gn;
-  t.gn = gn | (xcd_mask << 8);
+  t.gn = 8 / bgm;
+  t.rm = (t.tiles_m + bgm - 1) / bgm; t.rn = (t.tiles_n + t.gn - 1) / t.gn;
   *grid = 8 * t.rm * t.rn;
 #ifdef CRCT_GEMM_LAB   // timing ablations exist in the -DCRCT_GEMM_LAB build of tools/gemm_lab only
   static const int dbg = getenv("CRCT_GEMM_DBG") ? atoi(getenv("CRCT_GEMM_DBG")) : 0;
@@ -1340,7 +1327,7 @@ template <int TM, int TN, int WM, int WN, int NS>
 hipError_t launch_f8(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles, g.xcd_mask);
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_F8(BF8_, MX_)                                                                                          \
@@ -1548,7 +1535,7 @@ template <int TM, int TN, int WM, int WN, int NS>
 hipError_t launch_f8t(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles, g.xcd_mask);
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * 128;
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_F8T(MX_)                                                                                               \
@@ -1690,7 +1677,7 @@ hipError_t launch_group(const CrctGemmArgs* gs, int n, hipStream_t s) {
     const CrctGemmArgs& g = gs[i];
     ga.tile_begin[i] = total;
     int grid = 0;
-    ga.map[i] = make_tile_map(g.M, g.N, BM, BN, &grid, gs[0].xcd_mask);
+    ga.map[i] = make_tile_map(g.M, g.N, BM, BN, &grid);
     total += grid;
     ga.p[i] = g;
   }
@@ -1729,7 +1716,7 @@ hipError_t launch_group_ldr(const CrctGemmArgs* gs, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     ga.tile_begin[i] = total;
     int grid = 0;
-    ga.map[i] = make_tile_map(gs[i].M, gs[i].N, BM, BN, &grid, gs[0].xcd_mask);
+    ga.map[i] = make_tile_map(gs[i].M, gs[i].N, BM, BN, &grid);
     ga.map[i].dbg = 0;
     total += grid;
     ga.p[i] = gs[i];
@@ -1776,7 +1763,7 @@ hipError_t launch_group_f8t(const CrctGemmArgs* gs, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     ga.tile_begin[i] = total;
     int grid = 0;
-    ga.map[i] = make_tile_map(gs[i].M, gs[i].N, BM, BN, &grid, gs[0].xcd_mask);
+    ga.map[i] = make_tile_map(gs[i].M, gs[i].N, BM, BN, &grid);
     ga.map[i].dbg = 0;
     total += grid;
     ga.p[i] = gs[i];
@@ -1807,7 +1794,7 @@ template <int TM, int TN, int WM, int WN, int NS>
 hipError_t launch_splitk(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles, g.xcd_mask);
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_SK(TB_)                                                                                                \
@@ -1832,7 +1819,7 @@ template <int TM, int TN, int WM, int WN, int NS, int PM = 0>
 hipError_t launch_pipe(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles, g.xcd_mask);
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_PIPE(TA_, TB_)                                                                                         \
@@ -1858,7 +1845,7 @@ template <int TM, int TN, int WM, int WN, int NS, int NL, int PIPE = 0>
 hipError_t launch_ldr(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles, g.xcd_mask);
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
   hipError_t e = hipSuccess;
 #define CRCT_LAUNCH_LDR(TA_, TB_)                                                                                          \
@@ -1895,7 +1882,7 @@ template <int TM, int TN>
 hipError_t launch_cfg(const CrctGemmArgs& g, hipStream_t s) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int tiles = 0;
-  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles, g.xcd_mask);
+  const TileMap tmap = make_tile_map(g.M, g.N, BM, BN, &tiles);
   const size_t lds = (size_t)(BM + BN) * BK * 2;
   if (!g.ta && !g.tb) launch_kernel(gemm_kernel<TM, TN, false, false>, dim3(tiles), dim3(256), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);
   else if (!g.ta && g.tb) launch_kernel(gemm_kernel<TM, TN, false, true>, dim3(tiles), dim3(256), lds, s, GEMM_HOT_ARGS(g, tmap) g, tmap);

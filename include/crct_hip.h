@@ -78,11 +78,6 @@ typedef struct CrctGemmArgs {
    * stream-ordered.  0 / 1 = off.  Not with ta (weight gradients), rowsum_out or fp8. */
   int32_t split_k;
   float* splitk_ws; uint32_t* splitk_cnt;
-  /* XCD placement (round 6 experiment, profiles/r6_xcd_partition_lab.txt): a set of XCD labels (bit x = workgroups with blockIdx % 8 == x;
-   * 0 or 0xff = all eight) the launch's tiles are confined to.  The grid is still dealt over all eight labels -- workgroups outside the
-   * set return at once -- so that concurrent launches on other streams can be given the other XCDs (their L2s and CUs).  Placement only:
-   * results do not depend on it.  LDS-DMA kernels (single, split-K and grouped launches; a grouped launch takes the first problem's set). */
-  int32_t xcd_mask;
 } CrctGemmArgs;
 
 /* GEMM sites of the step.  The FFN group of BASELINE.md section 4 ("fraction of the FFN-GEMM roofline") = the four *_FFN_* sites. */

@@ -187,30 +187,6 @@ def test_gemm_split_k_under_uneven_load():
     assert bad == 0
 
 
-def test_gemm_xcd_mask_is_placement_only(gemm_path):
-    """CrctGemmArgs.xcd_mask confines a launch's tiles to a set of XCD labels (workgroups outside it return at once): every tile is
-    still computed once, by the same code -- forward, data gradient, split-K, weight gradient and a grouped launch give the same
-    bits for every mask."""
-    if gemm_path != "pipelined":
-        pytest.skip("XCD placement exists in the LDS-DMA kernels")
-    M, N, K = 1600, 768, 3072
-    A, B, Bt = bf(rand(M, K, seed=1)), bf(rand(N, K, seed=2)), bf(rand(K, N, seed=3))
-    bias = rand(N, seed=4)
-    dy, x = bf(rand(M, N, seed=5)), bf(rand(M, K, seed=6))
-    base = dict(fwd=ops.gemm(A, B, M, N, K, bias=bias, act="gelu"), dgrad=ops.gemm(A, Bt, M, N, K, tb=True), sk=ops.gemm(A, B, M, N, K, bias=bias, split_k=3),
-                wgrad=ops.gemm(dy, x, N, K, M, ta=True, tb=True, out_f32=True))
-    gr = [dict(A=dy, B=x, M=N, N=K, K=M, ta=True, tb=True, out_f32=True), dict(A=dy, B=dy, M=N, N=N, K=M, ta=True, tb=True, out_f32=True)]
-    base_g = ops.gemm_grouped([dict(p) for p in gr])
-    for mask in (0b00000111, 0b10000000, 0b01110000, 0b00101101, 0xff):
-        assert torch.equal(ops.gemm(A, B, M, N, K, bias=bias, act="gelu", xcd_mask=mask), base["fwd"]), mask
-        assert torch.equal(ops.gemm(A, Bt, M, N, K, tb=True, xcd_mask=mask), base["dgrad"]), mask
-        assert torch.equal(ops.gemm(A, B, M, N, K, bias=bias, split_k=3, xcd_mask=mask), base["sk"]), mask
-        assert torch.equal(ops.gemm(dy, x, N, K, M, ta=True, tb=True, out_f32=True, xcd_mask=mask), base["wgrad"]), mask
-        for a, b in zip(ops.gemm_grouped([dict(p, xcd_mask=mask) for p in gr]), base_g):
-            assert torch.equal(a, b), mask
-    assert float(base["fwd"].float().abs().max()) > 0
-
-
 def test_gemm_strided_rows():
     # CLS-row gather: A rows are hidden_states[:, 0] with row stride T*H
     B, T, H, N = 80, 20, 768, 1024

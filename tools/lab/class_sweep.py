@@ -2,7 +2,7 @@
 (--wgrad-cfg) for one workload, every variant a fresh bench.py process on the same box; the first and last rows are the
 unmodified step (box drift).  Usage on the GPU box:
 
-    python tools/lab/class_sweep.py --workload plotqa-real "L.w=50" "L.w=9" "wgrad=48" "L.w=50,L.n=15"
+    python tools/lab/class_sweep.py --workload plotqa-real "L.w=50" "L.w=9" "wgrad=48" "L.w=50,L.n=15" "s:t.ffn_up:fwd:50"
 """
 import argparse
 import json
@@ -16,7 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 def run(workload, variant, steps, extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup", "6", "--no-cpu-baseline",
            "--no-h2d-leg", "--sustained-s", "0", "--profile-steps", "0"] + extra
-    cls = [v for v in variant.split(",") if v and not v.startswith("wgrad=") and not v.startswith("tw=")]
+    cls = [v for v in variant.split(",") if v and not v.startswith(("wgrad=", "tw=", "s:"))]
+    sites = ["%s:%s:-1:%s:0" % tuple(v.split(":")[1:4]) for v in variant.split(",") if v.startswith("s:")]      # s:<site>:<fwd|dgrad>:<cfg>
+    if sites:
+        cmd += ["--site-policy", ",".join(sites)]
     for v in variant.split(","):
         if v.startswith("wgrad="):
             cmd += ["--wgrad-cfg", v.split("=")[1]]
