@@ -20,6 +20,7 @@ struct AttnArgs {
   uint8_t* ctx_q; const float* ctx_qscale; float* ctx_qamax;
   uint8_t* dq_q; uint8_t* dk_q; uint8_t* dv_q;
   const float* dq_qscale; float* dq_qamax; const float* dkv_qscale; float* dkv_qamax;
+  int keep_cache;      // attention_long.hip backward: the dropout bits of phase A are kept in LDS for phase B (set by its launcher)
   int dbg;      // ablation bits, read only by -DCRCT_ATTN_LAB builds (tools/attn_lab); always 0 in the shipped library
 };
 

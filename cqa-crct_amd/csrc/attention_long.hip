@@ -107,6 +107,8 @@ inline size_t fwd_lds(int NK, int ND) { const int NKP = (NK + 1) & ~1; return (s
 inline size_t bwd_lds(int NQ, int NK, int ND, int NW) {
   return (size_t)32 * (NQ + NK) * (32 * ND + 16) + 256 * NQ + 64 * NK + (size_t)NW * 16 * SCR_STB;
 }
+// + the dropout bits of the whole score matrix, one byte per lane and tile pair (phase A writes, phase B reads): where it fits
+inline size_t keep_cache_bytes(int NQ, int NK) { return (size_t)64 * NQ * NK; }
 
 template <int ND, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_long(ATTN_HOT_PARAMS) {
@@ -222,6 +224,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   float4* stats = reinterpret_cast<float4*>(Vs + 16 * NK * STB);      // per query: m, 1 / l, delta
   float* kbias = reinterpret_cast<float*>(stats + 16 * NQ);
   char* scr = reinterpret_cast<char*>(kbias + 16 * NK) + wv * 16 * SCR_STB;
+  // dropout bits of tile pair (it, jt) as phase A's lanes hold them -- the layout phase B needs them in (lane = query 16 it + n, keys
+  // 16 jt + 4 g ..): one Philox call per lane and tile pair instead of two (v_mul_hi / v_mul_lo are quarter-rate: ~900 cycles a call,
+  // the largest single cost of this kernel with dropout on)
+  uint8_t* keepc = reinterpret_cast<uint8_t*>(kbias + 16 * NK) + NW * 16 * SCR_STB;
+  const bool cached = a.keep_cache != 0;
   load_image<ND>(Qs, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, 16 * NQ, tid, 64 * NW);
   load_image<ND>(Os, a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, 16 * NQ, tid, 64 * NW);
   load_image<ND>(Ks, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, 16 * NK, tid, 64 * NW);
@@ -257,6 +264,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
           const float alpha = __builtin_amdgcn_exp2f(m - mn);
           const uint32_t nib = keep_nibble(a, bh, i, 16 * jt + 4 * g, Tkp);
           w |= nib << (4 * ji);
+          if (cached) keepc[(it * NK + jt) * 64 + lane] = (uint8_t)nib;
           float ps = 0.f, pd = 0.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
         gp = mma16(vf[ks], frag_rows(Os, STB, 16 * it, 16 * ks, lane), gp);
       }
       const float4 st = stats[i];
-      const uint32_t nib = keep_nibble(a, bh, i, 16 * jt + 4 * g, Tkp);
+      const uint32_t nib = cached ? keepc[(it * NK + jt) * 64 + lane] : keep_nibble(a, bh, i, 16 * jt + 4 * g, Tkp);
       f4_t pdv, dsv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -382,10 +390,19 @@ hipError_t launch_nw(const AttnArgs& a, size_t lds, hipStream_t s) {
 // waves per (batch, head): 8 when a phase has at least 8 tiles to hand out, else 4
 inline int waves_for(bool bwd, int NQ, int NK) { return (bwd ? (NQ > NK ? NQ : NK) : NQ) >= 8 ? 8 : 4; }
 template <bool BWD, int ND>
-hipError_t launch_d(const AttnArgs& a, hipStream_t s) {
+hipError_t launch_d(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
   const int NQ = (a.Tq + 15) >> 4, NK = (a.Tk + 15) >> 4;
-  if (waves_for(BWD, NQ, NK) == 8) return launch_nw<BWD, ND, 8>(a, BWD ? bwd_lds(NQ, NK, ND, 8) : fwd_lds(NK, ND), s);
-  return launch_nw<BWD, ND, 4>(a, BWD ? bwd_lds(NQ, NK, ND, 4) : fwd_lds(NK, ND), s);
+  const int NW = waves_for(BWD, NQ, NK);
+  size_t lds = BWD ? bwd_lds(NQ, NK, ND, NW) : fwd_lds(NK, ND);
+  a.keep_cache = 0;
+  // ... where it does not lower the number of workgroups a CU's 160 KB hold
+  if (BWD && a.thr && lds + keep_cache_bytes(NQ, NK) <= (size_t)LDS_CAP && LDS_CAP / (lds + keep_cache_bytes(NQ, NK)) == LDS_CAP / lds) {
+    a.keep_cache = 1;
+    lds += keep_cache_bytes(NQ, NK);
+  }
+  if (NW == 8) return launch_nw<BWD, ND, 8>(a, lds, s);
+  return launch_nw<BWD, ND, 4>(a, lds, s);
 }
 template <bool BWD>
 hipError_t launch(const AttnArgs& a, hipStream_t s) {

@@ -1936,9 +1936,12 @@ constexpr int CLS_COUNT = MB_COUNT * CLS_PER_BUCKET;
 // 7.31 - 7.33 ms at configs[1], 11.74 -> 11.68 long context, forced exchange 8.04 -> 7.87 (profiles/r4_class_resweep.txt)
 static int g_class_table[CLS_COUNT] = {15, 15, 15,      // S: text rows of configs[1] (and, below, every narrow GEMM of text width)
                                        15, 15, 4,       // M: visual rows of configs[1] (nl: 128x128, 3 stages: 7.61 -> 7.56 ms)
-                                       15, 50, 50};     // L: long-context visual rows: 256x128 tiles with loader waves for the narrow outputs
+                                       9, 50, 50};      // L: long-context visual rows: 256x128 tiles with loader waves for the narrow outputs
                                                         //    (in-step sweep, profiles/r4_longctx_class_sweep.txt: 12.11 -> 12.04 each, 11.95 -> 11.79 ms
-                                                        //    together with the text-width rule below; every other entry measured neutral or worse)
+                                                        //    together with the text-width rule below; every other entry measured neutral or worse).
+                                                        //    Round 6: wide outputs 15 -> 9 (128x128, 8 waves, 2 stages) for the 9 920 text rows of the
+                                                        //    reference's PlotQA shape (B 80 x 124 tokens: FFN-up / QKV forward, FFN-down data gradient):
+                                                        //    19.12 -> 18.69 ms per step there, 11.57 -> 11.57 at configs[3] (profiles/r6_plotqa_class_sweep.txt)
 extern "C" int crct_gemm_class_config(int cls, int cfg) {
   if (cls < 0 || cls >= CLS_COUNT) return -1;
   const int old = g_class_table[cls];
