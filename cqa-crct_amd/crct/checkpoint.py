@@ -110,12 +110,17 @@ def resume(model, optimizer, ckpt_path, params, iters_per_epoch, scheduler_cls=W
 
 
 def get_encoder(params, ckpt=None, config=None):
-    """evaluation.py:22-66 without the DDP wrap: build the encoder and load ``ckpt`` (either mode reads only the
-    model weights there)."""
+    """evaluation.py:22-66: build the encoder, load ``ckpt`` (either mode reads only the model weights there) and, in a
+    multi-rank evaluation (``params['ddp'] and params['world_size'] > 1``, :56-61), wrap it as the reference does -- with
+    ``FlatGradDDP`` in DistributedDataParallel's place (an initialised process group is the caller's, as there)."""
     from .model import VisualDialogEncoder
     enc = VisualDialogEncoder(params, config=config)
     if ckpt:
         load_model_weights(enc, ckpt)
+    if params.get("ddp") and int(params.get("world_size", 1)) > 1:
+        from .ddp import FlatGradDDP
+        dev = _device_of(enc)
+        enc = FlatGradDDP(enc, device_ids=[dev.index if getattr(dev, "index", None) is not None else 0], find_unused_parameters=True)
     return enc
 
 
