@@ -48,6 +48,12 @@ def main():
         ("ffn_dn fwd   [9920x768x3072]  bias+residual", lambda t: ops.gemm(h, w_dn, M, H, I, bias=b_dn, addend=x, out=y, tile=t), 2.0 * M * I * H),
         ("ffn_up dgrad [9920x768x3072]  tb, +addend", lambda t: ops.gemm(du, w_up, M, H, I, tb=True, addend=dl, out=dx, tile=t), 2.0 * M * I * H),
     ]
+    dy_up, dy_dn = bf(M, I, seed=7), bf(M, H, seed=8)
+    gw_up, gw_dn = torch.zeros(I, H, device=DEV), torch.zeros(H, I, device=DEV)
+    cases += [
+        ("ffn_up wgrad [3072x768x9920]  ta tb, fp32 out", lambda t: ops.gemm(dy_up, x, I, H, M, ta=True, tb=True, out=gw_up, out_f32=True, tile=t), 2.0 * M * I * H),
+        ("ffn_dn wgrad [768x3072x9920]  ta tb, fp32 out", lambda t: ops.gemm(dy_dn, h, H, I, M, ta=True, tb=True, out=gw_dn, out_f32=True, tile=t), 2.0 * M * I * H),
+    ]
     tiles = [int(t) for t in sys.argv[1:]] or [15, 9, 4, 50, 55, 48]
     print("%-52s" % "us per launch (fraction of 2.5 PF)" + "".join("%16s" % ("cfg %d" % t) for t in tiles))
     for name, fn, fl in cases:
