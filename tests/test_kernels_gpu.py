@@ -397,6 +397,30 @@ def test_attention_long_and_short_kernels_agree_under_dropout():
     assert rel_err(g1[2].float().sum(1), ctx.float().sum(1)) < 1e-2
 
 
+def test_attention_random_shapes_and_masks():
+    """Thirty seeded random shapes (1 <= Tq, Tk <= 256, head size 32 / 48 / 64, 1 - 6 heads, 1 - 3 batch rows) with random key masks
+    (at least one attended key per row; masked keys anywhere, not only at the end) through whichever MFMA path takes them, forward and
+    backward against fp32 PyTorch on the same bf16 operands."""
+    g = torch.Generator().manual_seed(2026)
+    for case in range(30):
+        B, heads = int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 7, (1,), generator=g))
+        Tq, Tk = int(torch.randint(1, 257, (1,), generator=g)), int(torch.randint(1, 257, (1,), generator=g))
+        d = (32, 48, 64)[int(torch.randint(0, 3, (1,), generator=g))]
+        Hh = heads * d
+        q, k, v = (bf((torch.randn(B, T, Hh, generator=g)).to(DEV)) for T in (Tq, Tk, Tk))
+        km = (torch.rand(B, Tk, generator=g) < 0.7).to(torch.uint8)
+        km[torch.arange(B), torch.randint(0, Tk, (B,), generator=g)] = 1
+        km = km.to(DEV)
+        ctx = ops.attention_fwd(q, k, v, km, heads, d)
+        qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+        ref = _attn_ref(qr, kr, vr, km, heads, d)
+        assert rel_err(ctx, ref.detach()) < 1e-2, (case, B, heads, Tq, Tk, d)
+        dctx = bf((torch.randn(B, Tq, Hh, generator=g)).to(DEV))
+        ref.backward(dctx.float())
+        for got, want, nm in zip(ops.attention_bwd(q, k, v, km, dctx, heads, d), (qr.grad, kr.grad, vr.grad), "qkv"):
+            assert rel_err(got, want) < 1.5e-2, (case, nm, B, heads, Tq, Tk, d)
+
+
 def test_attention_long_kernels_are_bit_reproducible_beside_other_work():
     """The long-sequence kernels have one owner and one summation order per output element (no atomics; the phases of the backward
     meet at workgroup barriers): 25 repetitions at the PlotQA lengths, with dropout, while GEMMs on another stream share the CUs,
