@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrct_hip.so")
 
 c_i32, c_i64, c_u32, c_u64, c_f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
-ATTN_MAX_LEN = 256           # CRCT_ATTN_MAX_LEN of include/crct_hip.h: longest query / key sequence of the attention kernels
+ATTN_MAX_LEN = 512           # CRCT_ATTN_MAX_LEN of include/crct_hip.h: longest query / key sequence of the attention kernels
 FP8_AMAX_LANES = 64          # CRCT_FP8_AMAX_LANES of include/crct_hip.h: fp32 words per amax value
 vp = C.c_void_p
 

@@ -1,6 +1,6 @@
 // MFMA attention for sequences beyond the 112 x 112 register-resident kernels of attention_mfma.hip: the reference's own PlotQA
 // shape (config/plotqa.json:5-6: 124 text tokens x 44 visual elements; options.py:27 defaults to 256 tokens), up to
-// CRCT_ATTN_MAX_LEN = 256 queries x 256 keys at head sizes 32 / 48 / 64.  Same math, same -10000 additive key mask, same
+// CRCT_ATTN_MAX_LEN = 512 queries x 512 keys (the text position table of config/vilbert.json) at head sizes 32 / 48 / 64.  Same math, same -10000 additive key mask, same
 // Philox element numbering (and therefore the same dropout masks) as attention.hip / attention_mfma.hip:
 //   P = softmax(q k^T / sqrt(d) + (1 - keymask) * -10000) ; ctx = dropout(P) v
 // Reference: BertSelfAttention.forward vilbert.py:392-412, BertImageSelfAttention :522-543, BertBiAttention :684-723.
@@ -14,7 +14,8 @@
 // computed transposed (S^T = K Q^T): a lane owns one query and four consecutive keys per tile, its probabilities are the B
 // operand of ctx^T = V^T P^T as they lie.
 //
-// Backward (nothing but q, k, v is kept from the forward): Q, dO, K, V as LDS images, then
+// Backward (nothing but q, k, v is kept from the forward): Q, dO, K, V as LDS images (beyond 256 x 256 x 64: K, V for phase A and Q, dO
+// in the same space for phase B, a wave's OWN tile straight from global memory), then
 //   phase A, a wave per QUERY tile: sweep 1 over the key tiles gives the row statistics -- m, 1 / l and
 //            delta_i = sum_j P_ij dP_ij, accumulated online like l -- and keeps the dropout bits of the tile row (4 bits per
 //            lane and key tile); sweep 2 recomputes S^T and dP^T per key tile, dS^T = P^T (dP^T - delta) and accumulates
@@ -101,11 +102,13 @@ __device__ __forceinline__ void wave_amax(float* dst, float am, int lane) {
   if (lane == 0) amax_update(dst, am);
 }
 
-// LDS bytes: forward = K, V images of NKP = NK rounded up to 2 key tiles + the key bias; backward = Q, dO, K, V images + row
-// statistics (16 B per query) + key bias + one transposition tile per wave
+// LDS bytes: forward = K, V images of NKP = NK rounded up to 2 key tiles + the key bias; backward = Q, dO, K, V images (or, SHARE, one
+// pair of images: K, V in phase A, Q, dO in phase B, in the same place) + row statistics (16 B per query) + key bias + one
+// transposition tile per wave
 inline size_t fwd_lds(int NK, int ND) { const int NKP = (NK + 1) & ~1; return (size_t)32 * NKP * (32 * ND + 16) + 64 * NKP; }
-inline size_t bwd_lds(int NQ, int NK, int ND, int NW) {
-  return (size_t)32 * (NQ + NK) * (32 * ND + 16) + 256 * NQ + 64 * NK + (size_t)NW * 16 * SCR_STB;
+inline size_t bwd_lds(int NQ, int NK, int ND, int NW, bool share) {
+  const int rows = share ? 2 * (NQ > NK ? NQ : NK) : 2 * (NQ + NK);      // image tiles of 16 rows
+  return (size_t)16 * rows * (32 * ND + 16) + 256 * NQ + 64 * NK + (size_t)NW * 16 * SCR_STB;
 }
 // + the dropout bits of the whole score matrix, one byte per lane and tile pair (phase A writes, phase B reads): where it fits
 inline size_t keep_cache_bytes(int NQ, int NK) { return (size_t)64 * NQ * NK; }
@@ -208,7 +211,10 @@ __device__ __forceinline__ void score_tiles(f4_t& s, f4_t& gp, const char* Ks, c
   for (int r = 0; r < 4; ++r) s[r] = fmaf(s[r], sc, kb[r]);
 }
 
-template <int ND, int NW>
+// SHARE = false: all four images resident (up to 256 x 256 x 64) -- every fragment out of LDS.  SHARE = true (beyond that, up to 512 x 512 x 64):
+// the images of the two phases share one space and a wave's OWN tile (q / dO in phase A, k / v in phase B) comes straight from global
+// memory; costs the PlotQA-shaped step 0.27 ms (18.95 against 18.68) where both fit, hence only where it must.
+template <int ND, int NW, bool SHARE>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   ATTN_HOT_UNPACK
   constexpr int STB = 32 * ND + 16, d = 16 * ND;
@@ -217,11 +223,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   const int NQ = (a.Tq + 15) >> 4, NK = (a.Tk + 15) >> 4;
   const long bh = blockIdx.x;
   const int b = (int)(bh / a.heads), h = (int)(bh % a.heads);
-  char* Qs = smem;
-  char* Os = Qs + 16 * NQ * STB;          // dO
-  char* Ks = Os + 16 * NQ * STB;
-  char* Vs = Ks + 16 * NK * STB;
-  float4* stats = reinterpret_cast<float4*>(Vs + 16 * NK * STB);      // per query: m, 1 / l, delta
+  // SHARE: phase A reads K, V from LDS (every wave sweeps all key tiles) and its own q / dO fragments from global memory; phase B reads
+  // Q, dO from LDS (every wave sweeps all query tiles) and its own k / v fragments from global memory; the images of the two phases
+  // share the space: 2 x max(Tq, Tk) rows instead of 2 x (Tq + Tk) -- 512 x 512 x 64 fits the 160 KB exactly
+  const int NX = NQ > NK ? NQ : NK;
+  char* Ks = smem;
+  char* Vs = Ks + 16 * (SHARE ? NX : NK) * STB;
+  char* Qs = SHARE ? Ks : Vs + 16 * NK * STB;
+  char* Os = SHARE ? Vs : Qs + 16 * NQ * STB;          // dO
+  float4* stats = reinterpret_cast<float4*>(SHARE ? Vs + 16 * NX * STB : Os + 16 * NQ * STB);      // per query: m, 1 / l, delta
   float* kbias = reinterpret_cast<float*>(stats + 16 * NQ);
   char* scr = reinterpret_cast<char*>(kbias + 16 * NK) + wv * 16 * SCR_STB;
   // dropout bits of tile pair (it, jt) as phase A's lanes hold them -- the layout phase B needs them in (lane = query 16 it + n, keys
@@ -229,10 +239,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   // the largest single cost of this kernel with dropout on)
   uint8_t* keepc = reinterpret_cast<uint8_t*>(kbias + 16 * NK) + NW * 16 * SCR_STB;
   const bool cached = a.keep_cache != 0;
-  load_image<ND>(Qs, a.q + (long)b * a.Tq * a.ldq + h * d, a.ldq, a.Tq, 16 * NQ, tid, 64 * NW);
-  load_image<ND>(Os, a.dctx + (long)b * a.Tq * a.ldo + h * d, a.ldo, a.Tq, 16 * NQ, tid, 64 * NW);
-  load_image<ND>(Ks, a.k + (long)b * a.Tk * a.ldk + h * d, a.ldk, a.Tk, 16 * NK, tid, 64 * NW);
-  load_image<ND>(Vs, a.v + (long)b * a.Tk * a.ldv + h * d, a.ldv, a.Tk, 16 * NK, tid, 64 * NW);
+  const bf16_t* qg = a.q + (long)b * a.Tq * a.ldq + h * d;
+  const bf16_t* og = a.dctx + (long)b * a.Tq * a.ldo + h * d;
+  const bf16_t* kg = a.k + (long)b * a.Tk * a.ldk + h * d;
+  const bf16_t* vg = a.v + (long)b * a.Tk * a.ldv + h * d;
+  if constexpr (!SHARE) {
+    load_image<ND>(Qs, qg, a.ldq, a.Tq, 16 * NQ, tid, 64 * NW);
+    load_image<ND>(Os, og, a.ldo, a.Tq, 16 * NQ, tid, 64 * NW);
+  }
+  load_image<ND>(Ks, kg, a.ldk, a.Tk, 16 * NK, tid, 64 * NW);
+  load_image<ND>(Vs, vg, a.ldv, a.Tk, 16 * NK, tid, 64 * NW);
   load_keybias(kbias, a.keymask + (long)b * a.Tk, a.Tk, 16 * NK, tid, 64 * NW);
   __syncthreads();
   const float sc = a.scale * LOG2E, ds = a.thr ? a.dscale : 1.0f;
@@ -244,8 +260,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
     s4_t qf[ND], of[ND];
 #pragma unroll
     for (int ks = 0; ks < ND; ++ks) {
-      qf[ks] = frag_rows(Qs, STB, 16 * it, 16 * ks, lane);
-      of[ks] = frag_rows(Os, STB, 16 * it, 16 * ks, lane);
+      if constexpr (SHARE) {
+        qf[ks] = frag_rows_global(qg, a.ldq, a.Tq, 16 * it, 16 * ks, lane);
+        of[ks] = frag_rows_global(og, a.ldo, a.Tq, 16 * it, 16 * ks, lane);
+      } else {
+        qf[ks] = frag_rows(Qs, STB, 16 * it, 16 * ks, lane);
+        of[ks] = frag_rows(Os, STB, 16 * it, 16 * ks, lane);
+      }
     }
     float m = -INFINITY, l = 0.f, dl = 0.f;
     uint32_t kw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};      // keep bits, 4 per key tile (up to 32 key tiles)
@@ -315,15 +336,25 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
     }
   }
   if (a.dq_q) wave_amax(a.dq_qamax, am_q, lane);
-  __syncthreads();                          // the statistics of every query tile are in LDS
+  __syncthreads();                          // the statistics of every query tile are in LDS; every wave is done with the K, V images
+  if constexpr (SHARE) {
+    load_image<ND>(Qs, qg, a.ldq, a.Tq, 16 * NQ, tid, 64 * NW);
+    load_image<ND>(Os, og, a.ldo, a.Tq, 16 * NQ, tid, 64 * NW);
+    __syncthreads();
+  }
   // ---------------------------------------------------------------- phase B: dv and dk of the wave's key tiles
   for (int jt = wv; jt < NK; jt += NW) {
     const int j = 16 * jt + n;
     s4_t kf[ND], vf[ND];
 #pragma unroll
     for (int ks = 0; ks < ND; ++ks) {
-      kf[ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
-      vf[ks] = frag_rows(Vs, STB, 16 * jt, 16 * ks, lane);
+      if constexpr (SHARE) {
+        kf[ks] = frag_rows_global(kg, a.ldk, a.Tk, 16 * jt, 16 * ks, lane);
+        vf[ks] = frag_rows_global(vg, a.ldv, a.Tk, 16 * jt, 16 * ks, lane);
+      } else {
+        kf[ks] = frag_rows(Ks, STB, 16 * jt, 16 * ks, lane);
+        vf[ks] = frag_rows(Vs, STB, 16 * jt, 16 * ks, lane);
+      }
     }
     const f4_t kb = *reinterpret_cast<const f4_t*>(kbias + 16 * jt + 4 * g);
     f4_t dv[ND], dk[ND];
@@ -374,9 +405,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   if (a.dv_q || a.dk_q) wave_amax(a.dkv_qamax, am_kv, lane);
 }
 
-template <bool BWD, int ND, int NW>
+template <bool BWD, int ND, int NW, bool SHARE>
 hipError_t launch_nw(const AttnArgs& a, size_t lds, hipStream_t s) {
-  auto kern = BWD ? attn_bwd_long<ND, NW> : attn_fwd_long<ND, NW>;
+  auto kern = BWD ? attn_bwd_long<ND, NW, SHARE> : attn_fwd_long<ND, NW>;
   static bool raised = false;             // first call is eager (outside any stream capture)
   if (lds > 64 * 1024 && !raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CAP);
@@ -392,20 +423,23 @@ hipError_t launch_nw(const AttnArgs& a, size_t lds, hipStream_t s) {
 // 3 of 8 waves busy in one of the two phases, and with thousands of (batch, head) pairs queued a CU is better filled by twice as many
 // 4-wave workgroups (wave-slot utilisation 0.82 - 0.90 against 0.47 - 0.64; in the step the two are within noise: 19.00 against 19.03 ms)
 inline int waves_for(bool bwd, int NQ, int NK) { return (bwd ? (NQ < NK ? NQ : NK) : NQ) >= 8 ? 8 : 4; }
+// backward: four resident images where they fit, the shared image pair beyond (bwd_share)
+inline bool bwd_share(int NQ, int NK, int ND, int NW) { return bwd_lds(NQ, NK, ND, NW, false) > (size_t)LDS_CAP; }
 template <bool BWD, int ND>
 hipError_t launch_d(const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in;
   const int NQ = (a.Tq + 15) >> 4, NK = (a.Tk + 15) >> 4;
   const int NW = waves_for(BWD, NQ, NK);
-  size_t lds = BWD ? bwd_lds(NQ, NK, ND, NW) : fwd_lds(NK, ND);
+  const bool share = BWD && bwd_share(NQ, NK, ND, NW);
+  size_t lds = BWD ? bwd_lds(NQ, NK, ND, NW, share) : fwd_lds(NK, ND);
   a.keep_cache = 0;
   // ... where it does not lower the number of workgroups a CU's 160 KB hold
   if (BWD && a.thr && lds + keep_cache_bytes(NQ, NK) <= (size_t)LDS_CAP && LDS_CAP / (lds + keep_cache_bytes(NQ, NK)) == LDS_CAP / lds) {
     a.keep_cache = 1;
     lds += keep_cache_bytes(NQ, NK);
   }
-  if (NW == 8) return launch_nw<BWD, ND, 8>(a, lds, s);
-  return launch_nw<BWD, ND, 4>(a, lds, s);
+  if (share) return NW == 8 ? launch_nw<BWD, ND, 8, true>(a, lds, s) : launch_nw<BWD, ND, 4, true>(a, lds, s);
+  return NW == 8 ? launch_nw<BWD, ND, 8, false>(a, lds, s) : launch_nw<BWD, ND, 4, false>(a, lds, s);
 }
 template <bool BWD>
 hipError_t launch(const AttnArgs& a, hipStream_t s) {
@@ -420,11 +454,12 @@ hipError_t launch(const AttnArgs& a, hipStream_t s) {
 }  // namespace
 
 // Both directions must fit (the forward of a shape the backward cannot take is of no use to the step): head size 32 / 48 / 64
-// and at most CRCT_ATTN_MAX_LEN queries and keys -- 256 x 256 x 64 needs 155 KB of the 160 KB for the backward's four images.
+// and at most CRCT_ATTN_MAX_LEN queries and keys -- 512 x 512 x 64: forward 146 KB for the K, V images, backward exactly the 160 KB
+// (two images + statistics + key bias + eight transposition tiles).
 bool crct_attention_long_ok(int Tq, int Tk, int d) {
   if (!(d == 32 || d == 48 || d == 64) || Tq < 1 || Tk < 1 || Tq > CRCT_ATTN_MAX_LEN || Tk > CRCT_ATTN_MAX_LEN) return false;
   const int NQ = (Tq + 15) >> 4, NK = (Tk + 15) >> 4, ND = d / 16;
-  return bwd_lds(NQ, NK, ND, waves_for(true, NQ, NK)) <= (size_t)LDS_CAP && fwd_lds(NK, ND) <= (size_t)LDS_CAP;
+  return bwd_lds(NQ, NK, ND, waves_for(true, NQ, NK), true) <= (size_t)LDS_CAP && fwd_lds(NK, ND) <= (size_t)LDS_CAP;
 }
 hipError_t crct_attention_long_fwd(const AttnArgs& a, hipStream_t s) { return launch<false>(a, s); }
 hipError_t crct_attention_long_bwd(const AttnArgs& a, hipStream_t s) { return launch<true>(a, s); }

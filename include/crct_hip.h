@@ -302,11 +302,12 @@ int crct_cast_runs_bf16_f32(const void* x, float* y, const int64_t* off, const i
  * Replaces vilbert.py:392-412 (text self), :522-543 (visual self), :684-701 / :704-723 (co-attn).
  * q [B][Tq][ldq], k/v [B][Tk][ldk] bf16 with head h at column h*d; keymask fp32/int-free: uint8 [B][Tk]
  * (1 = attend); ctx bf16 [B][Tq][ldo].
- * Lengths: Tq, Tk <= CRCT_ATTN_MAX_LEN (256: CRCT/options.py:27's default max_seq_len; config/plotqa.json:5-6 trains at 124 text
- * tokens x 44 visual elements) for head sizes 32 / 48 / 64 -- the three of config/vilbert.json; any other head size (d <= 64,
+ * Lengths: Tq, Tk <= CRCT_ATTN_MAX_LEN (512: the text position table of config/vilbert.json, i.e. every length the reference model can
+ * embed; CRCT/options.py:27's default max_seq_len is 256, config/plotqa.json:5-6 trains at 124 text tokens x 44 visual elements) for
+ * head sizes 32 / 48 / 64 -- the three of config/vilbert.json; any other head size (d <= 64,
  * d % 8 == 0) only up to 112 x 112.  Anything else is refused with an error, never truncated.
  */
-#define CRCT_ATTN_MAX_LEN 256
+#define CRCT_ATTN_MAX_LEN 512
 int crct_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx,
                        int B, int heads, int Tq, int Tk, int d,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,

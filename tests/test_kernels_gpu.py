@@ -335,9 +335,11 @@ def test_attention_fwd_bwd(B, heads, Tq, Tk, d, attn_path):
 
 
 # Beyond 112 queries / keys: attention_long.hip.  (124, 44) is the reference's own PlotQA shape (config/plotqa.json:5-6), 256 its
-# default max_seq_len (options.py:27) and this library's limit; ragged lengths around the 16-row tiles; padding keys in every batch row.
+# default max_seq_len (options.py:27), 512 its position table and this library's limit; ragged lengths around the 16-row tiles; padding
+# keys in every batch row.
 LONG_SHAPES = [(4, 16, 124, 124, 48), (4, 32, 124, 44, 32), (4, 32, 44, 124, 32), (2, 16, 256, 256, 64), (2, 16, 130, 200, 48),
-               (3, 4, 113, 17, 32), (2, 4, 17, 113, 64), (2, 8, 256, 256, 32), (2, 4, 241, 129, 48), (1, 2, 1, 200, 64)]
+               (3, 4, 113, 17, 32), (2, 4, 17, 113, 64), (2, 8, 256, 256, 32), (2, 4, 241, 129, 48), (1, 2, 1, 200, 64),
+               (1, 16, 512, 512, 64), (2, 8, 300, 512, 48), (1, 4, 512, 40, 32), (1, 3, 33, 497, 64)]
 
 
 @pytest.mark.parametrize("B,heads,Tq,Tk,d", LONG_SHAPES)
@@ -398,13 +400,13 @@ def test_attention_long_and_short_kernels_agree_under_dropout():
 
 
 def test_attention_random_shapes_and_masks():
-    """Thirty seeded random shapes (1 <= Tq, Tk <= 256, head size 32 / 48 / 64, 1 - 6 heads, 1 - 3 batch rows) with random key masks
+    """Thirty seeded random shapes (1 <= Tq, Tk <= 512, head size 32 / 48 / 64, 1 - 6 heads, 1 - 3 batch rows) with random key masks
     (at least one attended key per row; masked keys anywhere, not only at the end) through whichever MFMA path takes them, forward and
     backward against fp32 PyTorch on the same bf16 operands."""
     g = torch.Generator().manual_seed(2026)
     for case in range(30):
         B, heads = int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 7, (1,), generator=g))
-        Tq, Tk = int(torch.randint(1, 257, (1,), generator=g)), int(torch.randint(1, 257, (1,), generator=g))
+        Tq, Tk = int(torch.randint(1, 513, (1,), generator=g)), int(torch.randint(1, 513, (1,), generator=g))
         d = (32, 48, 64)[int(torch.randint(0, 3, (1,), generator=g))]
         Hh = heads * d
         q, k, v = (bf((torch.randn(B, T, Hh, generator=g)).to(DEV)) for T in (Tq, Tk, Tk))
@@ -427,7 +429,7 @@ def test_attention_long_kernels_are_bit_reproducible_beside_other_work():
     must reproduce the first result bit for bit -- forward, dq, dk, dv, both co-attention directions included."""
     side = torch.cuda.Stream()
     A, Bm = bf(rand(4096, 1024, seed=7)), bf(rand(1024, 1024, seed=8))
-    for B, heads, Tq, Tk, d in ((8, 16, 124, 124, 48), (8, 32, 124, 44, 32), (8, 32, 44, 124, 32), (2, 16, 256, 256, 64)):
+    for B, heads, Tq, Tk, d in ((8, 16, 124, 124, 48), (8, 32, 124, 44, 32), (8, 32, 44, 124, 32), (2, 16, 256, 256, 64), (1, 16, 512, 512, 64)):
         Hh = heads * d
         q, k, v = bf(rand(B, Tq, Hh, seed=1)), bf(rand(B, Tk, Hh, seed=2)), bf(rand(B, Tk, Hh, seed=3))
         dctx = bf(rand(B, Tq, Hh, seed=4))
@@ -451,8 +453,8 @@ def test_attention_long_kernels_are_bit_reproducible_beside_other_work():
 
 def test_attention_length_and_head_size_limits_are_errors():
     lib = L.load()
-    assert L.ATTN_MAX_LEN == 256
-    for Tq, Tk, d in ((257, 20, 64), (20, 257, 32), (120, 120, 40), (113, 20, 16)):
+    assert L.ATTN_MAX_LEN == 512
+    for Tq, Tk, d in ((513, 20, 64), (20, 513, 32), (120, 120, 40), (113, 20, 16)):
         q = bf(rand(1, Tq, 2 * d, seed=1))
         k = bf(rand(1, Tk, 2 * d, seed=2))
         km = torch.ones(1, Tk, dtype=torch.uint8, device=DEV)
