@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 LIB = os.path.join(ROOT, "tools", "lab", "libcrct_lab.so")
 
 
+SHAPE = []      # extra step_time.py arguments (--batch / --vis / --tokens): set from --shape
+
+
 def run(skip, reps, report=False, extra=None):
     env = dict(os.environ)
     env.pop("CRCT_LAB_SKIP", None)
@@ -21,7 +24,7 @@ def run(skip, reps, report=False, extra=None):
         env["CRCT_LAB_SKIP"] = skip
     if report:
         env["CRCT_LAB_REPORT"] = "1"
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "lab", "step_time.py"), "--lib", LIB, "--reps", str(reps)] + (["--steps", "4"] if report else [])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "lab", "step_time.py"), "--lib", LIB, "--reps", str(reps)] + SHAPE + (["--steps", "4"] if report else [])
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     m = re.search(r"step_time.*: ([0-9., ]+) ms", p.stdout)
     times = [float(x) for x in m.group(1).split(",")] if m else []
@@ -32,7 +35,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--set", default="classes", help="classes: one kernel class left out at a time; interference: what KIND of load the side work is")
+    ap.add_argument("--shape", default="", help="B,V,T of the step (default: configs[1] = 80,36,20); 80,44,124 = the reference's PlotQA shape")
     a = ap.parse_args()
+    if a.shape:
+        B, V, T = a.shape.split(",")
+        SHAPE.extend(["--batch", B, "--vis", V, "--tokens", T])
     _, err = run("", 1, report=True)
     streams = {}
     for line in err.splitlines():
@@ -62,8 +69,8 @@ def main():
         ("LayerNorm forward (both)", "ln_fwd_kernel"),
         ("attention backward (both)", "attn_bwd"),
         ("attention forward (both)", "attn_fwd"),
-        ("every GEMM of the text stream", "gemm_pipe@%d,gemm_kernel@%d" % (t, t)),
-        ("every GEMM of the visual stream", "gemm_pipe@%d,gemm_kernel@%d" % (v, v)),
+        ("every GEMM of the text stream", "gemm_pipe@%d,gemm_kernel@%d,gemm_ldr@%d" % (t, t, t)),
+        ("every GEMM of the visual stream", "gemm_pipe@%d,gemm_kernel@%d,gemm_ldr@%d" % (v, v, v)),
         ("everything on the visual stream", "*@%d" % v),
         ("everything on the text stream", "*@%d" % t),
         ("everything but the text stream", "*@%d,*@%d,*@%d,adamw_kernel" % (v, wt, wv)),
