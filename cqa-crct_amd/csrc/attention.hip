@@ -168,12 +168,6 @@ __device__ __forceinline__ void mm_tn(float* out, const float* P, int ldp, const
     }
 }
 
-__device__ __forceinline__ uint32_t philox_one(uint64_t seed, uint32_t site, uint64_t idx) {
-  const Philox4 p = philox4x32_10(seed, site, idx >> 2);
-  const uint32_t k = (uint32_t)idx & 3u;
-  return k == 0 ? p.x : (k == 1 ? p.y : (k == 2 ? p.z : p.w));
-}
-
 // 8-lane group reductions (3 butterfly steps instead of 6 for a whole wave)
 __device__ __forceinline__ float group8_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
@@ -195,7 +189,6 @@ __device__ __forceinline__ void softmax_rows_c(float* S, int ldS, const uint8_t*
                                                int tid, int mode) {
   constexpr int C = 4 * CQ;
   const int g = tid & 7;
-  const long Tkp = (Tk + 3) & ~3;
   for (int i = tid >> 3; i < ((Tq + 31) & ~31); i += 32) {      // whole groups stay converged for the shuffles
     const bool live = i < Tq;
     float* row = S + (live ? i : 0) * ldS;
@@ -219,11 +212,11 @@ __device__ __forceinline__ void softmax_rows_c(float* S, int ldS, const uint8_t*
       if (j >= ldS) continue;
       float p[4] = {v[4 * q] * inv, v[4 * q + 1] * inv, v[4 * q + 2] * inv, v[4 * q + 3] * inv};
       if (thr && j < Tk) {
-        const Philox4 r = philox4x32_10(seed, site, ((uint64_t)(bh * Tq + i) * (uint64_t)Tkp + (uint64_t)j) >> 2);
-        const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+        // this quad = keys j .. j + 3 = the keys of MFMA lane group (j >> 2) & 3 in key tile j >> 4: one half of call (pair j >> 5, group)
+        const uint32_t kb = attn_keep8(seed, site, bh, Tq, Tk, i, j >> 5, (j >> 2) & 3, thr) >> (((j >> 4) & 1) * 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const bool keep = u[c] >= thr;
+          const bool keep = (kb >> c) & 1u;
           p[c] = mode == 0 ? (keep ? p[c] * dscale : 0.f) : (keep ? p[c] : -p[c]);
         }
       }

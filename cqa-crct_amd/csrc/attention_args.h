@@ -24,6 +24,15 @@ struct AttnArgs {
   int dbg;      // ablation bits, read only by -DCRCT_ATTN_LAB builds (tools/attn_lab); always 0 in the shipped library
 };
 
+// Dropout bits of the attention probabilities, shared by the three implementations.  The MFMA kernels give a lane the keys 16 jt + 4 g .. + 3
+// of every key tile jt, so the 8 elements of one Philox call (philox_keep8) are numbered to suit THEM: call ((bh Tq + i) NP + P) 4 + g covers
+// query i, keys 32 P + 4 g + r (slices 0 - 3) and 32 P + 16 + 4 g + r (slices 4 - 7) -- the lane's keys of the key-tile pair P = jt / 2;
+// NP = ceil(Tk / 32).  Returns the 8 keep bits (bit 4 (jt & 1) + r: key 16 jt + 4 g + r).
+__device__ __forceinline__ uint32_t attn_keep8(uint64_t seed, uint32_t site, long bh, int Tq, int Tk, int i, int pair, int g, uint32_t thr) {
+  const uint64_t np = (uint64_t)((Tk + 31) >> 5);
+  return philox_keep8(seed, site, (((uint64_t)(bh * Tq + i)) * np + (uint64_t)pair) * 4u + (uint64_t)g, thr);
+}
+
 bool crct_attention_mfma_ok(int Tq, int Tk, int d);
 hipError_t crct_attention_mfma_fwd(const AttnArgs& a, hipStream_t s);
 hipError_t crct_attention_mfma_bwd(const AttnArgs& a, hipStream_t s);

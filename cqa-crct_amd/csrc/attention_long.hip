@@ -62,15 +62,12 @@ __device__ __forceinline__ void load_image(char* img, const bf16_t* __restrict__
 __device__ __forceinline__ void load_keybias(float* kb, const uint8_t* km, int Tk, int n, int tid, int nthr) {
   for (int j = tid; j < n; j += nthr) kb[j] = j < Tk ? (km[j] ? 0.f : -10000.f * LOG2E) : -INFINITY;
 }
-// the lane's 4 keep bits of key tile jt for query i (bit r: key 16 jt + 4 g + r is kept): one Philox call, the element numbering
-// of attention.hip (softmax_rows_c) and attention_mfma.hip (softmax_cols)
-__device__ __forceinline__ uint32_t keep_nibble(const AttnArgs& a, long bh, int i, int j0, long Tkp) {
-  uint32_t nib = 0xfu;
-  if (a.thr && j0 < a.Tk && i < a.Tq) {
-    const Philox4 rnd = philox4x32_10(a.seed, a.site, ((uint64_t)(bh * a.Tq + i) * (uint64_t)Tkp + (uint64_t)j0) >> 2);
-    nib = (rnd.x >= a.thr ? 1u : 0u) | (rnd.y >= a.thr ? 2u : 0u) | (rnd.z >= a.thr ? 4u : 0u) | (rnd.w >= a.thr ? 8u : 0u);
-  }
-  return nib;
+// the lane's 8 keep bits of the key-tile PAIR jp for query i (bit 4 u + r: key 16 (2 jp + u) + 4 g + r is kept): one Philox call, the
+// numbering all three implementations share (attention_args.h, attn_keep8)
+__device__ __forceinline__ uint32_t keep_byte(const AttnArgs& a, long bh, int i, int jp, int g) {
+  uint32_t kb = 0xffu;
+  if (a.thr && 32 * jp + 4 * g < a.Tk && i < a.Tq) kb = attn_keep8(a.seed, a.site, bh, a.Tq, a.Tk, i, jp, g, a.thr);
+  return kb;
 }
 // Result tile t (lane: column `row` of the transposed product, its rows 4 g + r = columns col0 .. col0 + 3 of the row-major matrix)
 // -> 8 bytes of bf16 to global memory, optionally with the fp8 copy of the bf16-rounded values (E4M3: OCP e4m3, else e5m2;
@@ -130,7 +127,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long(ATTN_HOT_PARAMS) {
   load_keybias(kbias, a.keymask + (long)b * a.Tk, a.Tk, 16 * NKP, tid, 64 * NW);
   __syncthreads();
   const float sc = a.scale * LOG2E, ds = a.thr ? a.dscale : 1.0f;
-  const long Tkp = (a.Tk + 3) & ~3;
   const bf16_t* qg = a.q + (long)b * a.Tq * a.ldq + h * d;
   float am = 0.f;
   for (int it = wv; it < NQ; it += NW) {
@@ -162,9 +158,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long(ATTN_HOT_PARAMS) {
       const float alpha = __builtin_amdgcn_exp2f(m - mn);
       float ps = 0.f;
       s4_t pb[2];
+      const uint32_t kb8 = keep_byte(a, bh, i, jt >> 1, g);          // jt is even: one call for the pair
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const uint32_t nib = keep_nibble(a, bh, i, 16 * (jt + u) + 4 * g, Tkp);
+        const uint32_t nib = (kb8 >> (4 * u)) & 0xfu;
         f4_t p;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -252,7 +249,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   load_keybias(kbias, a.keymask + (long)b * a.Tk, a.Tk, 16 * NK, tid, 64 * NW);
   __syncthreads();
   const float sc = a.scale * LOG2E, ds = a.thr ? a.dscale : 1.0f;
-  const long Tkp = (a.Tk + 3) & ~3;
   float am_q = 0.f, am_kv = 0.f;
   // ---------------------------------------------------------------- phase A: statistics and dq of the wave's query tiles
   for (int it = wv; it < NQ; it += NW) {
@@ -273,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
 #pragma unroll
     for (int jo = 0; jo < 4; ++jo) {
       if (8 * jo < NK) {
-        uint32_t w = 0u;
+        uint32_t w = 0u, kb8 = 0xffu;
         const int je = min(8, NK - 8 * jo);
 #pragma unroll 1
         for (int ji = 0; ji < je; ++ji) {
@@ -283,7 +279,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
           const float cm = xmax2(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
           const float mn = fmaxf(m, cm);
           const float alpha = __builtin_amdgcn_exp2f(m - mn);
-          const uint32_t nib = keep_nibble(a, bh, i, 16 * jt + 4 * g, Tkp);
+          if (!(ji & 1)) kb8 = keep_byte(a, bh, i, jt >> 1, g);      // jt = 8 jo + ji: even ji = first tile of a pair
+          const uint32_t nib = (kb8 >> (4 * (ji & 1))) & 0xfu;
           w |= nib << (4 * ji);
           if (cached) keepc[(it * NK + jt) * 64 + lane] = (uint8_t)nib;
           float ps = 0.f, pd = 0.f;
@@ -370,7 +367,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
         gp = mma16(vf[ks], frag_rows(Os, STB, 16 * it, 16 * ks, lane), gp);
       }
       const float4 st = stats[i];
-      const uint32_t nib = cached ? keepc[(it * NK + jt) * 64 + lane] : keep_nibble(a, bh, i, 16 * jt + 4 * g, Tkp);
+      const uint32_t nib = cached ? keepc[(it * NK + jt) * 64 + lane] : (keep_byte(a, bh, i, jt >> 1, g) >> (4 * (jt & 1))) & 0xfu;
       f4_t pdv, dsv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -160,18 +160,17 @@ __device__ __forceinline__ void softmax_cols(f4_t (&s)[NK], uint32_t& keep, uint
     }
   const float inv = 1.0f / xsum2(sum);
   keep = 0xffffffffu;
-  const long Tkp = (Tk + 3) & ~3;
 #pragma unroll
   for (int jt = 0; jt < NK; ++jt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[jt][r] *= inv;
-    const int j0 = 16 * jt + 4 * g;
-    if (a.thr && j0 < Tk && i < Tq) {
-      const Philox4 rnd = philox4x32_10(a.seed, a.site, ((uint64_t)(bh * Tq + i) * (uint64_t)Tkp + (uint64_t)j0) >> 2);
-      const uint32_t u[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+  }
+  // one Philox call per key-tile PAIR: its 8 slices are this lane's keys 16 jt + 4 g + r of the two tiles (attention_args.h, attn_keep8)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (u[r] < a.thr) keep &= ~(1u << (4 * jt + r));
+  for (int jp = 0; jp < (NK + 1) / 2; ++jp) {
+    if (a.thr && 32 * jp + 4 * g < Tk && i < Tq) {
+      const uint32_t kb = attn_keep8(a.seed, a.site, bh, Tq, Tk, i, jp, g, a.thr);
+      keep = (keep & ~(0xffu << (8 * jp))) | (kb << (8 * jp));
     }
   }
 }

@@ -58,20 +58,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
-// ------------------------------------------------------------------ Philox4x32-10 (counter based RNG)
+// ------------------------------------------------------------------ Philox4x32 (counter based RNG), 7 rounds
 // Dropout masks are never stored: forward and backward regenerate them from
-// (seed, site, element index).  One call yields 4 x u32 for elements idx..idx+3 (idx % 4 == 0).
+// (seed, site, element index).  One call yields 4 x u32 = eight 16-bit slices for the elements 8 idx8 .. 8 idx8 + 7 (philox_keep8).
+// Rounds: 7 is the smallest count at which Philox4x32 passes BigCrush (Salmon, Moraes, Dror, Shaw: "Parallel Random Numbers: As Easy as
+// 1, 2, 3", SC'11, table 2: "Crush-resistant" from 7 rounds on; the library default of 10 is that plus a safety margin).  A dropout mask asks
+// for far less than BigCrush does, and every round is two quarter-rate integer multiply pairs per lane: all dropout together costs the
+// step 0.25 ms at configs[1] and 0.87 ms at the reference's PlotQA shape (bench.py --no-dropout), most of it these rounds.
+#define CRCT_PHILOX_ROUNDS 7
 struct Philox4 { uint32_t x, y, z, w; };
 // `seed` is either the value itself or, with bit 63 set, the device address of a u64 holding it:
 // a captured hipGraph bakes kernel arguments, so the per-step seed is then read from memory that the
 // host refreshes before every replay (uniform address -> one scalar load).
 #define CRCT_SEED_IN_MEMORY 0x8000000000000000ull
-__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, uint64_t idx4) {
+__device__ __forceinline__ Philox4 philox4x32(uint64_t seed, uint32_t site, uint64_t idx4) {
   if (seed & CRCT_SEED_IN_MEMORY) seed = *reinterpret_cast<const uint64_t*>(seed & ~CRCT_SEED_IN_MEMORY);
   uint32_t c0 = (uint32_t)idx4, c1 = (uint32_t)(idx4 >> 32), c2 = site, c3 = 0x9E3779B9u;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < CRCT_PHILOX_ROUNDS; ++r) {
     uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
@@ -80,7 +85,17 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, u
   }
   return Philox4{c0, c1, c2, c3};
 }
-// keep-threshold for drop probability p: keep iff u32 >= thr
+// Dropout bits, 8 per call: element e of the 8-element group `idx8` (e = element index & 7; every site numbers its elements row-major and
+// its groups are 8-aligned) is kept iff the e-th 16-bit slice of the call's 128 random bits is >= the upper half of the 32-bit threshold --
+// the drop probability is resolved to 2^-16 (p = 0.1 -> 6553 / 65536: 1e-5 below the scale's 1 / (1 - p), far under anything a mask of
+// 10^6 elements can show) and one Philox call serves 8 elements instead of 4.  Bit e of the result = element e is kept.
+__device__ __forceinline__ uint32_t philox_keep8(uint64_t seed, uint32_t site, uint64_t idx8, uint32_t thr) {
+  const Philox4 p = philox4x32(seed, site, idx8);
+  const uint32_t t = thr >> 16;
+  return ((p.x & 0xffffu) >= t ? 1u : 0u) | ((p.x >> 16) >= t ? 2u : 0u) | ((p.y & 0xffffu) >= t ? 4u : 0u) | ((p.y >> 16) >= t ? 8u : 0u) |
+         ((p.z & 0xffffu) >= t ? 16u : 0u) | ((p.z >> 16) >= t ? 32u : 0u) | ((p.w & 0xffffu) >= t ? 64u : 0u) | ((p.w >> 16) >= t ? 128u : 0u);
+}
+// keep-threshold for drop probability p: keep iff u32 >= thr (the kernels compare 16-bit slices against thr >> 16: philox_keep8)
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
   if (t <= 0.0) return 0u;

@@ -302,11 +302,10 @@ __device__ __forceinline__ void gemm_epilogue(const CrctGemmArgs& g, f4_t (&acc)
         v[3] *= act_grad(g.dact, bf2f((bf16_t)(s.y >> 16)));
       }
       if (thr) {            // inverted dropout, mask regenerated in backward from (seed, site, index)
-        const Philox4 r = philox4x32_10(g.seed, g.drop_site, ((uint64_t)m * (uint64_t)g.N + (uint64_t)n) >> 2);
-        v[0] = r.x >= thr ? v[0] * dscale : 0.f;
-        v[1] = r.y >= thr ? v[1] * dscale : 0.f;
-        v[2] = r.z >= thr ? v[2] * dscale : 0.f;
-        v[3] = r.w >= thr ? v[3] * dscale : 0.f;
+        const uint64_t idx = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;        // n % 4 == 0: this thread's four are one half of a group of 8
+        const uint32_t kb = philox_keep8(g.seed, g.drop_site, idx >> 3, thr) >> ((uint32_t)idx & 4u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * dscale : 0.f;
       }
       if (g.addend) {       // residual / upstream-gradient add (bf16)
         const uint2 s = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.addend) + (long)m * g.ld_add + n);
@@ -483,11 +482,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
         }
       }
       if (thr) {
-        const uint64_t i4 = ((uint64_t)m * (uint64_t)g.N + (uint64_t)n) >> 2;
-        const Philox4 r0 = philox4x32_10(g.seed, g.drop_site, i4), r1 = philox4x32_10(g.seed, g.drop_site, i4 + 1);
-        const uint32_t u[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const uint32_t kb = philox_keep8(g.seed, g.drop_site, ((uint64_t)m * (uint64_t)g.N + (uint64_t)n) >> 3, thr);      // n % 8 == 0, N % 8 == 0
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = u[j] >= thr ? v[j] * dscale : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * dscale : 0.f;
       }
       if (g.addend) {
         const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.addend) + (long)m * g.ld_add + n);

@@ -21,10 +21,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __device__ __forceinline__ bool head_keep(const CrctHeadArgs& a, int b, int c) {
   if (!a.drop_thr) return true;
   const uint64_t idx = (uint64_t)b * (uint64_t)a.Hb + (uint64_t)c;
-  const Philox4 p = philox4x32_10(a.seed, a.drop_site, idx >> 2);
-  const uint32_t k = (uint32_t)idx & 3u;
-  const uint32_t u = k == 0 ? p.x : (k == 1 ? p.y : (k == 2 ? p.z : p.w));
-  return u >= a.drop_thr;
+  return (philox_keep8(a.seed, a.drop_site, idx >> 3, a.drop_thr) >> ((uint32_t)idx & 7u)) & 1u;
 }
 
 // scratch row layout (fp32 x 8): dlogit0, dlogit1, dz, nsp_loss_b, valid, ok5, okt, needs

@@ -197,11 +197,9 @@ __device__ __forceinline__ void row_normalize(Row<NCH>& r, const Row<NCH>& gamma
 #pragma unroll
       for (int j = 0; j < 8; ++j) r.v[i][j] = gamma.v[i][j] * ((r.v[i][j] - mean) * rstd) + beta.v[i][j];
       if (thr) {
-        const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)c;
-        const Philox4 p0 = philox4x32_10(seed, site, idx >> 2), p1 = philox4x32_10(seed, site, (idx >> 2) + 1);
-        const uint32_t u[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        const uint32_t kb = philox_keep8(seed, site, ((uint64_t)row * (uint64_t)H + (uint64_t)c) >> 3, thr);      // c % 8 == 0, H % 8 == 0
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[i][j] = u[j] >= thr ? r.v[i][j] * scale : 0.f;
+        for (int j = 0; j < 8; ++j) r.v[i][j] = ((kb >> j) & 1u) ? r.v[i][j] * scale : 0.f;
       }
     }
   }
@@ -222,11 +220,9 @@ __device__ __forceinline__ void row_normalize(Row<NCH>& r, const float* gamma, c
 #pragma unroll
       for (int j = 0; j < 8; ++j) r.v[i][j] = gg[j] * ((r.v[i][j] - mean) * rstd) + bb[j];
       if (thr) {
-        const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)c;
-        const Philox4 p0 = philox4x32_10(seed, site, idx >> 2), p1 = philox4x32_10(seed, site, (idx >> 2) + 1);
-        const uint32_t u[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        const uint32_t kb = philox_keep8(seed, site, ((uint64_t)row * (uint64_t)H + (uint64_t)c) >> 3, thr);      // c % 8 == 0, H % 8 == 0
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[i][j] = u[j] >= thr ? r.v[i][j] * scale : 0.f;
+        for (int j = 0; j < 8; ++j) r.v[i][j] = ((kb >> j) & 1u) ? r.v[i][j] * scale : 0.f;
       }
     }
   }
@@ -241,11 +237,9 @@ __device__ __forceinline__ void row_apply_dropmask(Row<NCH>& r, int H, int lane,
   for (int i = 0; i < NCH; ++i) {
     const int c = (lane + 64 * i) * 8;
     if (c < H) {
-      const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)c;
-      const Philox4 p0 = philox4x32_10(seed, site, idx >> 2), p1 = philox4x32_10(seed, site, (idx >> 2) + 1);
-      const uint32_t u[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+      const uint32_t kb = philox_keep8(seed, site, ((uint64_t)row * (uint64_t)H + (uint64_t)c) >> 3, thr);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = u[j] >= thr ? r.v[i][j] * scale : 0.f;
+      for (int j = 0; j < 8; ++j) r.v[i][j] = ((kb >> j) & 1u) ? r.v[i][j] * scale : 0.f;
     }
   }
 }

@@ -50,7 +50,7 @@ typedef struct CrctGemmArgs {
   int32_t c_is_f32, accumulate;
   int32_t tile;             /* -1 = auto; 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64 */
   float alpha;
-  uint32_t drop_thr;        /* 0 = no dropout, else keep iff philox_u32 >= thr */
+  uint32_t drop_thr;        /* 0 = no dropout, else keep iff a 16-bit Philox slice >= thr >> 16 (drop probability thr / 2^32 to within 2^-16) */
   float drop_scale;         /* 1/(1-p) */
   uint32_t drop_site;
   uint64_t seed;
