@@ -80,7 +80,8 @@ class AmpState(C.Structure):
 
 class AttnQuant(C.Structure):
     _fields_ = [("ctx_q", vp), ("ctx_scale", vp), ("ctx_amax", vp), ("dq_q", vp), ("dk_q", vp), ("dv_q", vp),
-                ("dq_scale", vp), ("dq_amax", vp), ("dkv_scale", vp), ("dkv_amax", vp)]
+                ("dq_scale", vp), ("dq_amax", vp), ("dkv_scale", vp), ("dkv_amax", vp),
+                ("row_lse", vp), ("ctx", vp), ("ld_ctx", c_i64)]
 
 
 class Fp8Shadow(C.Structure):

@@ -204,13 +204,23 @@ def cast_bf16(x, out=None):
     return out
 
 
-def attention_fwd(q, k, v, keymask, heads, d, p_drop=0.0, site=0, seed=0):
-    """q [B,Tq,ldq] / k,v [B,Tk,ld*] bf16 (may be column slices of a wider buffer: pass the *slice*)."""
+def attention_fwd(q, k, v, keymask, heads, d, p_drop=0.0, site=0, seed=0, row_lse=None):
+    """q [B,Tq,ldq] / k,v [B,Tk,ld*] bf16 (may be column slices of a wider buffer: pass the *slice*).
+    row_lse: fp32 [B, heads, Tq] that the long-sequence kernels fill with the softmax row statistics (CrctAttnQuant.row_lse; the
+    other kernels leave it untouched) -- hand it, with the returned ctx, to ``attention_bwd``."""
     lib = L.load()
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[1]
     ctx = torch.empty(B, Tq, heads * d, device=q.device, dtype=torch.bfloat16)
     thr, sc, st = _drop(p_drop, site)
+    if row_lse is not None:
+        assert tuple(row_lse.shape) == (B, heads, Tq)
+        qz = L.AttnQuant()
+        qz.row_lse = L.ptr(_chk(row_lse, torch.float32))
+        L.check(lib.crct_attention_fwd_q(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(_chk(keymask, torch.uint8)), L.ptr(ctx), B, heads, Tq, Tk, d,
+                                         q.stride(1), k.stride(1), v.stride(1), heads * d, thr, sc, st, seed, C.byref(qz), L.current_stream()),
+                "attention_fwd")
+        return ctx
     L.check(lib.crct_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(_chk(keymask, torch.uint8)), L.ptr(ctx), B, heads, Tq, Tk, d,
                                    q.stride(1), k.stride(1), v.stride(1), heads * d, thr, sc, st, seed, L.current_stream()),
             "attention_fwd")
@@ -252,7 +262,9 @@ def attention_bwd_q(q, k, v, keymask, dctx, heads, d, dq_scale, dq_amax, dkv_sca
     return (dq, dk, dv), (dq8, dk8, dv8)
 
 
-def attention_bwd(q, k, v, keymask, dctx, heads, d, p_drop=0.0, site=0, seed=0):
+def attention_bwd(q, k, v, keymask, dctx, heads, d, p_drop=0.0, site=0, seed=0, row_lse=None, ctx=None):
+    """row_lse / ctx: what ``attention_fwd(..., row_lse=)`` of the same operands produced -- the long-sequence kernels then skip
+    their statistics sweep (the other kernels ignore both)."""
     lib = L.load()
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[1]
@@ -260,6 +272,13 @@ def attention_bwd(q, k, v, keymask, dctx, heads, d, p_drop=0.0, site=0, seed=0):
     dk = torch.empty(B, Tk, heads * d, device=q.device, dtype=torch.bfloat16)
     dv = torch.empty_like(dk)
     thr, sc, st = _drop(p_drop, site)
+    if row_lse is not None or ctx is not None:
+        qz = L.AttnQuant()
+        qz.row_lse, qz.ctx, qz.ld_ctx = L.ptr(_chk(row_lse, torch.float32)), L.ptr(_chk(ctx, torch.bfloat16)), (ctx.stride(1) if ctx is not None else 0)
+        L.check(lib.crct_attention_bwd_q(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(keymask), L.ptr(_chk(dctx, torch.bfloat16)), L.ptr(dq), L.ptr(dk),
+                                         L.ptr(dv), B, heads, Tq, Tk, d, q.stride(1), k.stride(1), v.stride(1), dctx.stride(1),
+                                         heads * d, heads * d, heads * d, thr, sc, st, seed, C.byref(qz), L.current_stream()), "attention_bwd")
+        return dq, dk, dv
     L.check(lib.crct_attention_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(keymask), L.ptr(_chk(dctx, torch.bfloat16)), L.ptr(dq), L.ptr(dk), L.ptr(dv),
                                    B, heads, Tq, Tk, d, q.stride(1), k.stride(1), v.stride(1), dctx.stride(1),
                                    heads * d, heads * d, heads * d, thr, sc, st, seed, L.current_stream()), "attention_bwd")

@@ -430,6 +430,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
+  if (qz && qz->row_lse) a.lse = qz->row_lse;          // written by the long-sequence kernels only (CrctAttnQuant)
 #ifdef CRCT_ATTN_LAB
   static const int dbg = getenv("CRCT_ATTN_DBG") ? atoi(getenv("CRCT_ATTN_DBG")) : 0;
   a.dbg = dbg;
@@ -483,6 +484,10 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.thr = drop_thr; a.dscale = drop_scale; a.site = drop_site; a.seed = seed;
   a.scale = 1.0f / sqrtf((float)d);
+  if (qz && (qz->row_lse || qz->ctx)) {
+    CRCT_REQUIRE(qz->row_lse && qz->ctx && qz->ld_ctx % 4 == 0, "attention_bwd_q: row_lse and ctx (ld_ctx %% 4 == 0) come together");
+    a.lse = qz->row_lse; a.ctx = (bf16_t*)qz->ctx; a.ldc = qz->ld_ctx;      // read only
+  }
   const int path = pick_path(Tq, Tk, d);
   if (path == PATH_MFMA) {
     CRCT_CHECK_HIP(crct_attention_mfma_bwd(a, (hipStream_t)stream));

@@ -20,6 +20,10 @@ struct AttnArgs {
   uint8_t* ctx_q; const float* ctx_qscale; float* ctx_qamax;
   uint8_t* dq_q; uint8_t* dk_q; uint8_t* dv_q;
   const float* dq_qscale; float* dq_qamax; const float* dkv_qscale; float* dkv_qamax;
+  // Row statistics of the softmax, attention_long.hip only (include/crct_hip.h CrctAttnQuant.row_lse): the forward writes
+  // log2 sum_j exp2(s_ij) per (batch, head, query) [B][heads][Tq]; a backward that gets them AND the forward's output (`ctx`, leading
+  // dimension ldc) skips its statistics sweep: p = exp2(s - lse), delta_i = dctx_i . ctx_i
+  float* lse; long ldc;
   int keep_cache;      // attention_long.hip backward: the dropout bits of phase A are kept in LDS for phase B (set by its launcher)
   int dbg;      // ablation bits, read only by -DCRCT_ATTN_LAB builds (tools/attn_lab); always 0 in the shipped library
 };

@@ -14,7 +14,7 @@
 // computed transposed (S^T = K Q^T): a lane owns one query and four consecutive keys per tile, its probabilities are the B
 // operand of ctx^T = V^T P^T as they lie.
 //
-// Backward (nothing but q, k, v is kept from the forward): Q, dO, K, V as LDS images (beyond 256 x 256 x 64: K, V for phase A and Q, dO
+// Backward (q, k, v; and, when the caller kept them, the forward's output and row statistics -- see LSE below): Q, dO, K, V as LDS images (beyond 256 x 256 x 64: K, V for phase A and Q, dO
 // in the same space for phase B, a wave's OWN tile straight from global memory), then
 //   phase A, a wave per QUERY tile: sweep 1 over the key tiles gives the row statistics -- m, 1 / l and
 //            delta_i = sum_j P_ij dP_ij, accumulated online like l -- and keeps the dropout bits of the tile row (4 bits per
@@ -23,6 +23,9 @@
 //   phase B, a wave per KEY tile: for every query tile S^T, dP^T again, P and dS from the statistics; both tiles pass through
 //            a 16 x 16 LDS tile of the wave (written from the accumulator layout, read back transposed) to become the B
 //            operands of dv^T += dO^T Pd and dk^T += Q^T dS.
+//   LSE (the forward wrote lse_i = log2 sum_j exp2(s_ij), and its output is still there -- the step engine keeps both): sweep 1 is
+//            dropped.  P_ij = exp2(s_ij - lse_i) needs no running maximum, and delta_i = sum_j P_ij dP_ij = dO_i . O_i (with dropout
+//            too: O = (mask o P / (1 - p)) V) is a d-element dot product per query.  A quarter of the kernel's instructions.
 // Every output element is accumulated by ONE wave in a fixed order: no atomics, bit-reproducible.  The price is 9 d / 16 MFMAs
 // per tile pair instead of the minimal 5 d / 16 -- on < 3 % of the step's arithmetic.
 #include "common.hip.h"
@@ -180,11 +183,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long(ATTN_HOT_PARAMS) {
         for (int u = 0; u < 2; ++u) o[ct] = mma16(frag_cols(Vs, STB, 16 * (jt + u), 16 * ct, lane), pb[u], o[ct]);        // ctx^T[c][i]
       }
     }
-    const float inv = 1.0f / xsum2(l);
+    const float lsum = xsum2(l);
+    const float inv = 1.0f / lsum;
     if (i < a.Tq) {
 #pragma unroll
       for (int ct = 0; ct < ND; ++ct)
         store_tile_t<true>(a.ctx, a.ctx_q, a.ldo, (long)b * a.Tq + i, h * d + 16 * ct + 4 * g, o[ct] * inv, a.ctx_qscale, am);
+      if (a.lse && g == 0) a.lse[bh * a.Tq + i] = m + __builtin_amdgcn_logf(lsum);      // v_log_f32: log2
     }
   }
   if (a.ctx_q) wave_amax(a.ctx_qamax, am, lane);
@@ -211,7 +216,7 @@ __device__ __forceinline__ void score_tiles(f4_t& s, f4_t& gp, const char* Ks, c
 // SHARE = false: all four images resident (up to 256 x 256 x 64) -- every fragment out of LDS.  SHARE = true (beyond that, up to 512 x 512 x 64):
 // the images of the two phases share one space and a wave's OWN tile (q / dO in phase A, k / v in phase B) comes straight from global
 // memory; costs the PlotQA-shaped step 0.27 ms (18.95 against 18.68) where both fit, hence only where it must.
-template <int ND, int NW, bool SHARE>
+template <int ND, int NW, bool SHARE, bool LSE>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   ATTN_HOT_UNPACK
   constexpr int STB = 32 * ND + 16, d = 16 * ND;
@@ -232,8 +237,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   float* kbias = reinterpret_cast<float*>(stats + 16 * NQ);
   char* scr = reinterpret_cast<char*>(kbias + 16 * NK) + wv * 16 * SCR_STB;
   // dropout bits of tile pair (it, jt) as phase A's lanes hold them -- the layout phase B needs them in (lane = query 16 it + n, keys
-  // 16 jt + 4 g ..): one Philox call per lane and tile pair instead of two (v_mul_hi / v_mul_lo are quarter-rate: ~900 cycles a call,
-  // the largest single cost of this kernel with dropout on)
+  // 16 jt + 4 g ..): one Philox call per lane and tile pair instead of two (~140 SIMD cycles a wave-call at 7 rounds:
+  // tools/lab/philox_rate.hip; a fifth of this issue-bound kernel's instructions with dropout on)
   uint8_t* keepc = reinterpret_cast<uint8_t*>(kbias + 16 * NK) + NW * 16 * SCR_STB;
   const bool cached = a.keep_cache != 0;
   const bf16_t* qg = a.q + (long)b * a.Tq * a.ldq + h * d;
@@ -266,9 +271,24 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
     }
     float m = -INFINITY, l = 0.f, dl = 0.f;
     uint32_t kw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};      // keep bits, 4 per key tile (up to 32 key tiles)
+    if constexpr (LSE) {
+      // the forward's statistics: m <- lse (then exp2(s - m) IS the probability: l = 1), delta from the forward's output
+      const bf16_t* cg = a.ctx + ((long)b * a.Tq + min(i, a.Tq - 1)) * a.ldc + h * d + 4 * g;
+#pragma unroll
+      for (int ks = 0; ks < ND; ++ks) {
+        const uint2 ov = *reinterpret_cast<const uint2*>(cg + 16 * ks);
+        dl = fmaf(bf2f((bf16_t)(ov.x & 0xffff)), bf2f((bf16_t)of[ks][0]), dl);
+        dl = fmaf(bf2f((bf16_t)(ov.x >> 16)), bf2f((bf16_t)of[ks][1]), dl);
+        dl = fmaf(bf2f((bf16_t)(ov.y & 0xffff)), bf2f((bf16_t)of[ks][2]), dl);
+        dl = fmaf(bf2f((bf16_t)(ov.y >> 16)), bf2f((bf16_t)of[ks][3]), dl);
+      }
+      // a query past Tq (padding of the last tile: q and dO rows are zero) gets m = +inf: its probabilities are exactly 0 whatever its scores
+      m = i < a.Tq ? a.lse[bh * a.Tq + i] : INFINITY;
+      l = 0.25f;                                   // xsum2 over the four lane groups below: 1
+    }
 #pragma unroll
     for (int jo = 0; jo < 4; ++jo) {
-      if (8 * jo < NK) {
+      if (!LSE && 8 * jo < NK) {
         uint32_t w = 0u, kb8 = 0xffu;
         const int je = min(8, NK - 8 * jo);
 #pragma unroll 1
@@ -307,13 +327,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
     for (int jo = 0; jo < 4; ++jo) {
       if (8 * jo < NK) {
         const uint32_t w = kw[jo];
+        uint32_t kb8 = 0xffu;
         const int je = min(8, NK - 8 * jo);
 #pragma unroll 1
         for (int ji = 0; ji < je; ++ji) {
           const int jt = 8 * jo + ji;
           f4_t s, gp;
           score_tiles<ND>(s, gp, Ks, Vs, kbias, qf, of, jt, sc, lane);
-          const uint32_t nib = (w >> (4 * ji)) & 0xfu;
+          uint32_t nib;
+          if constexpr (LSE) {                     // no sweep 1: the dropout bits are made (and parked for phase B) here
+            if (!(ji & 1)) kb8 = keep_byte(a, bh, i, jt >> 1, g);
+            nib = (kb8 >> (4 * (ji & 1))) & 0xfu;
+            if (cached) keepc[(it * NK + jt) * 64 + lane] = (uint8_t)nib;
+          } else {
+            nib = (w >> (4 * ji)) & 0xfu;
+          }
           f4_t dsv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -402,9 +430,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_long(ATTN_HOT_PARAMS) {
   if (a.dv_q || a.dk_q) wave_amax(a.dkv_qamax, am_kv, lane);
 }
 
-template <bool BWD, int ND, int NW, bool SHARE>
+template <bool BWD, int ND, int NW, bool SHARE, bool LSE>
 hipError_t launch_nw(const AttnArgs& a, size_t lds, hipStream_t s) {
-  auto kern = BWD ? attn_bwd_long<ND, NW, SHARE> : attn_fwd_long<ND, NW>;
+  auto kern = BWD ? attn_bwd_long<ND, NW, SHARE, LSE> : attn_fwd_long<ND, NW>;
   static bool raised = false;             // first call is eager (outside any stream capture)
   if (lds > 64 * 1024 && !raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CAP);
@@ -435,8 +463,14 @@ hipError_t launch_d(const AttnArgs& a_in, hipStream_t s) {
     a.keep_cache = 1;
     lds += keep_cache_bytes(NQ, NK);
   }
-  if (share) return NW == 8 ? launch_nw<BWD, ND, 8, true>(a, lds, s) : launch_nw<BWD, ND, 4, true>(a, lds, s);
-  return NW == 8 ? launch_nw<BWD, ND, 8, false>(a, lds, s) : launch_nw<BWD, ND, 4, false>(a, lds, s);
+  if constexpr (BWD) {
+    if (a.lse && a.ctx) {     // the forward's statistics and output are at hand: no statistics sweep
+      if (share) return NW == 8 ? launch_nw<true, ND, 8, true, true>(a, lds, s) : launch_nw<true, ND, 4, true, true>(a, lds, s);
+      return NW == 8 ? launch_nw<true, ND, 8, false, true>(a, lds, s) : launch_nw<true, ND, 4, false, true>(a, lds, s);
+    }
+  }
+  if (share) return NW == 8 ? launch_nw<BWD, ND, 8, true, false>(a, lds, s) : launch_nw<BWD, ND, 4, true, false>(a, lds, s);
+  return NW == 8 ? launch_nw<BWD, ND, 8, false, false>(a, lds, s) : launch_nw<BWD, ND, 4, false, false>(a, lds, s);
 }
 template <bool BWD>
 hipError_t launch(const AttnArgs& a, hipStream_t s) {

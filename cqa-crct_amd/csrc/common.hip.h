@@ -63,8 +63,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // (seed, site, element index).  One call yields 4 x u32 = eight 16-bit slices for the elements 8 idx8 .. 8 idx8 + 7 (philox_keep8).
 // Rounds: 7 is the smallest count at which Philox4x32 passes BigCrush (Salmon, Moraes, Dror, Shaw: "Parallel Random Numbers: As Easy as
 // 1, 2, 3", SC'11, table 2: "Crush-resistant" from 7 rounds on; the library default of 10 is that plus a safety margin).  A dropout mask asks
-// for far less than BigCrush does, and every round is two quarter-rate integer multiply pairs per lane: all dropout together costs the
-// step 0.25 ms at configs[1] and 0.87 ms at the reference's PlotQA shape (bench.py --no-dropout), most of it these rounds.
+// for far less than BigCrush does, and every round is two 32 x 32 -> 64-bit multiplies per lane (measured, tools/lab/philox_rate.hip:
+// 21 - 22 SIMD cycles per round and wave): all dropout together cost the step 0.25 ms at configs[1] and 0.87 ms at the reference's
+// PlotQA shape with 10 rounds and 4 elements per call (bench.py --no-dropout).
 #define CRCT_PHILOX_ROUNDS 7
 struct Philox4 { uint32_t x, y, z, w; };
 // `seed` is either the value itself or, with bit 63 set, the device address of a u64 holding it:
@@ -77,8 +78,10 @@ __device__ __forceinline__ Philox4 philox4x32(uint64_t seed, uint32_t site, uint
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < CRCT_PHILOX_ROUNDS; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // 64-bit products: ONE v_mad_u64_u32 each instead of a v_mul_hi_u32 / v_mul_lo_u32 pair (tools/lab/philox_rate.hip: 136 against 158
+    // cycles per 7-round wave-call)
+    const uint64_t p0 = (uint64_t)c0 * 0xD2511F53ull, p1 = (uint64_t)c2 * 0xCD9E8D57ull;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

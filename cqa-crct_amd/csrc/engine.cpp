@@ -41,7 +41,7 @@ void crct_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crct_last_error(void) { return g_err; }
-extern "C" int crct_abi_version(void) { return 5; }
+extern "C" int crct_abi_version(void) { return 6; }
 
 extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a != nullptr, "gemm: null args");
@@ -101,8 +101,9 @@ struct ConnLayerP { LinearP qkv1, qkv2; ProjP proj_v, proj_t; FfnP ffn_v, ffn_t;
 struct FfnA { size_t u, h, s, y, mean, rstd, hq, yq; int site_h, site_y; int g_dl, g_du; };      // g_*: gradient scale sites (fp8 backward)      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
 struct ProjA { size_t s, a, mean, rstd, aq; int site_a; int g_dl; };
 // ctxq / site_ctx: e4m3 copy of the attention context and its activation scale site; g_dqkv: gradient scale site of the fused dqkv buffer
-struct SelfLayerA { size_t qkv, ctx, ctxq; int site_ctx, g_dqkv; ProjA proj; FfnA ffn; };
-struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2, ctx1q, ctx2q; int site_ctx1, site_ctx2, g_dqkv1, g_dqkv2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
+// lse*: softmax row statistics [B][heads][Tq] fp32 the long-sequence attention forward leaves for its backward (CrctAttnQuant.row_lse)
+struct SelfLayerA { size_t qkv, ctx, ctxq, lse; int site_ctx, g_dqkv; ProjA proj; FfnA ffn; };
+struct ConnLayerA { size_t qkv1, qkv2, ctx1, ctx2, ctx1q, ctx2q, lse1, lse2; int site_ctx1, site_ctx2, g_dqkv1, g_dqkv2; ProjA proj_v, proj_t; FfnA ffn_v, ffn_t; };
 struct StreamScratch { size_t dy[2], dres_a, dlin_a, dres_b, dlin_b, gc, du, dctx, dqkv, part_a, part_b, dlq_a, dlq_b, duq, dqkvq; };      // *q: e5m2 copies (fp8 backward)
 
 struct Step { char kind; int idx; };
@@ -535,12 +536,14 @@ struct Run {
   }
   // ctxq / site_ctx: also the e4m3 copy of ctx (the fp8 forward GEMM and weight gradient of the attention-output projection read it)
   void attn_fwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km, bf16_t* ctx,
-                int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr, size_t ctxq = (size_t)-1, int site_ctx = -1) {
+                int64_t ldo, int B, int heads, int Tq, int Tk, int d, const Drop& dr, size_t ctxq = (size_t)-1, int site_ctx = -1,
+                size_t lse = (size_t)-1) {
     if (rc) return;
     ++tick;
     const uint64_t seed = c->seed;
     CrctAttnQuant qz;
     memset(&qz, 0, sizeof(qz));
+    if (lse != (size_t)-1) qz.row_lse = F(lse);
     if (ctxq != (size_t)-1 && site_ctx >= 0) {
       qz.ctx_q = W<uint8_t>(ctxq); qz.ctx_scale = c->fp8_act_scale + site_ctx; qz.ctx_amax = c->fp8_act_amax + (int64_t)site_ctx * CRCT_FP8_AMAX_LANES;
     }
@@ -550,12 +553,13 @@ struct Run {
   void attn_bwd(const bf16_t* q, int64_t ldq, const bf16_t* k, const bf16_t* v, int64_t ldk, const uint8_t* km,
                 const bf16_t* dctx, int64_t ldo, bf16_t* dq, int64_t lddq, bf16_t* dk, bf16_t* dv, int64_t lddk, int B,
                 int heads, int Tq, int Tk, int d, const Drop& dr, uint8_t* dqq = nullptr, int g_dq = -1, uint8_t* dkq = nullptr,
-                uint8_t* dvq = nullptr, int g_dkv = -1) {
+                uint8_t* dvq = nullptr, int g_dkv = -1, size_t lse = (size_t)-1, const bf16_t* ctx = nullptr, int64_t ldc = 0) {
     if (rc) return;
     ++tick;
     const uint64_t seed = c->seed;
     CrctAttnQuant qz;
     memset(&qz, 0, sizeof(qz));
+    if (lse != (size_t)-1 && ctx) { qz.row_lse = F(lse); qz.ctx = ctx; qz.ld_ctx = ldc; }
     if (dqq && g_dq >= 0) { qz.dq_q = dqq; qz.dq_scale = gscale(g_dq); qz.dq_amax = gamax(g_dq); }
     if (dkq && dvq && g_dkv >= 0) { qz.dk_q = dkq; qz.dv_q = dvq; qz.dkv_scale = gscale(g_dkv); qz.dkv_amax = gamax(g_dkv); }
     fail(crct_attention_bwd_q(q, k, v, km, dctx, dq, dk, dv, B, heads, Tq, Tk, d, ldq, ldk, ldk, ldo, lddq, lddk, lddk, dr.thr, dr.scale,
@@ -627,7 +631,7 @@ struct Run {
     else lin_fwd(A(x), p.qkv.in, p.qkv, M, A(a.qkv), 3 * H, Opt());
     const bool cq = f8_lin(p.proj.dense) && attn_q_ok(T, T, d);
     attn_fwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(a.ctx), H, B, p.heads, T, T, d, drop(p.p_attn, p.site),
-             cq ? a.ctxq : (size_t)-1, cq ? a.site_ctx : -1);
+             cq ? a.ctxq : (size_t)-1, cq ? a.site_ctx : -1, a.lse);
     proj_fwd(p.proj, a.proj, a.ctx, x, M, drop(p.p_hid, p.site + 1), a.ctxq, cq ? a.site_ctx : -1);
     ffn_fwd(p.ffn, a.ffn, a.proj.a, a.proj.aq, a.proj.site_a, M, drop(p.p_hid, p.site + 2));
   }
@@ -643,7 +647,7 @@ struct Run {
     uint8_t* dq8 = gq ? W<uint8_t>(sc.dqkvq) : nullptr;
     attn_bwd(A(a.qkv), 3 * H, A(a.qkv) + H, A(a.qkv) + 2 * H, 3 * H, km, A(sc.dctx), H, A(sc.dqkv), 3 * H, A(sc.dqkv) + H,
              A(sc.dqkv) + 2 * H, 3 * H, B, p.heads, T, T, d, drop(p.p_attn, p.site), dq8, a.g_dqkv, gq ? dq8 + H : nullptr,
-             gq ? dq8 + 2 * H : nullptr, a.g_dqkv);
+             gq ? dq8 + 2 * H : nullptr, a.g_dqkv, a.lse, A(a.ctx), H);
     WgQ8 w8;
     if (gq) { w8.dyq = sc.dqkvq; w8.g_dy = a.g_dqkv; w8.xq = xq; w8.site_x = site_x; }
     lin_wgrad(A(sc.dqkv), 3 * H, A(x), H, p.qkv, M, true, w8);
@@ -667,10 +671,10 @@ struct Run {
     const bool aq = attn_q_ok(b->T, b->V, d) && attn_q_ok(b->V, b->T, d);
     const bool cq1 = aq && f8_lin(p.proj_t.dense), cq2 = aq && V.f8_lin(p.proj_v.dense);
     attn_fwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(a.ctx1), Hb, B, D.b_heads,
-             b->T, b->V, d, drop(D.p_v_attn, p.site), cq1 ? a.ctx1q : (size_t)-1, cq1 ? a.site_ctx1 : -1);
+             b->T, b->V, d, drop(D.p_v_attn, p.site), cq1 ? a.ctx1q : (size_t)-1, cq1 ? a.site_ctx1 : -1, a.lse1);
     // visual queries over text keys/values -> ctx2 [B,V,Hb]  :704-723
     V.attn_fwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(a.ctx2), Hb, B, D.b_heads,
-               b->V, b->T, d, drop(D.p_attn, p.site + 1), cq2 ? a.ctx2q : (size_t)-1, cq2 ? a.site_ctx2 : -1);
+               b->V, b->T, d, drop(D.p_attn, p.site + 1), cq2 ? a.ctx2q : (size_t)-1, cq2 ? a.site_ctx2 : -1, a.lse2);
     // cross wiring :780 -- visual stream takes ctx2, text stream takes ctx1
     V.proj_fwd(p.proj_v, a.proj_v, a.ctx2, xv, Mv, drop(D.p_v_hidden, p.site + 2), a.ctx2q, cq2 ? a.site_ctx2 : -1);
     proj_fwd(p.proj_t, a.proj_t, a.ctx1, xt, Mt, drop(D.p_hidden, p.site + 3), a.ctx1q, cq1 ? a.site_ctx1 : -1);
@@ -709,11 +713,11 @@ struct Run {
     uint8_t* vq8 = gq ? W<uint8_t>(sv.dqkvq) : nullptr;
     attn_bwd(A(a.qkv2), 3 * Hb, A(a.qkv1) + Hb, A(a.qkv1) + 2 * Hb, 3 * Hb, b->image_keymask, A(st.dctx), Hb, A(st.dqkv),
              3 * Hb, A(sv.dqkv) + Hb, A(sv.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->T, b->V, d, drop(D.p_v_attn, p.site),
-             tq8, a.g_dqkv2, gq ? vq8 + Hb : nullptr, gq ? vq8 + 2 * Hb : nullptr, a.g_dqkv1);
+             tq8, a.g_dqkv2, gq ? vq8 + Hb : nullptr, gq ? vq8 + 2 * Hb : nullptr, a.g_dqkv1, a.lse1, A(a.ctx1), Hb);
     // ctx2 = attn(q1, k2, v2): dq1 -> dqkv1[:, 0:Hb], dk2/dv2 -> dqkv2[:, Hb:3Hb]            (visual stream)
     V.attn_bwd(A(a.qkv1), 3 * Hb, A(a.qkv2) + Hb, A(a.qkv2) + 2 * Hb, 3 * Hb, b->text_keymask, A(sv.dctx), Hb, A(sv.dqkv),
                3 * Hb, A(st.dqkv) + Hb, A(st.dqkv) + 2 * Hb, 3 * Hb, B, D.b_heads, b->V, b->T, d, drop(D.p_attn, p.site + 1),
-               vq8, a.g_dqkv1, gq ? tq8 + Hb : nullptr, gq ? tq8 + 2 * Hb : nullptr, a.g_dqkv2);
+               vq8, a.g_dqkv1, gq ? tq8 + Hb : nullptr, gq ? tq8 + 2 * Hb : nullptr, a.g_dqkv2, a.lse2, A(a.ctx2), Hb);
     // each stream's dqkv buffer has been written by BOTH attention backward kernels
     cross_sync(V);
     WgQ8 wv, wt;
@@ -1052,17 +1056,18 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
   e->tla.resize(D.L); e->vla.resize(D.Lv); e->cla.resize(D.n_conn);
   for (int i = 0; i < D.L; ++i) {
     SelfLayerA& a = e->tla[i];
-    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.ctxq = ar.take(Mt * D.H); a.site_ctx = e->n_sites++; a.g_dqkv = e->n_gsites++; a.proj = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
+    a.qkv = ar.take(Mt * 3 * D.H * 2); a.ctx = ar.take(Mt * D.H * 2); a.ctxq = ar.take(Mt * D.H); a.lse = ar.take(Mt * D.heads * 4); a.site_ctx = e->n_sites++; a.g_dqkv = e->n_gsites++; a.proj = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);
   }
   for (int i = 0; i < D.Lv; ++i) {
     SelfLayerA& a = e->vla[i];
-    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.ctxq = ar.take(Mv * D.Hv); a.site_ctx = e->n_sites++; a.g_dqkv = e->n_gsites++; a.proj = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites);
+    a.qkv = ar.take(Mv * 3 * D.Hv * 2); a.ctx = ar.take(Mv * D.Hv * 2); a.ctxq = ar.take(Mv * D.Hv); a.lse = ar.take(Mv * D.v_heads * 4); a.site_ctx = e->n_sites++; a.g_dqkv = e->n_gsites++; a.proj = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.ffn = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites);
   }
   for (int i = 0; i < D.n_conn; ++i) {
     ConnLayerA& a = e->cla[i];
     a.qkv1 = ar.take(Mv * 3 * D.Hb * 2); a.qkv2 = ar.take(Mt * 3 * D.Hb * 2);
     a.ctx1 = ar.take(Mt * D.Hb * 2); a.ctx2 = ar.take(Mv * D.Hb * 2);
     a.ctx1q = ar.take(Mt * D.Hb); a.ctx2q = ar.take(Mv * D.Hb);
+    a.lse1 = ar.take(Mt * D.b_heads * 4); a.lse2 = ar.take(Mv * D.b_heads * 4);
     a.site_ctx1 = e->n_sites++; a.site_ctx2 = e->n_sites++; a.g_dqkv1 = e->n_gsites++; a.g_dqkv2 = e->n_gsites++;
     a.proj_v = proj_a(ar, Mv, D.Hv, e->n_sites, e->n_gsites); a.proj_t = proj_a(ar, Mt, D.H, e->n_sites, e->n_gsites);
     a.ffn_v = ffn_a(ar, Mv, D.Hv, D.Iv, e->n_sites, e->n_gsites); a.ffn_t = ffn_a(ar, Mt, D.H, D.I, e->n_sites, e->n_gsites);

@@ -484,6 +484,11 @@ typedef struct CrctAttnQuant {
   void* ctx_q; const float* ctx_scale; float* ctx_amax;
   void* dq_q; void* dk_q; void* dv_q;
   const float* dq_scale; float* dq_amax; const float* dkv_scale; float* dkv_amax;
+  /* Row statistics kept from the forward (independent of fp8; the long-sequence kernels use them, the others ignore them):
+   * crct_attention_fwd_q writes row_lse[B][heads][Tq] fp32 = log2 of the softmax denominator in the kernel's exp2 domain; a
+   * crct_attention_bwd_q that is given the SAME array and the forward's output (`ctx` bf16 [B][Tq][ld_ctx], head h at column h d) drops
+   * its statistics sweep: P = exp2(s - lse), delta_i = dctx_i . ctx_i.  Both NULL: everything is recomputed from q, k, v. */
+  float* row_lse; const void* ctx; int64_t ld_ctx;
 } CrctAttnQuant;
 int crct_attention_quant_ok(int Tq, int Tk, int d);
 int crct_attention_fwd_q(const void* q, const void* k, const void* v, const uint8_t* keymask, void* ctx,

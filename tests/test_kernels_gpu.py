@@ -342,8 +342,11 @@ LONG_SHAPES = [(4, 16, 124, 124, 48), (4, 32, 124, 44, 32), (4, 32, 44, 124, 32)
                (1, 16, 512, 512, 64), (2, 8, 300, 512, 48), (1, 4, 512, 40, 32), (1, 3, 33, 497, 64)]
 
 
+# stats = "kept": the forward leaves its softmax row statistics (CrctAttnQuant.row_lse) and the backward, given them and the forward's
+# output, skips its statistics sweep -- what the step engine does; "recomputed": the backward of the plain entry points (q, k, v only)
+@pytest.mark.parametrize("stats", ["recomputed", "kept"])
 @pytest.mark.parametrize("B,heads,Tq,Tk,d", LONG_SHAPES)
-def test_attention_long_sequences_fwd_bwd(B, heads, Tq, Tk, d):
+def test_attention_long_sequences_fwd_bwd(B, heads, Tq, Tk, d, stats):
     Hh = heads * d
     bufq = bf(rand(B, Tq, 3 * Hh, seed=1))
     bufk = bf(rand(B, Tk, 3 * Hh, seed=2))
@@ -351,16 +354,47 @@ def test_attention_long_sequences_fwd_bwd(B, heads, Tq, Tk, d):
     km = torch.ones(B, Tk, dtype=torch.uint8, device=DEV)
     for b in range(B):
         km[b, Tk - 1 - 5 * b:] = 0
-    ctx = ops.attention_fwd(q, k, v, km, heads, d)
+    lse = torch.full((B, heads, Tq), float("nan"), device=DEV) if stats == "kept" else None
+    ctx = ops.attention_fwd(q, k, v, km, heads, d, row_lse=lse)
     qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
     ref = _attn_ref(qr, kr, vr, km, heads, d)
     assert rel_err(ctx, ref) < 1e-2
+    if lse is not None:
+        # log2 of the softmax denominator in the exp2 domain = log2(e) * logsumexp of the masked, scaled scores
+        sc = torch.einsum("bihd,bjhd->bhij", q.float().view(B, Tq, heads, d), k.float().view(B, Tk, heads, d)) / math.sqrt(d)
+        sc = sc + (1.0 - km.float())[:, None, None, :] * -10000.0
+        want = torch.logsumexp(sc, dim=-1) * math.log2(math.e)
+        assert bool(torch.isfinite(lse).all()) and float((lse - want).abs().max()) < 2e-2
     dctx = bf(rand(B, Tq, Hh, seed=3))
     ref.backward(dctx.float())
-    dq, dk, dv = ops.attention_bwd(q, k, v, km, dctx, heads, d)
+    dq, dk, dv = ops.attention_bwd(q, k, v, km, dctx, heads, d, row_lse=lse, ctx=ctx if lse is not None else None)
     assert rel_err(dq, qr.grad) < 1.5e-2
     assert rel_err(dk, kr.grad) < 1.5e-2
     assert rel_err(dv, vr.grad) < 1.5e-2
+
+
+def test_attention_backward_with_kept_statistics_matches_the_recomputing_one_under_dropout():
+    """p = 0.1: the two backward forms regenerate the same mask (the kept-statistics form makes the dropout bits in its one sweep) and
+    agree to bf16 rounding; delta_i = dctx_i . ctx_i holds WITH dropout because ctx was computed from the masked, rescaled probabilities.
+    Also: row_lse and ctx come together (one without the other is an error), and both forms are bit-reproducible."""
+    p = 0.1
+    for B, heads, Tq, Tk, d in ((4, 16, 124, 124, 48), (3, 32, 124, 44, 32), (3, 32, 44, 124, 32), (1, 8, 300, 512, 64), (2, 4, 130, 17, 48)):
+        Hh = heads * d
+        q, k, v = bf(rand(B, Tq, Hh, seed=1)), bf(rand(B, Tk, Hh, seed=2)), bf(rand(B, Tk, Hh, seed=3))
+        km = torch.ones(B, Tk, dtype=torch.uint8, device=DEV)
+        km[:, Tk - 3:] = 0
+        dctx = bf(rand(B, Tq, Hh, seed=4))
+        lse = torch.empty(B, heads, Tq, device=DEV)
+        ctx = ops.attention_fwd(q, k, v, km, heads, d, p_drop=p, site=5, seed=77, row_lse=lse)
+        assert torch.equal(ctx, ops.attention_fwd(q, k, v, km, heads, d, p_drop=p, site=5, seed=77))      # writing the statistics changes nothing
+        plain = ops.attention_bwd(q, k, v, km, dctx, heads, d, p_drop=p, site=5, seed=77)
+        kept = ops.attention_bwd(q, k, v, km, dctx, heads, d, p_drop=p, site=5, seed=77, row_lse=lse, ctx=ctx)
+        again = ops.attention_bwd(q, k, v, km, dctx, heads, d, p_drop=p, site=5, seed=77, row_lse=lse, ctx=ctx)
+        for a, b, c in zip(plain, kept, again):
+            assert rel_err(b, a) < 1.5e-2
+            assert torch.equal(b, c)
+    with pytest.raises(RuntimeError, match="come together"):
+        ops.attention_bwd(q, k, v, km, dctx, heads, d, row_lse=lse)
 
 
 def test_attention_long_and_short_kernels_agree_under_dropout():

@@ -81,7 +81,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "symbol %s declared in include/crct_hip.h is not exported" % name
     assert set(L.PROTOTYPES) <= set(declared)
     handle = L.load()
-    assert handle.crct_abi_version() == 5
+    assert handle.crct_abi_version() == 6
 
 
 def test_shipped_library_carries_no_lab_hook():
