@@ -69,7 +69,7 @@ TILE_NAMES = {0: "dma128x128w4s3", 1: "dma128x64w4s4", 2: "dma64x128w4s4", 3: "d
               58: "ldrp128x128w4+4s3", 59: "ldrp128x128w8+4s3", 61: "ldrp128x64w4+2s4", 62: "ldrp128x128w4+4s2",
               63: "ldrp128x64w4+4s3", 64: "ldrp128x64w4+2s2", 60: "ldr256x128w4+4s3", 65: "ldr256x128w4+4s2",
               66: "ldrh256x128w4+4s3", 67: "ldrh256x128w8+4s3", 68: "ldrh128x128w4+4s3", 69: "ldrh128x64w4+2s3", 70: "ldrh128x128w8+4s3", 71: "ldrh256x128w4+4s2"}
-KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp")
+KERNEL_SOURCES = ("cqa-crct_amd/csrc/gemm.hip", "cqa-crct_amd/csrc/engine.cpp", "cqa-crct_amd/csrc/common.hip.h")
 
 
 def parse():

@@ -243,8 +243,9 @@ def attention_fwd_q(q, k, v, keymask, heads, d, q_scale, q_amax, p_drop=0.0, sit
     return ctx, ctx_q
 
 
-def attention_bwd_q(q, k, v, keymask, dctx, heads, d, dq_scale, dq_amax, dkv_scale, dkv_amax, p_drop=0.0, site=0, seed=0):
-    """attention_bwd that also returns the e5m2 copies of dq, dk, dv (uint8)."""
+def attention_bwd_q(q, k, v, keymask, dctx, heads, d, dq_scale, dq_amax, dkv_scale, dkv_amax, p_drop=0.0, site=0, seed=0, row_lse=None,
+                    ctx=None):
+    """attention_bwd that also returns the e5m2 copies of dq, dk, dv (uint8); row_lse / ctx as in ``attention_bwd``."""
     lib = L.load()
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[1]
@@ -255,6 +256,8 @@ def attention_bwd_q(q, k, v, keymask, dctx, heads, d, dq_scale, dq_amax, dkv_sca
     qz = L.AttnQuant()
     qz.dq_q, qz.dk_q, qz.dv_q = L.ptr(dq8), L.ptr(dk8), L.ptr(dv8)
     qz.dq_scale, qz.dq_amax, qz.dkv_scale, qz.dkv_amax = L.ptr(dq_scale), L.ptr(dq_amax), L.ptr(dkv_scale), L.ptr(dkv_amax)
+    if row_lse is not None or ctx is not None:
+        qz.row_lse, qz.ctx, qz.ld_ctx = L.ptr(_chk(row_lse, torch.float32)), L.ptr(_chk(ctx, torch.bfloat16)), (ctx.stride(1) if ctx is not None else 0)
     thr, sc, st = _drop(p_drop, site)
     L.check(lib.crct_attention_bwd_q(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(keymask), L.ptr(_chk(dctx, torch.bfloat16)), L.ptr(dq), L.ptr(dk), L.ptr(dv),
                                      B, heads, Tq, Tk, d, q.stride(1), k.stride(1), v.stride(1), dctx.stride(1),

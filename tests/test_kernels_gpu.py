@@ -910,6 +910,16 @@ def test_attention_fp8_copies_of_context_and_gradients():
                 for t, t8, s in ((dq, dq8, 3.0e5), (dk, dk8, 1.0e5), (dv, dv8, 1.0e5)):
                     want = (t.float() * s).clamp(-57344, 57344).to(torch.float8_e5m2)
                     assert torch.equal(t8.view(torch.float8_e5m2).float(), want.float()), (split, Tq, Tk, d)
+                if max(Tq, Tk) > 112:      # the long kernels' backward with the forward's row statistics (what the fp8 step runs): same contract
+                    lse = torch.empty(B, h, Tq, device=DEV)
+                    assert torch.equal(ops.attention_fwd(q, k, v, km, h, d, p_drop=0.1, site=3, seed=9, row_lse=lse), ctx)
+                    kept = ops.attention_bwd(q, k, v, km, do, h, d, p_drop=0.1, site=3, seed=9, row_lse=lse, ctx=ctx)
+                    a1.zero_(); a2.zero_()
+                    kept2, kept8 = ops.attention_bwd_q(q, k, v, km, do, h, d, s1, a1, s2, a2, p_drop=0.1, site=3, seed=9, row_lse=lse, ctx=ctx)
+                    for t, t2, t8, s in zip(kept, kept2, kept8, (3.0e5, 1.0e5, 1.0e5)):
+                        assert torch.equal(t, t2)
+                        assert torch.equal(t8.view(torch.float8_e5m2).float(), (t.float() * s).clamp(-57344, 57344).to(torch.float8_e5m2).float())
+                    assert float(a1.max()) == float(kept[0].float().abs().max())
                 assert float(a1.max()) == float(dq.float().abs().max())
                 assert float(a2.max()) == max(float(dk.float().abs().max()), float(dv.float().abs().max()))
     finally:
