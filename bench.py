@@ -114,6 +114,9 @@ def parse():
                     "reached by ring all-reduces on 8 x MI300-class nodes)")
     ap.add_argument("--emulate-ranks", type=int, default=1, help="test hook (N = 1): every step's batch is the CONCATENATION of the batches R "
                     "ranks would draw (batch R x --batch): the run a data-parallel R-rank run must agree with (config.global_loss)")
+    ap.add_argument("--residual-bf16", action="store_true", help="params['residual_fp32'] = False: the residual stream stored as bf16 (rounds 1 - 5; "
+                    "3 %% faster, gradient-cosine deficit against the fp32 oracle x 5: profiles/r6_residual_stream_parity.txt); not the default, "
+                    "never the headline line")
     ap.add_argument("--no-dropout", action="store_true", help="test hook: dropout probabilities 0 (run-to-run and rank-count independent losses)")
     ap.add_argument("--exchange-skip", default="", help="timing experiment: comma list of exchange parts to leave out (pack, collective, stats)")
     ap.add_argument("--vis-stream", type=int, default=1, help="0: the visual stream's layers on the caller's stream (developer timing experiment)")
@@ -497,6 +500,8 @@ def main():
         params["fp8_wgrad"] = False
     if a.fp8_bf16_forward:
         params["fp8_forward"] = False
+    if a.residual_bf16:
+        params["residual_fp32"] = False
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False                          # no .item() host syncs in the hot loop (train.py:178-183 does them)
@@ -736,7 +741,8 @@ def main():
                                        "; fp8 (e4m3) forward GEMMs of every encoder Linear, bf16 backward" if a.fp8_forward_only else
                                        "; every encoder Linear in fp8: forward e4m3 x e4m3, data gradient e5m2 x e4m3" +
                                        (", bf16 weight gradients" if a.fp8_bf16_wgrad else ", weight gradient e5m2 x e4m3"))
-                                      if a.dtype == "fp8" else ""),
+                                      if a.dtype == "fp8" else "") + ("; residual stream stored as bf16 (params['residual_fp32'] = False)" if a.residual_bf16 else ""),
+                          "residual_stream": "bf16" if a.residual_bf16 else "fp32",
                           "global_batch": a.batch * a.emulate_ranks * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                           "global_loss": global_loss, "input": a.input, "host_enqueue_ms_per_step": host_ms,
                           "sustained": sustained, "h2d_inclusive": h2d, "gradient_allreduce": comm, "site_policy": a.site_policy or None, "class_policy": a.class_policy or None,

@@ -96,6 +96,7 @@ class StepEngine(object):
         c.wgrad_overwrite = int(bool(step.get("wgrad_overwrite", False)))
         c.grads_bf16 = L.ptr(step.get("grads_bf16")) if c.wgrad_overwrite else None
         c.seed = int(step["seed"])
+        c.residual_fp32 = int(bool(step.get("residual_fp32", True)))
         c.g_nsp_dev, c.g_reg_dev, c.g_loss_dev = L.ptr(step.get("g_nsp")), L.ptr(step.get("g_reg")), L.ptr(step.get("g_loss"))
         f8 = step.get("fp8")
         if f8 is not None:          # (flat e4m3 weight shadow, weight scales, activation scales, activation amax): device tensors

@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
                 ("c_is_f32", c_i32), ("accumulate", c_i32), ("tile", c_i32), ("alpha", c_f32), ("drop_thr", c_u32),
                 ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64), ("rowsum_out", vp),
                 ("fp8", c_i32), ("scale_a", vp), ("scale_b", vp), ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("ld_q", c_i64),
-                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp)]
+                ("site", c_i32), ("split_k", c_i32), ("splitk_ws", vp), ("splitk_cnt", vp), ("addend_f32", c_i32), ("c_cached", c_i32)]
 
 
 class LaunchRec(C.Structure):
@@ -64,14 +64,14 @@ class Batch(C.Structure):
 class LnFwdArgs(C.Structure):
     _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("mean", vp), ("rstd", vp), ("M", c_i32), ("H", c_i32),
                 ("eps", c_f32), ("drop_thr", c_u32), ("drop_scale", c_f32), ("drop_site", c_u32), ("seed", c_u64),
-                ("q_out", vp), ("q_scale", vp), ("q_amax", vp)]
+                ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("x_f32", c_i32), ("y_f32", vp)]
 
 
 class LnBwdArgs(C.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("dx", vp), ("dx_lin", vp), ("partials", vp),
                 ("M", c_i32), ("H", c_i32), ("post_thr", c_u32), ("post_scale", c_f32), ("post_site", c_u32),
                 ("lin_thr", c_u32), ("lin_scale", c_f32), ("lin_site", c_u32), ("seed", c_u64),
-                ("q_out", vp), ("q_scale", vp), ("q_amax", vp)]
+                ("q_out", vp), ("q_scale", vp), ("q_amax", vp), ("x_f32", c_i32)]
 
 
 class AmpState(C.Structure):
@@ -94,7 +94,8 @@ class StepCfg(C.Structure):
                 ("seg_ready_events", vp), ("seg_done_events", vp),
                 ("fp8", c_i32), ("params_fp8", vp), ("fp8_w_scale", vp), ("fp8_act_scale", vp), ("fp8_act_amax", vp),
                 ("fp8_bwd", c_i32), ("fp8_wgrad", c_i32), ("params_fp8_t", vp), ("fp8_grad_scale", vp), ("fp8_grad_amax", vp),
-                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32), ("grads_bf16", vp)]
+                ("seg_enqueued", vp), ("seg_enqueued_user", vp), ("seg_done_mask", vp), ("wgrad_overwrite", c_i32), ("grads_bf16", vp),
+                ("residual_fp32", c_i32)]
 
 
 SEG_ENQUEUED_FN = C.CFUNCTYPE(None, C.c_int, vp)      # void (*seg_enqueued)(int seg, void* user)
@@ -138,6 +139,7 @@ PROTOTYPES = {
     "crct_softmax_rows_bf16_bf16": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "crct_layernorm_fwd_q": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, c_f32] + _u8 + [vp, vp, vp, vp]),
     "crct_layernorm_bwd_rows_args": (C.c_int, [C.POINTER(LnBwdArgs), vp]),
+    "crct_layernorm_fwd_args": (C.c_int, [C.POINTER(LnFwdArgs), vp]),
     "crct_fp8_transpose_weights": (C.c_int, [vp] * 6 + [C.c_int, c_i64, C.c_int, vp]),
     "crct_fp8_quantize_bf16": (C.c_int, [vp, vp, vp, vp, c_i64, vp]),
     "crct_fp8_update_scales": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, c_f32, vp]),

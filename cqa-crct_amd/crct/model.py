@@ -117,6 +117,10 @@ class CrctModel(nn.Module):
         # median gradient cosine 0.90 forward-only, 0.88 with everything; block scaling does not change it), while fp8 data and weight
         # gradients behind an unrounded forward cost ~0.01: this mode keeps most of the speed (backward is 2/3 of the GEMM work).
         self.fp8_forward = bool(params.get("fp8_forward", True)) if params else True
+        # params['residual_fp32'] (default on, round 6): the encoder's residual stream is carried in fp32 like the reference's autocast path
+        # carries it -- pre-LayerNorm sums and the residual copy of every LayerNorm output; GEMM operands stay bf16 (CrctStepCfg.residual_fp32).
+        # False = rounds 1 - 5: both stored as bf16, which is what cost the bf16 path most of its gradient-cosine deficit.
+        self.residual_fp32 = bool(params.get("residual_fp32", True)) if params else True
         self._fp8 = None
         self._entries = {e.name: e for e in self.table}
         self._build_tree()
@@ -566,7 +570,7 @@ class CrctModel(nn.Module):
         step = dict(training=self.training, use_l1=bool(p["L1"]), kind_l1=(kind == "L1"), tol_margin=float(p["tol_margin"]),
                     nsp_coeff=float(p.get("nsp_loss_coeff", 1.0)), reg_coeff=float(p.get("reg_loss_coeff", 1.0)),
                     seed=(self._seed + self._calls * 7919 + int(p.get("rank", 0)) * 104729) & 0x3FFFFFFFFFFFFFFF,
-                    seg_events=self._param_events)
+                    seg_events=self._param_events, residual_fp32=self.residual_fp32)
         self._param_events = None
         dev = self._flat_p.device
         if self.fp8 and not self.fp8_forward and not self.fp8_wgrad:

@@ -32,7 +32,9 @@ def _drop(p, site):
 
 def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=None, ldc=None, bias=None, act="none",
                preact_out=None, dact_src=None, dact="none", ld_aux=None, addend=None, ld_add=None, out_f32=False,
-               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0):
+               accumulate=False, tile=-1, alpha=1.0, p_drop=0.0, site=0, seed=0, rowsum_out=None, split_k=0, model_site=0, c_cached=False):
+    """addend may be bf16 or fp32 (the fp32 residual stream: CrctGemmArgs.addend_f32); c_cached: an fp32 output that the next kernel
+    reads (ordinary instead of streaming stores)."""
     _chk(A, torch.bfloat16), _chk(B, torch.bfloat16)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
@@ -49,6 +51,8 @@ def _gemm_args(g, A, B, M, N, K, ta=False, tb=False, lda=None, ldb=None, out=Non
     g.seed = seed
     g.rowsum_out = L.ptr(rowsum_out)
     g.site = int(model_site)
+    g.addend_f32 = int(addend is not None and addend.dtype == torch.float32)
+    g.c_cached = int(bool(c_cached))
     if split_k and split_k > 1:       # K-partitioned launch: slab space + ticket words (zero before the first use) per device
         ws, cnt = _splitk_space(A.device, M, N, split_k)
         g.split_k, g.splitk_ws, g.splitk_cnt = int(split_k), L.ptr(ws), L.ptr(cnt)
@@ -148,13 +152,22 @@ def gemm_wgrad_fp8(problems, accumulate=True, tile=-1):
         L.check(lib.crct_gemm_bf16_grouped(arr, len(problems), L.current_stream()), "gemm_wgrad_fp8 (grouped)")
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-12, p_drop=0.0, site=0, seed=0):
+def layernorm_fwd(x, gamma, beta, eps=1e-12, p_drop=0.0, site=0, seed=0, y_f32=False):
+    """x bf16 or fp32 [M, H] (fp32: the pre-LayerNorm sums of the fp32 residual stream); y_f32: also return y as fp32 (4th result)."""
     lib = L.load()
     M, H = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty(M, H, device=x.device, dtype=torch.bfloat16)
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     thr, sc, st = _drop(p_drop, site)
+    if x.dtype == torch.float32 or y_f32:
+        y32 = torch.empty(M, H, device=x.device, dtype=torch.float32) if y_f32 else None
+        a = L.LnFwdArgs()
+        a.x, a.gamma, a.beta, a.y, a.mean, a.rstd = L.ptr(_chk(x)), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd)
+        a.M, a.H, a.eps, a.drop_thr, a.drop_scale, a.drop_site, a.seed = M, H, eps, thr, sc, st, seed
+        a.x_f32, a.y_f32 = int(x.dtype == torch.float32), L.ptr(y32)
+        L.check(lib.crct_layernorm_fwd_args(C.byref(a), L.current_stream()), "layernorm_fwd")
+        return (y, mean, rstd, y32) if y_f32 else (y, mean, rstd)
     L.check(lib.crct_layernorm_fwd(L.ptr(_chk(x, torch.bfloat16)), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
                                    M, H, eps, thr, sc, st, seed, L.current_stream()), "layernorm_fwd")
     return y, mean, rstd
@@ -164,8 +177,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, want_lin=False, p_lin=0.0, lin_site=
                   dgamma=None, dbeta=None, dbias=None, accumulate=False):
     lib = L.load()
     M, H = x.shape
-    dx = torch.empty_like(x)
-    dxl = torch.empty_like(x) if want_lin else None
+    dx = torch.empty_like(dy)
+    dxl = torch.empty_like(dy) if want_lin else None
     nb = lib.crct_layernorm_bwd_blocks(M)
     part = torch.empty(3 * 4 * nb * H, device=x.device, dtype=torch.float32)       # one partial row per wave
     dgamma = torch.zeros(H, device=x.device) if dgamma is None else dgamma
@@ -173,6 +186,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, want_lin=False, p_lin=0.0, lin_site=
     dbias = torch.zeros(H, device=x.device) if dbias is None else dbias
     pt, ps, psite = _drop(p_post, post_site)
     lt, ls, lsite = _drop(p_lin, lin_site)
+    if x.dtype == torch.float32:      # the saved pre-norm rows of the fp32 residual stream: rows pass from the struct, then the column pass
+        a = L.LnBwdArgs()
+        a.dy, a.x, a.mean, a.rstd, a.gamma, a.dx, a.dx_lin, a.partials = (L.ptr(_chk(dy, torch.bfloat16)), L.ptr(x), L.ptr(mean), L.ptr(rstd),
+                                                                            L.ptr(gamma), L.ptr(dx), L.ptr(dxl), L.ptr(part))
+        a.M, a.H, a.post_thr, a.post_scale, a.post_site, a.lin_thr, a.lin_scale, a.lin_site, a.seed = M, H, pt, ps, psite, lt, ls, lsite, seed
+        a.x_f32 = 1
+        L.check(lib.crct_layernorm_bwd_rows_args(C.byref(a), L.current_stream()), "layernorm_bwd")
+        L.check(lib.crct_layernorm_bwd_finalize(L.ptr(part), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), M, H, int(accumulate), L.current_stream()),
+                "layernorm_bwd (finalize)")
+        return dx, dxl, dgamma, dbeta, dbias
     L.check(lib.crct_layernorm_bwd(L.ptr(_chk(dy, torch.bfloat16)), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dx), L.ptr(dxl),
                                    L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias), L.ptr(part), M, H, int(accumulate),
                                    pt, ps, psite, lt, ls, lsite, seed, L.current_stream()), "layernorm_bwd")

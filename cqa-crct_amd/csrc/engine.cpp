@@ -41,7 +41,7 @@ void crct_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crct_last_error(void) { return g_err; }
-extern "C" int crct_abi_version(void) { return 6; }
+extern "C" int crct_abi_version(void) { return 7; }
 
 extern "C" int crct_gemm_bf16(const CrctGemmArgs* a, crct_stream_t stream) {
   CRCT_REQUIRE(a != nullptr, "gemm: null args");
@@ -98,8 +98,10 @@ struct SelfLayerP { LinearP qkv; ProjP proj; FfnP ffn; int H, heads; float p_att
 struct ConnLayerP { LinearP qkv1, qkv2; ProjP proj_v, proj_t; FfnP ffn_v, ffn_t; uint32_t site; };
 
 // ---- activation offsets (bytes into the workspace)
-struct FfnA { size_t u, h, s, y, mean, rstd, hq, yq; int site_h, site_y; int g_dl, g_du; };      // g_*: gradient scale sites (fp8 backward)      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
-struct ProjA { size_t s, a, mean, rstd, aq; int site_a; int g_dl; };
+// s: the pre-LayerNorm sum, room for fp32 (the fp32 residual stream, CrctStepCfg.residual_fp32; bf16 in the first half otherwise);
+// y32 / a32: the fp32 copy of the LayerNorm output that the NEXT block's epilogue adds as its residual
+struct FfnA { size_t u, h, s, y, y32, mean, rstd, hq, yq; int site_h, site_y; int g_dl, g_du; };      // g_*: gradient scale sites (fp8 backward)      // hq / yq: e4m3 copies (fp8 forward), site_*: their scale slots
+struct ProjA { size_t s, a, a32, mean, rstd, aq; int site_a; int g_dl; };
 // ctxq / site_ctx: e4m3 copy of the attention context and its activation scale site; g_dqkv: gradient scale site of the fused dqkv buffer
 // lse*: softmax row statistics [B][heads][Tq] fp32 the long-sequence attention forward leaves for its backward (CrctAttnQuant.row_lse)
 struct SelfLayerA { size_t qkv, ctx, ctxq, lse; int site_ctx, g_dqkv; ProjA proj; FfnA ffn; };
@@ -139,6 +141,7 @@ struct crct_engine {
   int sk_tickets = 0;
   // fp8 forward (BASELINE configs[4]): scale slot of every Linear weight that has an e4m3 shadow, number of activation scale sites
   std::unordered_map<int64_t, int> wq_slot;
+  std::unordered_map<size_t, size_t> res32;      // workspace offset of a LayerNorm's bf16 output -> offset of its fp32 copy (fp32 residual stream)
   std::vector<std::pair<int64_t, int64_t>> wq_list;      // slot -> (flat offset, numel)
   int n_sites = 0;
   int n_gsites = 0;                    // gradient scale sites of the fp8 backward (CrctStepCfg.fp8_grad_scale / _amax)
@@ -206,7 +209,7 @@ LinearP fused3(crct_engine* e, const std::string& a, const std::string& b, const
 FfnA ffn_a(Arena& ar, size_t M, int H, int I, int& sites, int& gsites) {
   FfnA a;
   a.g_dl = gsites++; a.g_du = gsites++;
-  a.u = ar.take(M * I * 2); a.h = ar.take(M * I * 2); a.s = ar.take(M * H * 2); a.y = ar.take(M * H * 2);
+  a.u = ar.take(M * I * 2); a.h = ar.take(M * I * 2); a.s = ar.take(M * H * 4); a.y = ar.take(M * H * 2); a.y32 = ar.take(M * H * 4);
   a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
   a.hq = ar.take(M * I); a.yq = ar.take(M * H);
   a.site_h = sites++; a.site_y = sites++;
@@ -215,7 +218,7 @@ FfnA ffn_a(Arena& ar, size_t M, int H, int I, int& sites, int& gsites) {
 ProjA proj_a(Arena& ar, size_t M, int H, int& sites, int& gsites) {
   ProjA a;
   a.g_dl = gsites++;
-  a.s = ar.take(M * H * 2); a.a = ar.take(M * H * 2); a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
+  a.s = ar.take(M * H * 4); a.a = ar.take(M * H * 2); a.a32 = ar.take(M * H * 4); a.mean = ar.take(M * 4); a.rstd = ar.take(M * 4);
   a.aq = ar.take(M * H);
   a.site_a = sites++;
   return a;
@@ -324,6 +327,7 @@ struct Run {
   struct Opt {
     const float* bias = nullptr; void* preact = nullptr; const void* dact_src = nullptr; int dact = 0; int act = 0;
     const void* addend = nullptr; int64_t ld_aux = 0, ld_add = 0; Drop drop; bool f32 = false; bool acc = false;
+    bool add_f32 = false, c_cached = false;      // the fp32 residual stream: fp32 addend; fp32 output that the next kernel reads
     int site = 0;
     void* q_out = nullptr; const float* q_scale = nullptr; float* q_amax = nullptr; int64_t ld_q = 0;      // fp8 copy of the result (calibration passes):
     bool q_e4m3 = false;                                                                                   // e5m2 (a gradient) unless q_e4m3 (an activation)
@@ -339,7 +343,7 @@ struct Run {
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
-    g.site = o.site;
+    g.site = o.site; g.addend_f32 = o.add_f32; g.c_cached = o.c_cached;
     if (o.q_out) { g.q_out = o.q_out; g.q_scale = o.q_scale; g.q_amax = o.q_amax; g.ld_q = o.ld_q; g.fp8 = o.q_e4m3 ? 0 : 4; }      // bf16 GEMM + fp8 copy of its result
     if (!ta && st == s && o.site > 0 && o.site < CRCT_SITE_COUNT) {      // forward / data gradient on the data stream: the site's policy
       const crct_engine::SitePolicy& pol = e->policy[o.site][tb ? 1 : 0][phase];
@@ -418,6 +422,7 @@ struct Run {
     g.lda = l.in; g.ldb = l.in; g.ldc = ldy; g.ld_aux = o.ld_aux; g.ld_add = o.ld_add;
     g.M = M; g.N = l.out; g.K = l.in; g.act = o.act; g.dact = o.dact; g.c_is_f32 = o.f32; g.accumulate = o.acc;
     g.tile = -1; g.alpha = 1.0f; g.drop_thr = o.drop.thr; g.drop_scale = o.drop.scale; g.drop_site = o.drop.site; g.seed = c->seed;
+    g.addend_f32 = o.add_f32; g.c_cached = o.c_cached;
     g.fp8 = 1; g.scale_a = c->fp8_act_scale + site_in; g.scale_b = c->fp8_w_scale + e->wq_slot.at(l.w); g.site = l.site;
     if (l.site > 0 && l.site < CRCT_SITE_COUNT && e->policy[l.site][0][phase].cfg >= 0) g.tile = e->policy[l.site][0][phase].cfg;
     if (site_out >= 0) { g.q_out = W<uint8_t>(hq); g.ld_q = l.out; g.q_scale = c->fp8_act_scale + site_out; g.q_amax = c->fp8_act_amax + (int64_t)site_out * CRCT_FP8_AMAX_LANES; }
@@ -508,14 +513,23 @@ struct Run {
   void ln_fwd(size_t x, const LnP& ln, size_t y, size_t mean, size_t rstd, int M, int H, size_t yq, int site) {
     if (rc) return;
     ++tick;
-    CrctLnFwdArgs a = {A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, nullptr, nullptr, nullptr};
+    CrctLnFwdArgs a = {A(x), P(ln.g), P(ln.b), A(y), F(mean), F(rstd), M, H, 1e-12f, 0, 1.f, 0, c->seed, nullptr, nullptr, nullptr, 0, nullptr};
+    if (r32()) { a.x_f32 = 1; a.y_f32 = F(e->res32.at(y)); }
     if (f8()) { a.q_out = W<uint8_t>(yq); a.q_scale = c->fp8_act_scale + site; a.q_amax = c->fp8_act_amax + (int64_t)site * CRCT_FP8_AMAX_LANES; }
     fail(launch_ln_fwd(a, s));
   }
-  static int launch_ln_fwd(const CrctLnFwdArgs& a, hipStream_t st) {
-    if (a.q_out) return crct_layernorm_fwd_q(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale,
-                                             a.drop_site, a.seed, a.q_out, a.q_scale, a.q_amax, st);
-    return crct_layernorm_fwd(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale, a.drop_site, a.seed, st);
+  static int launch_ln_fwd(const CrctLnFwdArgs& a, hipStream_t st) { return crct_layernorm_fwd_args(&a, st); }
+  // The fp32 residual stream (CrctStepCfg.residual_fp32): the pre-LayerNorm sums are written and read as fp32, and every block adds
+  // the fp32 copy of its input where the producing LayerNorm left one (the embeddings' outputs have none: bf16 there, one rounding)
+  bool r32() const { return c->residual_fp32 != 0; }
+  void residual(Opt& o, size_t x, int64_t ld) const {
+    o.ld_add = ld;
+    if (r32()) {
+      o.f32 = true; o.c_cached = true;
+      auto it = e->res32.find(x);
+      if (it != e->res32.end()) { o.addend = F(it->second); o.add_f32 = true; return; }
+    }
+    o.addend = A(x);
   }
   static int launch_ln_bwd(const CrctLnBwdArgs& a, hipStream_t st) { return crct_layernorm_bwd_rows_args(&a, st); }
   // returns the buffer that holds the gradient of the producing Linear's output
@@ -526,7 +540,7 @@ struct Run {
     // weight-gradient work on the side stream -- `part` belongs to this layer's scratch set
     ++tick;
     CrctLnBwdArgs a = {A(dy), A(x), F(mean), F(rstd), P(ln.g), A(dres), dr.thr ? A(dlin) : nullptr, F(part), M, H,
-                       0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, nullptr, nullptr, nullptr};
+                       0, 1.f, 0, dr.thr, dr.scale, dr.site, c->seed, nullptr, nullptr, nullptr, r32() ? 1 : 0};
     if (g_site >= 0 && f8b() && f8b_lin(lin)) { a.q_out = W<uint8_t>(dlq); a.q_scale = gscale(g_site); a.q_amax = gamax(g_site); }
     fail(launch_ln_bwd(a, s));
     // the column pass is queued like the weight gradients: ONE ordering event per layer covers all of them
@@ -572,7 +586,7 @@ struct Run {
   // a = LN(dropout(dense(ctx)) + x)          vilbert.py:424-428 / :555-559 / :749-756
   // ctxq / site_ctx: the e4m3 copy of ctx the attention kernel wrote (-1: none, the projection runs in bf16)
   void proj_fwd(const ProjP& p, const ProjA& a, size_t ctx, size_t x, int M, const Drop& dr, size_t ctxq = (size_t)-1, int site_ctx = -1) {
-    Opt o; o.drop = dr; o.addend = A(x); o.ld_add = p.dense.out;
+    Opt o; o.drop = dr; residual(o, x, p.dense.out);
     if (site_ctx >= 0 && f8_lin(p.dense)) lin_fwd_f8(A(ctx), ctxq, site_ctx, p.dense, M, A(a.s), p.dense.out, o);
     else lin_fwd(A(ctx), p.dense.in, p.dense, M, A(a.s), p.dense.out, o);
     ln_fwd(a.s, p.ln, a.a, a.mean, a.rstd, M, p.dense.out, a.aq, a.site_a);
@@ -595,7 +609,7 @@ struct Run {
     const bool q_up = f8_lin(p.up), q_dn = f8_lin(p.down);
     if (q_up) lin_fwd_f8(A(x), xq, site_x, p.up, M, A(a.h), p.up.out, o, a.hq, q_dn ? a.site_h : -1);
     else lin_fwd(A(x), p.up.in, p.up, M, A(a.h), p.up.out, o);
-    Opt o2; o2.drop = dr; o2.addend = A(x); o2.ld_add = p.down.out;
+    Opt o2; o2.drop = dr; residual(o2, x, p.down.out);
     if (q_up && q_dn) lin_fwd_f8(A(a.h), a.hq, a.site_h, p.down, M, A(a.s), p.down.out, o2);
     else lin_fwd(A(a.h), p.down.in, p.down, M, A(a.s), p.down.out, o2);
     ln_fwd(a.s, p.ln, a.y, a.mean, a.rstd, M, p.down.out, a.yq, a.site_y);
@@ -1116,6 +1130,13 @@ extern "C" crct_engine_t* crct_engine_create(const CrctModelDims* dims, const ch
     for (int k = 0; k < 2; ++k) e->sk_ws[k] = ar.take(e->sk_ws_elems[k] * 4);
     e->sk_cnt[0] = ar.take((size_t)2 * e->sk_tickets * 4);      // [text | visual] in one block: one memset per call
     e->sk_cnt[1] = e->sk_cnt[0] + (size_t)e->sk_tickets * 4;
+  }
+  {
+    auto reg_ffn = [&](const FfnA& a) { e->res32[a.y] = a.y32; };
+    auto reg_proj = [&](const ProjA& a) { e->res32[a.a] = a.a32; };
+    for (const SelfLayerA& a : e->tla) { reg_proj(a.proj); reg_ffn(a.ffn); }
+    for (const SelfLayerA& a : e->vla) { reg_proj(a.proj); reg_ffn(a.ffn); }
+    for (const ConnLayerA& a : e->cla) { reg_proj(a.proj_v); reg_proj(a.proj_t); reg_ffn(a.ffn_v); reg_ffn(a.ffn_t); }
   }
   e->ws_bytes = ar.top;
 

@@ -307,7 +307,10 @@ __device__ __forceinline__ void gemm_epilogue(const CrctGemmArgs& g, f4_t (&acc)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * dscale : 0.f;
       }
-      if (g.addend) {       // residual / upstream-gradient add (bf16)
+      if (g.addend && g.addend_f32) {       // the fp32 residual stream (CrctGemmArgs.addend_f32)
+        const float4 s = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.addend) + (long)m * g.ld_add + n);
+        v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+      } else if (g.addend) {       // residual / upstream-gradient add (bf16)
         const uint2 s = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.addend) + (long)m * g.ld_add + n);
         v[0] += bf2f((bf16_t)(s.x & 0xffff));
         v[1] += bf2f((bf16_t)(s.x >> 16));
@@ -486,7 +489,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * dscale : 0.f;
       }
-      if (g.addend) {
+      if (g.addend && g.addend_f32) {       // the fp32 residual stream (CrctGemmArgs.addend_f32)
+        const float4* ap = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.addend) + (long)m * g.ld_add + n);
+        const float4 s0 = ap[0], s1 = ap[1];
+        v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+      } else if (g.addend) {
         const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(g.addend) + (long)m * g.ld_add + n);
         const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
@@ -514,6 +521,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const CrctGemmArgs& g_in, f
 #if CRCT_GEMM_NT_F32   // fp32 outputs are weight gradients: written once per step, read by AdamW / the all-reduce much later
         f4_t* dst = reinterpret_cast<f4_t*>(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n);
         f4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        if (g.c_cached) {         // ... or pre-LayerNorm sums of the fp32 residual stream, which the next kernel reads: ordinary stores
+          dst[0] = o0; dst[1] = o1;
+          continue;
+        }
         if (g.accumulate) {
           o0 += __builtin_nontemporal_load(dst);
           o1 += __builtin_nontemporal_load(dst + 1);

@@ -4,6 +4,8 @@
 // registers, so a row is read once and written once.  Statistics are fp32.
 // Reference arithmetic: BertLayerNorm vilbert.py:281-294; BertEmbeddingLocation :320-358;
 // BertImageEmbeddings :1474-1496.
+#include <type_traits>
+
 #include "common.hip.h"
 #include "crct_internal.h"
 
@@ -52,6 +54,27 @@ __device__ __forceinline__ void row_unpack_bf16(Row<NCH>& r, const RawRow<NCH>& 
     r.v[i][2] = bf2f((bf16_t)(y & 0xffff)); r.v[i][3] = bf2f((bf16_t)(y >> 16));
     r.v[i][4] = bf2f((bf16_t)(z & 0xffff)); r.v[i][5] = bf2f((bf16_t)(z >> 16));
     r.v[i][6] = bf2f((bf16_t)(w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(w >> 16));
+  }
+}
+// the same pair for fp32 rows (the pre-LayerNorm sums of the fp32 residual stream)
+template <int NCH>
+struct RawRowF { float4 a[NCH], b[NCH]; };
+template <int NCH>
+__device__ __forceinline__ void row_fetch_f32(RawRowF<NCH>& raw, const float* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = min((lane + 64 * i) * 8, H - 8);
+    raw.a[i] = *reinterpret_cast<const float4*>(p + c);
+    raw.b[i] = *reinterpret_cast<const float4*>(p + c + 4);
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void row_unpack_f32(Row<NCH>& r, const RawRowF<NCH>& raw, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float m = (lane + 64 * i) * 8 < H ? 1.f : 0.f;
+    r.v[i][0] = raw.a[i].x * m; r.v[i][1] = raw.a[i].y * m; r.v[i][2] = raw.a[i].z * m; r.v[i][3] = raw.a[i].w * m;
+    r.v[i][4] = raw.b[i].x * m; r.v[i][5] = raw.b[i].y * m; r.v[i][6] = raw.b[i].z * m; r.v[i][7] = raw.b[i].w * m;
   }
 }
 template <int NCH>
@@ -540,6 +563,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
 struct LnFwdP {
   const bf16_t* x; const float* gamma; const float* beta; bf16_t* y; float* mean_o; float* rstd_o; int M, H; float eps;
   uint32_t thr; float scale; uint32_t site; uint64_t seed; uint8_t* q_out; const float* q_scale; float* q_amax;
+  int x_f32; float* y_f32;      // the fp32 residual stream: x is fp32 [M][H]; also write y as fp32 (CrctLnFwdArgs)
 };
 template <int NCH>
 __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, const int nblk) {
@@ -553,11 +577,13 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, cons
   const long stride = (long)nblk * ROWS_PER_BLOCK;
   for (long row = (long)blk * ROWS_PER_BLOCK + wave; row < M; row += stride) {
     Row<NCH> r;
-    row_load_bf16(r, a.x + row * H, H, lane);
+    if (a.x_f32) row_load_f32(r, reinterpret_cast<const float*>(a.x) + row * H, H, lane);
+    else row_load_bf16(r, a.x + row * H, H, lane);
     float mean, rstd;
     row_stats(r, H, lane, a.eps, mean, rstd);
     row_normalize(r, g, b, H, lane, mean, rstd, row, a.thr, a.scale, a.site, a.seed);
     row_store_bf16(r, a.y + row * H, H, lane);
+    if (a.y_f32) row_store_f32(r, a.y_f32 + row * H, H, lane);
     if (a.q_out) amax = fmaxf(amax, row_store_fp8(r, a.q_out + row * H, H, lane, qs));     // the fp8 GEMMs' operand (BASELINE configs[4])
     if (lane == 0) { a.mean_o[row] = mean; a.rstd_o[row] = rstd; }
   }
@@ -588,7 +614,8 @@ struct LnBwdP {
   uint32_t lin_site; uint64_t seed;
   uint8_t* q_out; const float* q_scale; float* q_amax;       // optional e5m2 copy of the gradient the producing Linear's dgrad reads (dxl if given, else dx)
 };
-template <int NCH, bool COMBINE>
+// X32: x (the saved pre-LayerNorm rows) is fp32 -- the fp32 residual stream (CrctLnBwdArgs.x_f32)
+template <int NCH, bool COMBINE, bool X32>
 __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, const int nblk) {
   const bf16_t* __restrict__ dy_p = a.dy; const bf16_t* __restrict__ x_p = a.x;
   const float* __restrict__ mean_p = a.mean; const float* __restrict__ rstd_p = a.rstd; const float* __restrict__ gamma = a.gamma;
@@ -606,21 +633,26 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, cons
   // M / (4 x grid) is 1.6 rows per wave at the CRCT sizes: the second row's loads are issued before the first row is worked on
   const long stride = (long)nblk * ROWS_PER_BLOCK;
   long row = (long)blk * ROWS_PER_BLOCK + wave;
-  RawRow<NCH> dy_n, x_n;
+  RawRow<NCH> dy_n;
+  typename std::conditional<X32, RawRowF<NCH>, RawRow<NCH>>::type x_n;
+  const float* __restrict__ x32_p = reinterpret_cast<const float*>(a.x);
   float mean_n = 0.f, rstd_n = 0.f;
   if (row < M) {
     row_fetch_bf16(dy_n, dy_p + row * H, H, lane);
-    row_fetch_bf16(x_n, x_p + row * H, H, lane);
+    if constexpr (X32) row_fetch_f32(x_n, x32_p + row * H, H, lane);
+    else row_fetch_bf16(x_n, x_p + row * H, H, lane);
     mean_n = mean_p[row]; rstd_n = rstd_p[row];
   }
   for (; row < M; row += stride) {
     Row<NCH> dy, x;
     const float mean = mean_n, rstd = rstd_n;
     row_unpack_bf16(dy, dy_n, H, lane);
-    row_unpack_bf16(x, x_n, H, lane);
+    if constexpr (X32) row_unpack_f32(x, x_n, H, lane);
+    else row_unpack_bf16(x, x_n, H, lane);
     if (row + stride < M) {
       row_fetch_bf16(dy_n, dy_p + (row + stride) * H, H, lane);
-      row_fetch_bf16(x_n, x_p + (row + stride) * H, H, lane);
+      if constexpr (X32) row_fetch_f32(x_n, x32_p + (row + stride) * H, H, lane);
+      else row_fetch_bf16(x_n, x_p + (row + stride) * H, H, lane);
       mean_n = mean_p[row + stride]; rstd_n = rstd_p[row + stride];
     }
     row_apply_dropmask(dy, H, lane, row, post_thr, post_scale, post_site, seed);
@@ -660,12 +692,12 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdP& a, const int blk, cons
   }
 }
 
-template <int NCH, bool COMBINE>
+template <int NCH, bool COMBINE, bool X32 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd, const float* gamma, int M, int H,
                                                        bf16_t* dx, bf16_t* dxl, const LnBwdP a_in) {
   LnBwdP a = a_in;
   a.dy = dy; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.M = M; a.H = H; a.dx = dx; a.dxl = dxl;
-  ln_bwd_body<NCH, COMBINE>(a, blockIdx.x, gridDim.x);
+  ln_bwd_body<NCH, COMBINE, X32>(a, blockIdx.x, gridDim.x);
 }
 #define LN_BWD_HOT(p) (p).dy, (p).x, (p).mean, (p).rstd, (p).gamma, (p).M, (p).H, (p).dx, (p).dxl,
 
@@ -1083,7 +1115,7 @@ extern "C" {
 
 static LnFwdP ln_fwd_problem(const CrctLnFwdArgs& a) {
   return LnFwdP{(const bf16_t*)a.x, a.gamma, a.beta, (bf16_t*)a.y, a.mean, a.rstd, a.M, a.H, a.eps, a.drop_thr, a.drop_scale,
-                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax};
+                a.drop_site, a.seed, (uint8_t*)a.q_out, a.q_scale, a.q_amax, a.x_f32, a.y_f32};
 }
 static int ln_fwd_check(const CrctLnFwdArgs& a) {
   CRCT_REQUIRE(a.H % 8 == 0 && a.H > 0, "layernorm: H=%d must be a positive multiple of 8", a.H);
@@ -1102,15 +1134,19 @@ static int ln_fwd_launch(const CrctLnFwdArgs& a, hipStream_t s) {
 int crct_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int M, int H, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site,
                        uint64_t seed, crct_stream_t stream) {
-  const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, nullptr, nullptr, nullptr};
+  const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, nullptr, nullptr, nullptr, 0, nullptr};
   return ln_fwd_launch(a, (hipStream_t)stream);
+}
+int crct_layernorm_fwd_args(const CrctLnFwdArgs* a, crct_stream_t stream) {
+  CRCT_REQUIRE(a, "layernorm_fwd_args: null argument");
+  return ln_fwd_launch(*a, (hipStream_t)stream);
 }
 
 int crct_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int M, int H, float eps, uint32_t drop_thr, float drop_scale, uint32_t drop_site,
                          uint64_t seed, void* q_out, const float* q_scale, float* q_amax, crct_stream_t stream) {
   CRCT_REQUIRE(q_out && q_scale, "layernorm_fwd_q: q_out and q_scale are required");
-  const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, q_out, q_scale, q_amax};
+  const CrctLnFwdArgs a = {x, gamma, beta, y, mean, rstd, M, H, eps, drop_thr, drop_scale, drop_site, seed, q_out, q_scale, q_amax, 0, nullptr};
   return ln_fwd_launch(a, (hipStream_t)stream);
 }
 
@@ -1137,7 +1173,13 @@ static int ln_bwd_launch(const CrctLnBwdArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int nb = crct_layernorm_bwd_blocks(a.M);
   const LnBwdP p = ln_bwd_problem(a);
-  if (ln_bwd_combines(a.H)) {
+  if (a.x_f32) {
+    if (ln_bwd_combines(a.H)) {
+      DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, true, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, LN_BWD_HOT(p) p));
+    } else {
+      DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, false, true>), dim3(nb), dim3(256), 0, s, LN_BWD_HOT(p) p));
+    }
+  } else if (ln_bwd_combines(a.H)) {
     DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, true>), dim3(nb), dim3(256), (size_t)3 * ROWS_PER_BLOCK * a.H * 4, s, LN_BWD_HOT(p) p));
   } else {
     DISPATCH_NCH(a.H, crct_launch((ln_bwd_kernel<NCH, false>), dim3(nb), dim3(256), 0, s, LN_BWD_HOT(p) p));
@@ -1150,7 +1192,7 @@ int crct_layernorm_bwd_rows(const void* dy, const void* x, const float* mean, co
                             uint32_t post_site, uint32_t lin_thr, float lin_scale, uint32_t lin_site, uint64_t seed,
                             crct_stream_t stream) {
   const CrctLnBwdArgs a = {dy, x, mean, rstd, gamma, dx, dx_lin, partials, M, H, post_thr, post_scale, post_site, lin_thr, lin_scale,
-                           lin_site, seed, nullptr, nullptr, nullptr};
+                           lin_site, seed, nullptr, nullptr, nullptr, 0};
   return ln_bwd_launch(a, (hipStream_t)stream);
 }
 int crct_layernorm_bwd_rows_args(const CrctLnBwdArgs* a, crct_stream_t stream) {

@@ -78,6 +78,10 @@ typedef struct CrctGemmArgs {
    * stream-ordered.  0 / 1 = off.  Not with ta (weight gradients), rowsum_out or fp8. */
   int32_t split_k;
   float* splitk_ws; uint32_t* splitk_cnt;
+  /* The fp32 residual stream of the step engine (CrctStepCfg.residual_fp32): addend_f32 != 0 -> `addend` is fp32 [M][ld_add] (the previous
+   * LayerNorm's fp32 output copy) instead of bf16; c_cached != 0 with c_is_f32 (and accumulate == 0) -> C is an activation (the
+   * pre-LayerNorm sum, read by the next kernel) and is written with ordinary instead of streaming stores.  ld_add % 8 == 0 either way. */
+  int32_t addend_f32, c_cached;
 } CrctGemmArgs;
 
 /* GEMM sites of the step.  The FFN group of BASELINE.md section 4 ("fraction of the FFN-GEMM roofline") = the four *_FFN_* sites. */
@@ -191,7 +195,12 @@ typedef struct CrctLnFwdArgs {
   const void* x; const float* gamma; const float* beta; void* y; float* mean; float* rstd;
   int32_t M, H; float eps; uint32_t drop_thr; float drop_scale; uint32_t drop_site; uint64_t seed;
   void* q_out; const float* q_scale; float* q_amax;
+  /* The fp32 residual stream (CrctStepCfg.residual_fp32): x_f32 != 0 -> x is fp32 [M][H] (the pre-LayerNorm sum as the GEMM epilogue
+   * left it, CrctGemmArgs.c_cached); y_f32 != NULL -> y is ALSO written as fp32 [M][H] (the next block's residual addend,
+   * CrctGemmArgs.addend_f32).  The bf16 y stays what GEMMs read. */
+  int32_t x_f32; float* y_f32;
 } CrctLnFwdArgs;
+int crct_layernorm_fwd_args(const CrctLnFwdArgs* a, crct_stream_t stream);
 
 /* Every amax "value" below and in CrctGemmArgs / CrctStepCfg / CrctFp8Shadow is CRCT_FP8_AMAX_LANES consecutive fp32 words
  * (the kernels spread their atomic maxima over them; crct_fp8_update_scales takes the maximum of the words): an amax array
@@ -257,6 +266,7 @@ typedef struct CrctLnBwdArgs {
    * (dx_lin when given, else dx), quantised as q = g * *q_scale (saturating at +-57344), max |g| max-ed into *q_amax
    * (CRCT_FP8_AMAX_LANES words): the A operand of that Linear's fp8 data-gradient GEMM. */
   void* q_out; const float* q_scale; float* q_amax;
+  int32_t x_f32;            /* x (the saved pre-norm rows) is fp32 [M][H]: the fp32 residual stream */
 } CrctLnBwdArgs;
 int crct_layernorm_bwd_rows_args(const CrctLnBwdArgs* a, crct_stream_t stream);      /* crct_layernorm_bwd_rows from the struct (incl. q_out) */
 int crct_layernorm_bwd_finalize(const float* partials, float* dgamma, float* dbeta, float* dbias_lin,
@@ -601,6 +611,13 @@ typedef struct CrctStepCfg {
                                 rounded to bf16 by the GEMM epilogue, and NOT into grads_f32 -- the exchange need not pack them (1.4 GB
                                 of traffic per step less) and the weight-gradient GEMMs write half the bytes.  Every other gradient
                                 still goes to grads_f32. */
+  int32_t residual_fp32;     /* forward AND backward of one step alike.  != 0: the residual stream of the encoder is carried in fp32, as
+                                the reference's autocast path carries it (vilbert.py:424-428 etc. add in fp32 there: the custom LayerNorm
+                                runs in fp32): the pre-LayerNorm sums (Linear output + dropout + residual) are written and read as fp32, and
+                                every LayerNorm also leaves an fp32 copy of its output for the next block's residual add; GEMM operands
+                                stay bf16.  0: both are stored as bf16 (rounds 1 - 5).  Measured on the CPU oracle: storing them as bf16 is
+                                what costs the bf16 path its gradient fidelity beyond the bf16-autocast yardstick (median cosine deficit
+                                x 5 - 10 on ordinary draws); gradients of the stream stay bf16 -- rounding THEM changes nothing. */
 } CrctStepCfg;
 
 int crct_engine_forward(crct_engine_t*, const float* params_f32, const void* params_bf16,

@@ -273,6 +273,55 @@ def test_layernorm_fwd_bwd(M, H):
     assert rel_err(dg2, 2 * gr.grad) < 2e-3
 
 
+@pytest.mark.parametrize("M,H", [(1600, 768), (2880, 1024), (21, 64), (7, 2048), (9920, 768)])
+def test_layernorm_on_the_fp32_residual_stream(M, H):
+    """CrctLnFwdArgs.x_f32 / y_f32, CrctLnBwdArgs.x_f32: the pre-LayerNorm rows arrive as fp32 (the GEMM epilogue left them so), the output
+    is written as bf16 (GEMM operand) AND as fp32 (the next block's residual); the backward reads the fp32 rows.  Against the fp32 reference:
+    the fp32 output is exact to fp32 rounding, the bf16 one is its rounding, and the statistics are those of the UNROUNDED rows."""
+    x = rand(M, H, scale=2.0, seed=1) + 0.3            # fp32, not bf16-representable
+    gamma, beta = 1 + 0.1 * rand(H, seed=2), 0.1 * rand(H, seed=3)
+    y, mean, rstd, y32 = ops.layernorm_fwd(x, gamma, beta, y_f32=True)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = O.layer_norm(xr, gr, br)
+    assert float((y32 - yr).abs().max()) < 2e-5 * float(yr.abs().max())
+    assert torch.equal(y, y32.to(torch.bfloat16))
+    assert rel_err(mean, xr.mean(-1)) < 1e-6
+    # a bf16 input with the extra fp32 output, and an fp32 input without it
+    xb = bf(x)
+    yb, _, _, yb32 = ops.layernorm_fwd(xb, gamma, beta, y_f32=True)
+    assert torch.equal(yb, ops.layernorm_fwd(xb, gamma, beta)[0]) and torch.equal(yb, yb32.to(torch.bfloat16))
+    assert torch.equal(ops.layernorm_fwd(x, gamma, beta)[0], y)
+    dy = bf(rand(M, H, seed=4))
+    yr.backward(dy.float())
+    dx, dxl, dg, db, dbias = ops.layernorm_bwd(dy, x, mean, rstd, gamma, want_lin=True, p_lin=0.1, lin_site=3, seed=5)
+    assert dx.dtype == torch.bfloat16 and rel_err(dx, xr.grad) < 1e-2
+    assert rel_err(dg, gr.grad) < 2e-3 and rel_err(db, br.grad) < 2e-3
+    # the dropout-masked copy: same mask as the bf16-input kernel draws for (site, seed)
+    _, dxl_b, *_ = ops.layernorm_bwd(dy, xb, mean, rstd, gamma, want_lin=True, p_lin=0.1, lin_site=3, seed=5)
+    assert torch.equal(dxl == 0, dxl_b == 0) or float(((dxl == 0) != (dxl_b == 0)).float().mean()) < 1e-3      # exact zeros of dx aside
+
+
+def test_gemm_epilogue_on_the_fp32_residual_stream(gemm_path):
+    """CrctGemmArgs.addend_f32 / c_cached: y = dropout(x W^T + b) + r with r fp32 and y written as fp32 -- the attention-output and FFN-down
+    projections of the step (vilbert.py:424-428, :467-471) -- in the LDS-DMA kernel, the register-staged kernel and the split-K form."""
+    for M, N, K in ((1600, 768, 768), (1600, 768, 3072), (2880, 1024, 1024), (9920, 768, 3072), (100, 64, 72)):
+        x, w = bf(rand(M, K, seed=1)), bf(rand(N, K, scale=0.05, seed=2))
+        b, r = rand(N, seed=3), rand(M, N, seed=4)
+        ref = x.float() @ w.float().t() + b + r
+        out = ops.gemm(x, w, M, N, K, bias=b, addend=r, out_f32=True, c_cached=True)      # both kernels: the gemm_path fixture
+        assert out.dtype == torch.float32 and rel_err(out, ref) < 2e-3, (M, N, K)
+        if K % 64 == 0 and M >= 1600 and gemm_path == "pipelined":
+            o2 = ops.gemm(x, w, M, N, K, bias=b, addend=r, out_f32=True, c_cached=True, split_k=2)
+            assert rel_err(o2, ref) < 2e-3
+        # dropout in front of the fp32 residual: the mask of (site, seed) is the bf16 form's
+        o3 = ops.gemm(x, w, M, N, K, bias=b, addend=r, out_f32=True, c_cached=True, p_drop=0.1, site=7, seed=11)
+        o4 = ops.gemm(x, w, M, N, K, bias=b, addend=bf(r), p_drop=0.1, site=7, seed=11)
+        assert rel_err(o3, o4.float()) < 1e-2
+        kept = ((o3 - r).abs() > 0)
+        assert abs(float(kept.float().mean()) - 0.9) < 0.01
+
+
 def test_colsum_softmax_cast():
     x = bf(rand(1600, 3072, seed=1))
     assert rel_err(ops.colsum(x, 1600, 3072), x.float().sum(0)) < 1e-4

@@ -81,7 +81,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "symbol %s declared in include/crct_hip.h is not exported" % name
     assert set(L.PROTOTYPES) <= set(declared)
     handle = L.load()
-    assert handle.crct_abi_version() == 6
+    assert handle.crct_abi_version() == 7
 
 
 def test_shipped_library_carries_no_lab_hook():
@@ -96,10 +96,12 @@ def test_shipped_library_carries_no_lab_hook():
 
 def test_struct_mirrors_and_error_path():
     # sizes from the header's field lists (LP64)
-    assert C.sizeof(L.GemmArgs) == (7 * 8 + 5 * 8 + 10 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 5 * 8 + 8 + 4 + 4 + 8 + 8)     # ... seed, rowsum_out, fp8 (+pad), 5 pointers, ld_q, site, split_k, 2 pointers
+    assert C.sizeof(L.GemmArgs) == (7 * 8 + 5 * 8 + 10 * 4 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 5 * 8 + 8 + 4 + 4 + 8 + 8 + 4 + 4)     # ... seed, rowsum_out, fp8 (+pad), 5 pointers, ld_q, site, split_k, 2 pointers, addend_f32, c_cached
     assert C.sizeof(L.Batch) == 10 * 8 + 3 * 4 + 4 + 3 * 8 + 4 + 4      # ... B, T, V, pad, sep_indices, hist_len, image_mask, sep_stride, image_feat_bf16
     assert C.sizeof(L.ModelDims) == 16 * 4 + 64 * 4 + 2 * 4 + 5 * 4
-    assert C.sizeof(L.LnFwdArgs) == 6 * 8 + 2 * 4 + 4 * 4 + 8 + 3 * 8 and C.sizeof(L.LnBwdArgs) == 8 * 8 + 2 * 4 + 6 * 4 + 8 + 3 * 8
+    assert C.sizeof(L.LnFwdArgs) == 6 * 8 + 2 * 4 + 4 * 4 + 8 + 3 * 8 + 8 + 8       # ... x_f32 (+pad), y_f32
+    assert C.sizeof(L.LnBwdArgs) == 8 * 8 + 2 * 4 + 6 * 4 + 8 + 3 * 8 + 8            # ... x_f32 (+pad)
+    assert C.sizeof(L.AttnQuant) == 13 * 8
     lib = L.load()
     g = L.GemmArgs()
     g.M, g.N, g.K = 8, 6, 8            # N % 4 != 0 -> rejected before anything touches a GPU

@@ -85,6 +85,9 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange 2> $O/$
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --grad-dtype fp32 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_forced_exchange_fp32.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-exchange --ghost-ranks 8 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_ghost8.json
 python bench.py --steps 20 --warmup 5 --workload plotqa-real 2> $O/${tag}_bench_n1_plotqa_real.err | grep '^{' > $O/${tag}_bench_n1_plotqa_real.json
-for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32 bench_n1_ghost8 bench_n1_plotqa_real; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
+# the residual stream stored as bf16 (rounds 1 - 5; params['residual_fp32'] = False): the speed the default gives up for its gradient fidelity
+python bench.py --steps 20 --warmup 5 --residual-bf16 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_residual_bf16.json
+python bench.py --steps 20 --warmup 5 --residual-bf16 --no-cpu-baseline --workload plotqa-real 2>/dev/null | grep '^{' > $O/${tag}_bench_n1_plotqa_real_residual_bf16.json
+for f in bench_n1 bench_n1_fp8 bench_n1_fp8_bf16_wgrad bench_n1_fp8_forward_only bench_n1_fp8_bf16_forward bench_n1_longctx bench_n1_longctx_fp8 bench_n1_forced_exchange bench_n1_forced_exchange_pack_all bench_n1_forced_exchange_fp8 bench_n1_forced_exchange_fp32 bench_n1_ghost8 bench_n1_plotqa_real bench_n1_residual_bf16 bench_n1_plotqa_real_residual_bf16; do python -c "import json; d=json.load(open('$O/${tag}_$f.json')); print('$f', round(d['ms_per_step'],3), round(d['value']), 'ffn frac', round(d['roofline']['frac'],4), 'traffic', d['roofline']['traffic'])"; done
 fi
 head -45 $O/${tag}_pmc_sites.txt

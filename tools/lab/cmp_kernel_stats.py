@@ -1,0 +1,12 @@
+import csv, sys, glob
+def load(d):
+    f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+    return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6) for r in csv.DictReader(open(f))}
+a, b = load(sys.argv[1]), load(sys.argv[2])
+print("%-92s %6s %8s %8s %9s" % ("kernel", "calls", "fp32 us", "bf16 us", "d total ms"))
+rows = []
+for k in set(a) | set(b):
+    ca, ua, ta = a.get(k, (0, 0, 0)); cb, ub, tb = b.get(k, (0, 0, 0))
+    rows.append((ta - tb, k, ca, ua, ub))
+for d, k, c, ua, ub in sorted(rows, key=lambda r: -abs(r[0]))[:16]:
+    print("%-92s %6d %8.1f %8.1f %9.2f" % (k[:92], c, ua, ub, d))

@@ -35,10 +35,15 @@ def main():
     model.train()
     cpu = dict(params, device=torch.device("cpu"))
     lib = L.load()
-    seeds = [int(s) for s in sys.argv[1:]] or [1234, 1238]
-    for T, lens, nv in ((112, [112, 64, 87, 99], [44, 29, 37, 44]), (124, [124, 71, 96, 110], [44, 29, 37, 44]), (124, [124] * 4, [44] * 4)):
+    args = sys.argv[1:]
+    short = "short" in args          # "short": configs[1]'s lengths (20 tokens, 36 elements) instead, both kernel families
+    seeds = [int(s) for s in args if s != "short"] or [1234, 1238]
+    cases = ((112, [112, 64, 87, 99], [44, 29, 37, 44]), (124, [124, 71, 96, 110], [44, 29, 37, 44]), (124, [124] * 4, [44] * 4))
+    if short:
+        cases = ((20, [20, 17, 18, 16], [36, 30, 33, 36]),)
+    for T, lens, nv in cases:
         for seed in seeds:
-            batch = S.make_batch(4, T, 44, 1024, seed=seed, lengths=lens, n_vis=nv)
+            batch = S.make_batch(4, T, max(nv), 1024, seed=seed, lengths=lens, n_vis=nv)
             batch["R"][:, 1] = torch.tensor([1.0, 1.0, 0.0, 1.0])
             batch["needs_reg"] = (batch["R"][:, 1:2] == 1)
             sd = seeded_weights(cfg, cpu, base_seed=7)
@@ -56,16 +61,21 @@ def main():
                 return "min %.4f p10 %.4f median %.4f norm %.3f..%.3f" % (cs[0], cs[len(cs) // 10], cs[len(cs) // 2], min(qs), max(qs))
             print("T=%d lens=%s seed=%d  loss oracle %.5f" % (T, lens, seed, float(ref[0])))
             print("   bf16-autocast oracle : " + stats(lambda k: sd16[k].grad.float()))
-            for force in ((0, 1) if T <= 112 else (0,)):
+            modes = [(0, True), (1, True)] if (T <= 112 and not short) else [(0, True)]
+            if short:
+                modes = [(0, False), (0, True)]      # "short": the residual stream stored as bf16 (rounds 1 - 5) against fp32 (CrctStepCfg.residual_fp32)
+            for force, r32 in modes:
                 lib.crct_attention_force_long(force)
+                core.residual_fp32 = r32
                 core.zero_flat_grads()
                 out = step_forward(model, batch, params)
                 out[0].backward()
                 torch.cuda.synchronize()
                 named = dict(core.named_parameters())
-                print("   HIP %-17s: " % ("long kernels" if (force or T > 112) else "short kernels") + stats(lambda k: named[k].grad.float().cpu())
-                      + "  loss %.5f" % float(out[0]))
+                label = ("long kernels" if (force or T > 112) else "short kernels") + ("" if r32 else ", bf16 residual stream")
+                print("   HIP %-38s: " % label + stats(lambda k: named[k].grad.float().cpu()) + "  loss %.5f" % float(out[0]))
             lib.crct_attention_force_long(0)
+            core.residual_fp32 = True
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ def main():
                     "reading the bf16 buffer for EVERY element (the small fp32-accumulated gradients are not in it: wrong numerics)")
     ap.add_argument("--emb-late", type=int, default=0, help="timing only: all but the last N blocks of the embedding segment's AdamW launch run at the "
                     "END of the update sequence (the forward then waits for N blocks only and may read rows that are not updated yet)")
+    ap.add_argument("--residual-bf16", action="store_true", help="the residual stream stored as bf16 (rounds 1 - 5; params['residual_fp32'] = False)")
     ap.add_argument("--batch", type=int, default=80)
     ap.add_argument("--vis", type=int, default=36)
     ap.add_argument("--tokens", type=int, default=20)
@@ -37,6 +38,7 @@ def main():
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False
+    core.residual_fp32 = not a.residual_bf16
     core.stream_mode = (1, 1)
     model.train()
     opt = get_optimizer(params, model)
@@ -91,7 +93,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time emb_late=%d bf16_grads=%s lib=%s: %s ms" % (a.emb_late, a.bf16_grads, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time emb_late=%d bf16_grads=%s residual=%s lib=%s: %s ms" % (a.emb_late, a.bf16_grads, "bf16" if a.residual_bf16 else "fp32", os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":
