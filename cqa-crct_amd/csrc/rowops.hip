@@ -370,6 +370,20 @@ __device__ __forceinline__ void row_store_f32(const Row<NCH>& r, float* p, int H
   }
 }
 
+// streaming form: the fp32 copy of a LayerNorm output is read two kernels later (the next residual GEMM's epilogue), by every XCD --
+// write-through stores leave no dirty L2 lines for the end-of-kernel write-back (-0.1 ms per PlotQA-shaped step, neutral at configs[1])
+template <int NCH>
+__device__ __forceinline__ void row_store_f32_nt(const Row<NCH>& r, float* p, int H, int lane) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      __builtin_nontemporal_store(f4_t{r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]}, reinterpret_cast<f4_t*>(p + c));
+      __builtin_nontemporal_store(f4_t{r.v[i][4], r.v[i][5], r.v[i][6], r.v[i][7]}, reinterpret_cast<f4_t*>(p + c + 4));
+    }
+  }
+}
+
 // table[p][:] += sum of rows[r][:] over the rows r with idx[r] == p   (small tables: position / type / colour
 // embeddings, where thousands of rows hit a few dozen table rows and float atomics serialise).  One workgroup per
 // table row: the 256 threads scan idx in a fixed strided order, compact the matching row numbers into LDS through a
@@ -583,7 +597,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdP& a, const int blk, cons
     row_stats(r, H, lane, a.eps, mean, rstd);
     row_normalize(r, g, b, H, lane, mean, rstd, row, a.thr, a.scale, a.site, a.seed);
     row_store_bf16(r, a.y + row * H, H, lane);
-    if (a.y_f32) row_store_f32(r, a.y_f32 + row * H, H, lane);
+    if (a.y_f32) row_store_f32_nt(r, a.y_f32 + row * H, H, lane);
     if (a.q_out) amax = fmaxf(amax, row_store_fp8(r, a.q_out + row * H, H, lane, qs));     // the fp8 GEMMs' operand (BASELINE configs[4])
     if (lane == 0) { a.mean_o[row] = mean; a.rstd_o[row] = rstd; }
   }
