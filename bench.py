@@ -764,7 +764,8 @@ def main():
             ffn = ffn_roofline(sites, a.profile_steps, kind_peak)
             grp = ffn["fwd_dgrad"]
             dom = max(rows, key=lambda r: r["ms_per_step"])
-            traffic = pmc_traffic(["%s.%s" % (s, k) for s in FFN_SITES for k in ("fwd", "dgrad")], (a.batch, a.vis, a.tokens, a.feat), a.dtype)
+            # the committed PMC tables are of the default step (fp32 residual stream): no traffic figure for the bf16-residual variant
+            traffic = None if a.residual_bf16 else pmc_traffic(["%s.%s" % (s, k) for s in FFN_SITES for k in ("fwd", "dgrad")], (a.batch, a.vis, a.tokens, a.feat), a.dtype)
             out["roofline"] = {"bound": "mfma", "kernel": "FFN GEMMs: text / visual FFN-up + FFN-down, forward + data gradient (%d launches per step)"
                                                              % round(grp["launches_per_step"]),
                                "achieved": grp["tflops"], "peak": grp["peak"], "unit": "TFLOP/s", "frac": grp["frac"], "traffic": traffic,
