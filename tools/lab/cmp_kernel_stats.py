@@ -1,9 +1,12 @@
+"""Lab: two `rocprofv3 --kernel-trace --stats --output-format csv -d <dir>` runs side by side, per kernel: calls, average duration in each,
+difference of the totals -- largest differences first.  Used for the price of the fp32 residual stream per kernel
+(profiles/r6_residual_stream_parity.txt):   python tools/lab/cmp_kernel_stats.py <dir of run A> <dir of run B>"""
 import csv, sys, glob
 def load(d):
     f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
     return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6) for r in csv.DictReader(open(f))}
 a, b = load(sys.argv[1]), load(sys.argv[2])
-print("%-92s %6s %8s %8s %9s" % ("kernel", "calls", "fp32 us", "bf16 us", "d total ms"))
+print("%-92s %6s %8s %8s %9s" % ("kernel", "calls", "A us", "B us", "d total ms"))
 rows = []
 for k in set(a) | set(b):
     ca, ua, ta = a.get(k, (0, 0, 0)); cb, ub, tb = b.get(k, (0, 0, 0))
