@@ -120,9 +120,11 @@ def test_full_depth_model_tracks_the_oracle_over_five_adamw_steps():
     entries are rounding noise in any bf16 pipeline, and a 4-row batch is overfitted within five steps (loss 0.71 -> 0.43), so the
     curve of step 3 onward is one draw of that noise: over five draws this path deviates from the fp32 oracle by 0.2 - 3.8 % at its
     worst step and the fp32 oracle's own bf16-autocast self by 0.3 - 2.9 %, on DIFFERENT draws (profiles/r6_trajectory_draws.txt).
-    Asserted: the first two steps (before the noise is amplified) within 1.5 %; every draw within 5 % at every step; the mean over
-    the draws of the worst deviation within 3 x the bf16-autocast oracle's, computed here on the same draws; final parameters at
-    cosine >= 0.999 per tensor and the 5-step UPDATE of every tensor at median >= 0.90 / 10th percentile >= 0.75 (fixture draw)."""
+    That was measured with the residual stream stored as bf16.  With it in fp32 (CrctStepCfg.residual_fp32, the default since the end of
+    round 6) this path's worst step over the three draws below reads 0.59 % / 0.41 % / 0.16 % (the autocast oracle 0.41 % / 2.59 % / 0.34 %):
+    the 2 % pointwise bound VERDICT r5 asked for holds.  Asserted: the first two steps within 1 %; EVERY step of every draw within 2 %; the
+    mean over the draws of the worst deviation within 1.5 x the bf16-autocast oracle's, computed here on the same draws; final parameters
+    at cosine >= 0.999 per tensor and the 5-step UPDATE of every tensor at median >= 0.90 / 10th percentile >= 0.75 (fixture draw)."""
     torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
     z, meta, cfg, params, batch = load_case("full_B4_V36_T20_F1024")
     draws = [("fixture B4", batch), ("B4 seed 1", S.make_batch(4, 20, 36, 1024, seed=1)), ("B16 seed 4", S.make_batch(16, 20, 36, 1024, seed=4))]
@@ -139,10 +141,10 @@ def test_full_depth_model_tracks_the_oracle_over_five_adamw_steps():
         if name.startswith("fixture"):
             assert abs(ref[0] - float(z["out.loss"])) < 1e-5            # the oracle starts on the reference's own number
             assert med >= 0.90 and p10 >= 0.75, (med, p10, u_cos[:8])
-        assert max(dev[:2]) <= 1.5e-2 and max(dev) <= 5e-2, (name, dev)
+        assert max(dev[:2]) <= 1e-2 and max(dev) <= 2e-2, (name, dev)
         assert p_cos[0][0] >= 0.999, p_cos[:5]
         assert ref[-1] < ref[0] and hip[-1] < hip[0]
         worst_hip.append(max(dev))
         worst_yard.append(max(dev_y))
     print("worst-step deviation per draw: this path %s, bf16-autocast oracle %s" % (np.round(worst_hip, 4).tolist(), np.round(worst_yard, 4).tolist()))
-    assert np.mean(worst_hip) <= 3.0 * np.mean(worst_yard), (worst_hip, worst_yard)
+    assert np.mean(worst_hip) <= 1.5 * np.mean(worst_yard), (worst_hip, worst_yard)
