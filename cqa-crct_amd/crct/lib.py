@@ -164,6 +164,8 @@ PROTOTYPES = {
     "crct_attention_force_split": (None, [C.c_int]),
     "crct_embed_text_fwd": (C.c_int, [vp] * 14 + [C.c_int] * 4 + [c_f32] + _u8 + [vp]),
     "crct_embed_text_bwd": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp, vp, C.c_int, vp]),
+    "crct_embed_word_index": (None, [C.c_int]),
+    "crct_embed_text_bwd_indexed": (C.c_int, [vp] * 16 + [C.c_int] * 4 + _u8 + [vp, vp, C.c_int, vp, C.c_int, vp]),
     "crct_embed_image_fwd": (C.c_int, [vp] * 12 + [C.c_int] * 2 + [c_f32] + _u8 + [vp]),
     "crct_embed_image_bwd": (C.c_int, [vp] * 15 + [C.c_int] * 2 + _u8 + [vp, vp, C.c_int, vp]),
     "crct_head_loss": (C.c_int, [C.POINTER(HeadArgs), vp]),

@@ -142,6 +142,7 @@ struct crct_engine {
   // fp8 forward (BASELINE configs[4]): scale slot of every Linear weight that has an e4m3 shadow, number of activation scale sites
   std::unordered_map<int64_t, int> wq_slot;
   std::unordered_map<size_t, size_t> res32;      // workspace offset of a LayerNorm's bf16 output -> offset of its fp32 copy (fp32 residual stream)
+  int32_t* word_index = nullptr;      // device memory owned by the engine: crct_embed_text_bwd_indexed's first / last row per token id, zero between calls
   std::vector<std::pair<int64_t, int64_t>> wq_list;      // slot -> (flat offset, numel)
   int n_sites = 0;
   int n_gsites = 0;                    // gradient scale sites of the fp8 backward (CrctStepCfg.fp8_grad_scale / _amax)
@@ -776,10 +777,18 @@ struct Run {
     const Drop dt = drop(D.p_hidden, 1);
     layer_begin();
     ++tick;
-    if (!rc) fail(crct_embed_text_bwd(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
-                                      P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
-                                      G(e->et.ln.g), G(e->et.ln.b), F(partials), b->B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
-                                      dt.site, c->seed, F(e->embed_rows[0]), W<int32_t>(e->embed_idx[0]), D.n_types, s));
+    // the word-table index (first / last row per token id) is the ENGINE's memory: it must be zero whenever the call starts -- allocated and
+    // zeroed once, kept zero by the kernels themselves (include/crct_hip.h) -- which a caller-provided workspace cannot promise
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!rc && !e->word_index && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {      // never allocate inside a capture
+      if (hipMalloc((void**)&e->word_index, (size_t)2 * D.vocab * sizeof(int32_t)) != hipSuccess) { e->word_index = nullptr; (void)hipGetLastError(); }
+      else if (hipMemsetAsync(e->word_index, 0, (size_t)2 * D.vocab * sizeof(int32_t), s) != hipSuccess) { crct_set_error("engine: memset of the word index failed"); rc = 1; }
+    }
+    if (!rc) fail(crct_embed_text_bwd_indexed(A(gt), A(e->eta.sum), F(e->eta.mean), F(e->eta.rstd), b->tokens, b->segments, b->loc,
+                                              P(e->et.ln.g), G(e->et.word), G(e->et.pos), G(e->et.type), G(e->et.wloc), G(e->et.bloc),
+                                              G(e->et.ln.g), G(e->et.ln.b), F(partials), b->B, b->T, D.H, D.n_pos, dt.thr, dt.scale,
+                                              dt.site, c->seed, F(e->embed_rows[0]), W<int32_t>(e->embed_idx[0]), D.n_types, e->word_index,
+                                              e->word_index ? D.vocab : 0, s));
   }
   void embed_image_bwd(size_t gv) {
     const CrctModelDims& D = e->d;
@@ -1183,6 +1192,7 @@ extern "C" void crct_engine_destroy(crct_engine_t* e) {
   for (auto ev : e->evpool) (void)hipEventDestroy(ev);
   for (auto st : e->side) if (st) (void)hipStreamDestroy(st);
   if (e->aux) (void)hipStreamDestroy(e->aux);
+  if (e->word_index) (void)hipFree(e->word_index);
   delete e;
 }
 extern "C" size_t crct_engine_workspace_bytes(const crct_engine_t* e) { return e ? e->ws_bytes : 0; }

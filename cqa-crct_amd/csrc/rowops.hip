@@ -554,6 +554,122 @@ __device__ __forceinline__ void word_scatter_body(const float* __restrict__ rows
   }
 }
 
+// The same sums (same owner, same order, same bits) WITHOUT the O(M^2 / 64) scans: the kernel that produced the gradient rows has left,
+// per token id, first[id] = M - (smallest row with this id) and last[id] = (largest such row) + 1 (integer atomic maxima: order-free),
+// in two zero-initialised tables of vocabulary size.  A wave whose row is not its id's first row returns at once; an id that occurs once
+// (nearly all of them) costs its owner one row; otherwise the owner scans ids[r .. last] only, straight from global memory -- no LDS
+// image of all ids (40 KB per workgroup at 9 920 rows), no "does an earlier row carry my id" scan per row.  The owner puts its two table
+// entries back to zero (nobody else reads them any more: a later wave of the same id sees 0 != its own code and returns, as it would
+// have anyway).  embed_scatter: 320 -> 35 us at 9 920 rows, 68 -> 17 us at 1 600 (EXPERIMENTS.md round 6).
+template <int NCH>
+__device__ __forceinline__ void word_scatter_indexed_body(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
+                                                          float* __restrict__ table, int* __restrict__ first, int* __restrict__ last,
+                                                          const int blk, char* smem) {
+  int* list = reinterpret_cast<int*>(smem);              // [M]   matches of a heavy id
+  float* part = reinterpret_cast<float*>(list + ((M + 3) & ~3));      // [4][H] per-wave partial rows of a heavy id
+  __shared__ int s_cnt[ROWS_PER_BLOCK], s_last[ROWS_PER_BLOCK];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blk * ROWS_PER_BLOCK + w;
+  const int id = r < M ? (int)ids[r] : -1;
+  const bool own = r < M && first[id] == M - r;
+  const int l = own ? last[id] - 1 : r;                  // largest row with this id
+  // the ids of (r, l], 256 at a time: four independent loads per lane in flight before the first ballot (the scans are chains of dependent
+  // global loads otherwise: 25 round trips for a [PAD] owner at 1 600 rows)
+  auto hits4 = [&](int base, unsigned long long (&m)[4]) {
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = base + 64 * u + lane; v[u] = (i > r && i <= l) ? (int)ids[i] : -2; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = __ballot(v[u] == id);
+  };
+  int cnt = own ? 1 : 0;
+  if (own && l > r)
+    for (int base = (r + 1) & ~63; base <= l; base += 256) {
+      unsigned long long m[4];
+      hits4(base, m);
+      cnt += __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) + __builtin_popcountll(m[2]) + __builtin_popcountll(m[3]);
+    }
+  if (lane == 0) { s_cnt[w] = cnt; s_last[w] = l; }
+  __syncthreads();
+  if (own && cnt <= WORD_HEAVY) {
+    Row<NCH> acc;
+    row_zero(acc);
+    row_add_f32(acc, rows + (long)r * H, H, lane);
+    if (cnt > 1)
+      for (int base = (r + 1) & ~63; base <= l; base += 256) {
+        unsigned long long m[4];
+        hits4(base, m);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          while (m[u]) {                                 // increasing row order: a fixed summation order
+            const int j = base + 64 * u + __builtin_ctzll(m[u]);
+            m[u] &= m[u] - 1;
+            row_add_f32(acc, rows + (long)j * H, H, lane);
+          }
+      }
+    row_add_f32(acc, table + (long)id * H, H, lane);
+    row_store_f32(acc, table + (long)id * H, H, lane);
+  }
+  if (own && lane == 0) { first[id] = 0; last[id] = 0; }
+  for (int k = 0; k < ROWS_PER_BLOCK; ++k) {             // workgroup-uniform: s_cnt is shared
+    const int n = s_cnt[k];
+    if (n <= WORD_HEAVY) continue;
+    const int rk = blk * ROWS_PER_BLOCK + k, idk = (int)ids[rk], lk = s_last[k];
+    if (w == k) {                                        // here r == rk, id == idk, l == lk: the owner lists itself and its matches
+      int at = 0;
+      if (lane == 0) list[0] = rk;
+      at = 1;
+      for (int base = (rk + 1) & ~63; base <= lk; base += 256) {
+        unsigned long long m[4];
+        hits4(base, m);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if ((m[u] >> lane) & 1ull) list[at + __builtin_popcountll(m[u] & ((1ull << lane) - 1ull))] = base + 64 * u + lane;
+          at += __builtin_popcountll(m[u]);
+        }
+      }
+    }
+    __syncthreads();
+    Row<NCH> a0, a1, a2, a3;
+    row_zero(a0); row_zero(a1); row_zero(a2); row_zero(a3);
+    int e = w * 4;
+    for (; e + 3 < n; e += 16) {
+      const int j0 = list[e], j1 = list[e + 1], j2 = list[e + 2], j3 = list[e + 3];
+      row_add_f32(a0, rows + (long)j0 * H, H, lane);
+      row_add_f32(a1, rows + (long)j1 * H, H, lane);
+      row_add_f32(a2, rows + (long)j2 * H, H, lane);
+      row_add_f32(a3, rows + (long)j3 * H, H, lane);
+    }
+    if (e < n) row_add_f32(a0, rows + (long)list[e] * H, H, lane);
+    if (e + 1 < n) row_add_f32(a1, rows + (long)list[e + 1] * H, H, lane);
+    if (e + 2 < n) row_add_f32(a2, rows + (long)list[e + 2] * H, H, lane);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a0.v[i][j] = (a0.v[i][j] + a1.v[i][j]) + (a2.v[i][j] + a3.v[i][j]);
+    row_store_f32(a0, part + (long)w * H, H, lane);
+    __syncthreads();
+    if (w == k) {
+      Row<NCH> t, u;
+      row_load_f32(t, part, H, lane);
+      row_load_f32(u, part + H, H, lane);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.v[i][j] += u.v[i][j];
+      row_load_f32(u, part + 2 * (long)H, H, lane);
+      Row<NCH> v;
+      row_load_f32(v, part + 3 * (long)H, H, lane);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.v[i][j] += u.v[i][j] + v.v[i][j];
+      row_add_f32(t, table + (long)idk * H, H, lane);
+      row_store_f32(t, table + (long)idk * H, H, lane);
+    }
+    __syncthreads();
+  }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void word_scatter_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int M, int H,
                                                            float* __restrict__ table) {
@@ -566,9 +682,10 @@ template <int NCH>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ rows, const int* __restrict__ idx, int M, int H,
                                                             float* __restrict__ d_pos, int n0, const int* __restrict__ idx1,
                                                             float* __restrict__ d_type, int n_gather, const int64_t* __restrict__ ids,
-                                                            float* __restrict__ d_word) {
+                                                            float* __restrict__ d_word, int* __restrict__ w_first, int* __restrict__ w_last) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < n_gather) gather_sum_body(rows, idx, M, H, d_pos, n0, idx1, d_type, blockIdx.x, smem);
+  else if (w_first) word_scatter_indexed_body<NCH>(rows, ids, M, H, d_word, w_first, w_last, (int)blockIdx.x - n_gather, smem);
   else word_scatter_body<NCH>(rows, ids, M, H, d_word, (int)blockIdx.x - n_gather, smem);
 }
 
@@ -979,7 +1096,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     const float* __restrict__ loc, const float* __restrict__ gamma, float* __restrict__ d_word,
     float* __restrict__ d_pos, float* __restrict__ d_type, float* __restrict__ partials, int B, int T, int H, int n_pos,
     uint32_t thr, float scale, uint32_t site, uint64_t seed, float* __restrict__ rows_scratch, int* __restrict__ idx_scratch,
-    int type_partials) {
+    int type_partials, int* __restrict__ w_first, int* __restrict__ w_last) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long M = (long)B * T;
   Row<NCH> adg, adb, abl, aw0, aw1, aw2, aw3, at0, at1;
@@ -1009,7 +1126,14 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(
     }
     if (rows_scratch) {                                                 // position / type sums: gather_sum_kernel afterwards
       row_store_f32(dy, rows_scratch + row * H, H, lane);
-      if (lane == 0) { idx_scratch[row] = pid; idx_scratch[M + row] = tyid; }
+      if (lane == 0) {
+        idx_scratch[row] = pid; idx_scratch[M + row] = tyid;
+        if (w_first) {                                   // the word scatter's index (word_scatter_indexed_body): first / last row of every id
+          const long id = ids[row];
+          atomicMax(w_first + id, (int)(M - row));
+          atomicMax(w_last + id, (int)row + 1);
+        }
+      }
     } else {
       if (pid >= 0) row_atomic_add(dy, d_pos + (long)pid * H, H, lane);
       if (tyid >= 0) row_atomic_add(dy, d_type + (long)tyid * H, H, lane);
@@ -1522,6 +1646,8 @@ int crct_embed_text_fwd(const int64_t* ids, const int64_t* segs, const float* lo
 
 static int g_embed_scatter_split = 0;
 extern "C" void crct_embed_scatter_split(int on) { g_embed_scatter_split = on ? 1 : 0; }
+static int g_embed_word_index = 1;      // crct_embed_word_index(0): crct_embed_text_bwd_indexed ignores its index (A/B timing, tests; same bits)
+extern "C" void crct_embed_word_index(int on) { g_embed_word_index = on ? 1 : 0; }
 
 extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
                                         const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
@@ -1529,21 +1655,35 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
                                         float* d_gamma, float* d_beta, float* partials, int B, int T, int H, int n_pos,
                                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                                         float* rows_scratch, int32_t* idx_scratch, int n_types, crct_stream_t stream) {
+  return crct_embed_text_bwd_indexed(dy, sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type, d_wloc, d_bloc, d_gamma, d_beta,
+                                     partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch, idx_scratch, n_types, nullptr, 0,
+                                     stream);
+}
+extern "C" int crct_embed_text_bwd_indexed(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
+                                                const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
+                                                float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
+                                                float* d_gamma, float* d_beta, float* partials, int B, int T, int H, int n_pos,
+                                                uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                                                float* rows_scratch, int32_t* idx_scratch, int n_types, int32_t* word_index,
+                                                int n_vocab, crct_stream_t stream) {
   CRCT_REQUIRE(H % 8 == 0 && H > 0, "embed_text_bwd: H=%d must be a positive multiple of 8", H);
   const long M = (long)B * T;
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (!idx_scratch || M > GATHER_MAX_ROWS || n_types <= 0) rows_scratch = nullptr;      // atomics fall-back
   const int nb = embed_bwd_blocks(M);
+  // word_index: int32 [2][n_vocab] (first / last row per id), zero on entry and on exit; without it (or in the two-launch test form) the scanning kernel
+  int* w_first = (rows_scratch && word_index && n_vocab > 0 && !g_embed_scatter_split && g_embed_word_index) ? word_index : nullptr;
+  int* w_last = w_first ? word_index + n_vocab : nullptr;
   const int type_partials = rows_scratch && n_types >= 2 && d_type;     // partials then hold 9 row sets
   DISPATCH_NCH(H, crct_launch((embed_text_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy,
                                      (const bf16_t*)sum_saved, mean, rstd, ids, segs, loc, gamma, d_word, d_pos, d_type,
                                      partials, B, T, H, n_pos, drop_thr, drop_scale, drop_site, seed, rows_scratch,
-                                     rows_scratch ? idx_scratch : nullptr, type_partials));
+                                     rows_scratch ? idx_scratch : nullptr, type_partials, w_first, w_last));
   CRCT_CHECK_HIP(hipGetLastError());
   if (rows_scratch) {
     const int used_pos = n_pos < T ? n_pos : T;            // position ids are clamped to [0, n_pos) and never exceed T - 1
-    const size_t word_lds = (size_t)((2 * M + 3) & ~3L) * sizeof(int) + (size_t)ROWS_PER_BLOCK * H * sizeof(float);     // >= the gather's M ints
+    const size_t word_lds = (size_t)(((w_first ? 1 : 2) * M + 3) & ~3L) * sizeof(int) + (size_t)ROWS_PER_BLOCK * H * sizeof(float);     // >= the gather's M ints
     CRCT_REQUIRE(word_lds <= 152 * 1024, "embed_text_bwd: B*T=%ld rows need %zu bytes of LDS for the word-gradient scan", M, word_lds);
     const int n_gather = used_pos + n_types;
     if (g_embed_scatter_split) {      // test hook: the two launches the merged kernel replaces (same bits)
@@ -1570,7 +1710,8 @@ extern "C" int crct_embed_text_bwd(const void* dy, const void* sum_saved, const 
         big_lds = true;
       }
       crct_launch((embed_scatter_kernel<NCH>), dim3(n_gather + (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), word_lds, s,
-                         (const float*)rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type, n_gather, ids, d_word);
+                         (const float*)rows_scratch, idx_scratch, (int)M, H, d_pos, used_pos, idx_scratch + M, d_type, n_gather, ids, d_word,
+                         w_first, w_last);
     });
     CRCT_CHECK_HIP(hipGetLastError());
   }

@@ -369,6 +369,19 @@ int crct_embed_text_bwd(const void* dy, const void* sum_saved, const float* mean
                         uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
                         float* rows_scratch, int32_t* idx_scratch, int n_types,
                         crct_stream_t stream);
+/* The same with an index for the word-table sums: word_index = int32 [2][n_vocab] in device memory, ALL ZERO on entry and all zero again on
+ * exit (the kernels clean up what they set).  The row kernel leaves the first and last token row of every id there; the scatter kernel then
+ * lets every wave that is not its id's first row return at once and scans only [first, last] for the others -- same owner, same summation
+ * order, same bits as crct_embed_text_bwd, without its scan of all B*T ids per row (B*T = 9 920: 320 -> 35 us).  NULL / n_vocab 0: the scan. */
+void crct_embed_word_index(int on);      /* test / timing hook: 0 = crct_embed_text_bwd_indexed ignores its index (default 1) */
+int crct_embed_text_bwd_indexed(const void* dy, const void* sum_saved, const float* mean, const float* rstd,
+                                const int64_t* ids, const int64_t* segs, const float* loc, const float* gamma,
+                                float* d_word, float* d_pos, float* d_type, float* d_wloc, float* d_bloc,
+                                float* d_gamma, float* d_beta, float* partials,
+                                int B, int T, int H, int n_pos,
+                                uint32_t drop_thr, float drop_scale, uint32_t drop_site, uint64_t seed,
+                                float* rows_scratch, int32_t* idx_scratch, int n_types, int32_t* word_index, int n_vocab,
+                                crct_stream_t stream);
 
 /* Image embeddings: BertImageEmbeddings.forward (dataset 'plotqa'), vilbert.py:1474-1496.
  *  sum = img_lin (bf16 [M][H], = new_image_embeddings(softmax(feat)) from the GEMM) + W_loc loc + b_loc

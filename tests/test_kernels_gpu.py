@@ -810,7 +810,7 @@ def test_fp8_quantisers_and_layernorm_copy():
 
 
 # ------------------------------------------------------------------------------------------- word-gradient scan
-@pytest.mark.parametrize("B,T", [(80, 20), (7, 9), (64, 40)])
+@pytest.mark.parametrize("B,T", [(80, 20), (7, 9), (64, 40), (80, 124)])
 def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T, gemm_path):
     """crct_embed_text_bwd's word_embeddings gradient (index_add of the token-row gradients, vilbert.py:300 has no padding_idx, so
     [PAD] collects every padded position): the fixed-order scan -- light ids by one wave, heavy ids shared by the workgroup --
@@ -833,7 +833,9 @@ def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T,
     gamma = rand(H, seed=5)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def run(deterministic):
+    index = torch.zeros(2 * V, dtype=torch.int32, device=DEV)
+
+    def run(deterministic, indexed=False):
         d_word = torch.zeros(V, H, device=DEV)
         d_pos, d_type = torch.zeros(n_pos, H, device=DEV), torch.zeros(n_types, H, device=DEV)
         d_wloc, d_bloc = torch.zeros(H, 4, device=DEV), torch.zeros(H, device=DEV)
@@ -841,11 +843,18 @@ def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T,
         partials = torch.zeros(10 * 4 * 256 * H, device=DEV)
         rows = torch.zeros(M, H, device=DEV)
         idx = torch.zeros(2 * M, dtype=torch.int32, device=DEV)
-        rc = lib.crct_embed_text_bwd(dy.data_ptr(), saved.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ids.data_ptr(),
-                                     segs.data_ptr(), loc.data_ptr(), gamma.data_ptr(), d_word.data_ptr(), d_pos.data_ptr(),
-                                     d_type.data_ptr(), d_wloc.data_ptr(), d_bloc.data_ptr(), d_g.data_ptr(), d_b.data_ptr(),
-                                     partials.data_ptr(), B, T, H, n_pos, 0, 1.0, 0, 0,
-                                     rows.data_ptr() if deterministic else None, idx.data_ptr(), n_types, stream)
+        if indexed:      # crct_embed_text_bwd_indexed: first / last row per id left by the row kernel, no scan of all ids per row
+            rc = lib.crct_embed_text_bwd_indexed(dy.data_ptr(), saved.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ids.data_ptr(),
+                                                 segs.data_ptr(), loc.data_ptr(), gamma.data_ptr(), d_word.data_ptr(), d_pos.data_ptr(),
+                                                 d_type.data_ptr(), d_wloc.data_ptr(), d_bloc.data_ptr(), d_g.data_ptr(), d_b.data_ptr(),
+                                                 partials.data_ptr(), B, T, H, n_pos, 0, 1.0, 0, 0, rows.data_ptr(), idx.data_ptr(), n_types,
+                                                 index.data_ptr(), V, stream)
+        else:
+            rc = lib.crct_embed_text_bwd(dy.data_ptr(), saved.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ids.data_ptr(),
+                                         segs.data_ptr(), loc.data_ptr(), gamma.data_ptr(), d_word.data_ptr(), d_pos.data_ptr(),
+                                         d_type.data_ptr(), d_wloc.data_ptr(), d_bloc.data_ptr(), d_g.data_ptr(), d_b.data_ptr(),
+                                         partials.data_ptr(), B, T, H, n_pos, 0, 1.0, 0, 0,
+                                         rows.data_ptr() if deterministic else None, idx.data_ptr(), n_types, stream)
         L.check(rc, "embed_text_bwd")
         torch.cuda.synchronize()
         return d_word, d_pos, d_type
@@ -861,12 +870,17 @@ def test_word_gradient_scan_matches_the_atomic_scatter_and_is_reproducible(B, T,
     finally:
         lib.crct_embed_scatter_split(0)
     assert torch.equal(w1, w3) and torch.equal(p1, p3) and torch.equal(t1, t3)
+    # the indexed form (what the step engine calls): same owner, same order, same bits -- twice, and the index is all zero again each time
+    for _ in range(2):
+        w4, p4, t4 = run(True, indexed=True)
+        assert torch.equal(w1, w4) and torch.equal(p1, p4) and torch.equal(t1, t4)
+        assert int(index.abs().max()) == 0
     assert float(w1[0].abs().max()) > 0 and float(w1[V - 1].abs().max()) >= 0
     for a, b in ((w1, w_atomic), (p1, p_atomic), (t1, t_atomic)):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
     untouched = torch.ones(V, dtype=torch.bool, device=DEV)
     untouched[ids.flatten()] = False
-    assert float(w1[untouched].abs().max()) == 0.0
+    assert not bool(untouched.any()) or float(w1[untouched].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------- grouped forward / dgrad pairs

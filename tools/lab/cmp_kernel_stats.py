@@ -1,6 +1,6 @@
 """Lab: two `rocprofv3 --kernel-trace --stats --output-format csv -d <dir>` runs side by side, per kernel: calls, average duration in each,
 difference of the totals -- largest differences first.  Used for the price of the fp32 residual stream per kernel
-(profiles/r6_residual_stream_parity.txt):   python tools/lab/cmp_kernel_stats.py <dir of run A> <dir of run B>"""
+(profiles/r6_residual_stream_parity.txt):   python tools/lab/cmp_kernel_stats.py <dir of run A> <dir of run B> [name filter]"""
 import csv, sys, glob
 def load(d):
     f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
@@ -11,5 +11,7 @@ rows = []
 for k in set(a) | set(b):
     ca, ua, ta = a.get(k, (0, 0, 0)); cb, ub, tb = b.get(k, (0, 0, 0))
     rows.append((ta - tb, k, ca, ua, ub))
-for d, k, c, ua, ub in sorted(rows, key=lambda r: -abs(r[0]))[:16]:
+pick = sys.argv[3] if len(sys.argv) > 3 else None      # optional third argument: only kernels whose name contains it (all of them)
+rows = [r for r in rows if pick in r[1]] if pick else sorted(rows, key=lambda r: -abs(r[0]))[:16]
+for d, k, c, ua, ub in sorted(rows, key=lambda r: -abs(r[0])):
     print("%-92s %6d %8.1f %8.1f %9.2f" % (k[:92], c, ua, ub, d))

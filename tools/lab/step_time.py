@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--emb-late", type=int, default=0, help="timing only: all but the last N blocks of the embedding segment's AdamW launch run at the "
                     "END of the update sequence (the forward then waits for N blocks only and may read rows that are not updated yet)")
     ap.add_argument("--residual-bf16", action="store_true", help="the residual stream stored as bf16 (rounds 1 - 5; params['residual_fp32'] = False)")
+    ap.add_argument("--no-word-index", action="store_true", help="the word-embedding gradient by the scanning kernel (crct_embed_word_index(0)): same bits, round-5 speed")
     ap.add_argument("--batch", type=int, default=80)
     ap.add_argument("--vis", type=int, default=36)
     ap.add_argument("--tokens", type=int, default=20)
@@ -38,6 +39,9 @@ def main():
     model = VisualDialogEncoder(params, config=cfg)
     core = model.bert_pretrained
     core.sync_stats = False
+    if a.no_word_index:
+        from crct import lib as L2
+        L2.load().crct_embed_word_index(0)
     core.residual_fp32 = not a.residual_bf16
     core.stream_mode = (1, 1)
     model.train()
@@ -93,7 +97,7 @@ def main():
             step(i)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / a.steps * 1e3)
-    print("step_time emb_late=%d bf16_grads=%s residual=%s lib=%s: %s ms" % (a.emb_late, a.bf16_grads, "bf16" if a.residual_bf16 else "fp32", os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
+    print("step_time emb_late=%d bf16_grads=%s residual=%s word_index=%d lib=%s: %s ms" % (a.emb_late, a.bf16_grads, "bf16" if a.residual_bf16 else "fp32", not a.no_word_index, os.path.basename(a.lib) or "product", ", ".join("%.3f" % x for x in out)), flush=True)
 
 
 if __name__ == "__main__":
