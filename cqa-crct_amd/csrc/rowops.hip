@@ -56,6 +56,14 @@ __device__ __forceinline__ void row_unpack_bf16(Row<NCH>& r, const RawRow<NCH>& 
     r.v[i][6] = bf2f((bf16_t)(w & 0xffff)); r.v[i][7] = bf2f((bf16_t)(w >> 16));
   }
 }
+// r <- the values its bf16 copy holds (what row_store_bf16 followed by row_load_bf16 of the same row would give, without the round trip)
+template <int NCH>
+__device__ __forceinline__ void row_round_bf16(Row<NCH>& r) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[i][j] = bf2f(f2bf(r.v[i][j]));
+}
 // the same pair for fp32 rows (the pre-LayerNorm sums of the fp32 residual stream)
 template <int NCH>
 struct RawRowF { float4 a[NCH], b[NCH]; };
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(256) void embed_text_fwd_kernel(
     if (fabsf(l[0]) + fabsf(l[1]) + fabsf(l[2]) + fabsf(l[3]) != 0.f) row_add_loc_linear(r, w_loc, b_loc, l, H, lane);
     // the saved pre-norm row is the bf16-rounded one, and the norm is taken over exactly that
     row_store_bf16(r, sum_out + row * H, H, lane);
-    row_load_bf16(r, sum_out + row * H, H, lane);
+    row_round_bf16(r);
     float mean, rstd;
     row_stats(r, H, lane, eps, mean, rstd);
     row_normalize(r, gamma, beta, H, lane, mean, rstd, row, thr, scale, site, seed);
@@ -1178,7 +1186,7 @@ __global__ __launch_bounds__(256) void embed_image_fwd_kernel(
     row_add_loc_linear(r, w_loc, b_loc, l, H, lane);
     row_add_f32(r, color + target[row] * (long)H, H, lane);
     row_store_bf16(r, sum_out + row * H, H, lane);
-    row_load_bf16(r, sum_out + row * H, H, lane);
+    row_round_bf16(r);
     float mean, rstd;
     row_stats(r, H, lane, eps, mean, rstd);
     row_normalize(r, gamma, beta, H, lane, mean, rstd, row, thr, scale, site, seed);
